@@ -1,0 +1,132 @@
+// capi.cpp -- flat C entry points over the C++ host layer, for the Python test and
+// bench harness (ctypes).  Thin: every function forwards to the reference-shaped API
+// declared in include/cobbletrace_host.h.
+#include "cobbletrace_host.h"
+#include "host_internal.h"
+#include "scene_pack.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace {
+
+struct Handle {
+    scene_t scene;
+    bool owns_scene = false;
+    ct::PackedScene packed;
+    environment_t env;
+    bitmapSettings_t bitmap;
+    std::vector<event_t> events;
+};
+
+Handle *H(void *p) { return static_cast<Handle *>(p); }
+
+void ensure_packed(Handle *h) {
+    if (!h->packed.built) h->packed.build_from(&h->scene);
+}
+
+}  // namespace
+
+extern "C" {
+
+void *cth_load_scene(const char *path) {
+    Handle *h = new Handle();
+    std::memset(&h->scene, 0, sizeof h->scene);
+    InitSceneData(&h->scene);
+    std::vector<char> p(path, path + std::strlen(path) + 1);
+    ParseSceneFile(p.data(), &h->scene);
+    h->owns_scene = true;
+    return h;
+}
+
+void *cth_scene_from_vertices(const double *verts, uint32_t n) {
+    Handle *h = new Handle();
+    std::memset(&h->scene, 0, sizeof h->scene);
+    h->packed.build_from_vertices(verts, n);
+    return h;
+}
+
+void cth_free_scene(void *p) {
+    Handle *h = H(p);
+    if (!h) return;
+    if (h->owns_scene) {
+        std::free(h->scene.lightStack.lights);
+        std::free(h->scene.objectStack.objects);
+        std::free(h->scene.triangleLookup.indexes);
+    }
+    delete h;
+}
+
+scene_t *cth_scene_ptr(void *p) { return &H(p)->scene; }
+
+int cth_object_count(void *p) { return H(p)->scene.objectStack.index; }
+int cth_light_count(void *p) { return H(p)->scene.lightStack.index; }
+
+void cth_get_settings(void *p, int *threads, int *subsampling, int *wireframe, int *supersampling) {
+    const settings_t &s = H(p)->scene.settings;
+    *threads = s.numberOfThreads; *subsampling = s.subsampling; *wireframe = s.wireframe;
+    *supersampling = s.supersampling;
+}
+
+void cth_set_settings(void *p, int threads, int subsampling, int supersampling) {
+    settings_t &s = H(p)->scene.settings;
+    if (threads > 0) s.numberOfThreads = threads;
+    if (subsampling >= 0) s.subsampling = subsampling != 0;
+    if (supersampling >= 0) s.supersampling = supersampling != 0;
+}
+
+void cth_get_camera(void *p, double pos[3]) {
+    const v3_t &c = H(p)->scene.camera.position;
+    pos[0] = c.x; pos[1] = c.y; pos[2] = c.z;
+}
+
+int cth_scene_desc(void *p, ctgpu_scene_desc *out) {
+    Handle *h = H(p);
+    ensure_packed(h);
+    *out = h->packed.desc();
+    return 0;
+}
+
+uint32_t cth_tree_depth(void *p) { ensure_packed(H(p)); return H(p)->packed.tree_depth(); }
+
+// Known-answer hashes, defined as in SURVEY.md 8(c).
+uint64_t cth_triangle_hash(void *p) {
+    Handle *h = H(p);
+    ct::Fnv64 f;
+    for (int i = 0; i < h->scene.objectStack.index; i++) {
+        const scene_object_t &o = h->scene.objectStack.objects[i];
+        if (o.type != OT_TRIANGLE) continue;
+        f.bytes(&o.triangle.p1, 24); f.bytes(&o.triangle.p2, 24); f.bytes(&o.triangle.p3, 24);
+        f.bytes(&o.material.color, 4); f.bytes(&o.material.specular, 4); f.bytes(&o.material.reflection, 4);
+    }
+    return f.h;
+}
+
+uint64_t cth_node_hash(void *p) {
+    Handle *h = H(p);
+    ensure_packed(h);
+    ct::Fnv64 f;
+    for (uint32_t i = 0; i < h->packed.bvh.nodesUsed; i++) {
+        const bvh_node_t &n = h->packed.bvh.bvhNodes[i];
+        f.bytes(&n.aabbMin, 24); f.bytes(&n.aabbMax, 24);
+        f.bytes(&n.leftNode, 4); f.bytes(&n.firstTriangleIndex, 4); f.bytes(&n.triangleCount, 4);
+    }
+    return f.h;
+}
+
+uint64_t cth_index_hash(void *p) {
+    Handle *h = H(p);
+    ensure_packed(h);
+    ct::Fnv64 f;
+    f.bytes(h->packed.bvh.triangles.indexes, (size_t)h->packed.bvh.triangles.size * 4);
+    return f.h;
+}
+
+uint64_t cth_fnv1a64(const void *data, uint64_t n) {
+    ct::Fnv64 f;
+    f.bytes(data, (size_t)n);
+    return f.h;
+}
+
+}  // extern "C"

@@ -1,0 +1,179 @@
+// mesh_import.cpp -- OBJ / ASCII-PLY import behind ImportObject (objectLoader.h:4).
+//
+// What must hold for parity (objectLoader.cpp:16-288): every face becomes one
+// OT_TRIANGLE object carrying the import record's material, with vertices
+// transformed in double by row-vector x 4x4 products applied in the order
+// rotate-Y, rotate-X, rotate-Z, scale, translate, each product summed left to
+// right over all four terms; vertex and face numbers are parsed in binary32
+// (TextCursor::number) and widened.
+#include "cobbletrace_host.h"
+#include "host_internal.h"
+#include "text_cursor.h"
+
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace {
+
+using ct::TextCursor;
+
+struct Affine { double m[4][4]; };
+
+// (x y z 1) * M, w dropped (objectLoader.cpp:16-25 with mymath.h:58-66)
+inline v3_t transform(const Affine &a, const v3_t &p) {
+    const double w = 1.0;
+    v3_t r;
+    r.x = p.x * a.m[0][0] + p.y * a.m[1][0] + p.z * a.m[2][0] + w * a.m[3][0];
+    r.y = p.x * a.m[0][1] + p.y * a.m[1][1] + p.z * a.m[2][1] + w * a.m[3][1];
+    r.z = p.x * a.m[0][2] + p.y * a.m[1][2] + p.z * a.m[2][2] + w * a.m[3][2];
+    return r;
+}
+
+Affine identity() {
+    Affine a;
+    std::memset(&a, 0, sizeof a);
+    for (int i = 0; i < 4; i++) a.m[i][i] = 1.0;
+    return a;
+}
+
+// The five placement matrices of objectLoader.cpp:29-119.
+struct Placement {
+    Affine rot_y, rot_x, rot_z, scale, translate;
+
+    Placement(const v3_t &pos, const v3_t &rot, const v3_t &scl) {
+        rot_x = identity();
+        rot_x.m[1][1] = std::cos(rot.x);  rot_x.m[1][2] = -std::sin(rot.x);
+        rot_x.m[2][1] = std::sin(rot.x);  rot_x.m[2][2] = std::cos(rot.x);
+
+        rot_y = identity();
+        rot_y.m[0][0] = std::cos(rot.y);  rot_y.m[0][2] = std::sin(rot.y);
+        rot_y.m[2][0] = -std::sin(rot.y); rot_y.m[2][2] = std::cos(rot.y);
+
+        rot_z = identity();
+        rot_z.m[0][0] = std::cos(rot.z);  rot_z.m[0][1] = -std::sin(rot.z);
+        rot_z.m[1][0] = std::sin(rot.z);  rot_z.m[1][1] = std::cos(rot.z);
+
+        scale = identity();
+        scale.m[0][0] = scl.x; scale.m[1][1] = scl.y; scale.m[2][2] = scl.z;
+
+        translate = identity();
+        translate.m[3][0] = pos.x; translate.m[3][1] = pos.y; translate.m[3][2] = pos.z;
+        translate.m[3][3] = 0.0;   // objectLoader.cpp:119; w is discarded anyway
+    }
+
+    v3_t apply(v3_t p) const {
+        p = transform(rot_y, p);
+        p = transform(rot_x, p);
+        p = transform(rot_z, p);
+        p = transform(scale, p);
+        p = transform(translate, p);
+        return p;
+    }
+};
+
+void emit_triangle(scene_t *scene, const scene_object_t &record, const Placement &place,
+                   const v3_t &a, const v3_t &b, const v3_t &c, TextCursor &tc) {
+    scene_object_t obj = record;      // keeps the material; the union is overwritten below
+    obj.type = OT_TRIANGLE;
+    obj.triangle.p1 = place.apply(a);
+    obj.triangle.p2 = place.apply(b);
+    obj.triangle.p3 = place.apply(c);
+    if (scene->objectStack.index >= scene->objectStack.size) tc.fatal("object stack full");
+    std::memcpy(&scene->objectStack.objects[scene->objectStack.index++], &obj, sizeof obj);
+    scene->triangleLookup.triangleCount++;
+}
+
+std::string resolve(const scene_object_t &record) {
+    std::string name(record.import.filename.data ? record.import.filename.data : "",
+                     (size_t)record.import.filename.size);
+    if (FILE *f = std::fopen(name.c_str(), "rb")) { std::fclose(f); return name; }
+    // not under the working directory: look beside the scene file
+    std::string beside = ct::g_scene_dir + "/" + name;
+    if (FILE *f = std::fopen(beside.c_str(), "rb")) { std::fclose(f); return beside; }
+    return name;
+}
+
+// objectLoader.cpp:142-202 -- ASCII PLY: "element vertex N", "element face M",
+// first three numbers of each vertex line, "3 i j k" face lines.
+void import_ply(const scene_object_t &record, scene_t *scene) {
+    TextCursor tc(resolve(record));
+    if (!tc.ok()) tc.fatal("cannot open mesh");
+    if (tc.bare_word() != "ply") tc.fatal("not a PLY file");
+
+    uint32_t n_vertices = 0, n_faces = 0;
+    while (!tc.at_end()) {
+        std::string word = tc.bare_word();
+        if (word == "element") {
+            word = tc.bare_word();
+            if (word == "vertex") n_vertices = (uint32_t)tc.number();
+            else if (word == "face") n_faces = (uint32_t)tc.number();
+        } else if (word == "end_header") {
+            tc.skip_line();
+            break;
+        }
+    }
+
+    std::vector<v3_t> vertices(n_vertices);
+    for (uint32_t i = 0; i < n_vertices && !tc.at_end(); i++) {
+        double v[3];
+        tc.vec3_bare(v);
+        vertices[i] = v3_t{v[0], v[1], v[2]};
+        tc.skip_line();
+    }
+
+    const Placement place(record.import.position, record.import.rotation, record.import.scale);
+    for (uint32_t i = 0; i < n_faces && !tc.at_end(); i++) {
+        const int corners = (int)tc.number();
+        if (corners != 3) tc.fatal("only triangular faces are supported");
+        double f[3];
+        tc.vec3_bare(f);
+        tc.skip_line();
+        const int ia = (int)f[0], ib = (int)f[1], ic = (int)f[2];
+        if (ia < 0 || ib < 0 || ic < 0 || (uint32_t)ia >= n_vertices || (uint32_t)ib >= n_vertices ||
+            (uint32_t)ic >= n_vertices)
+            tc.fatal("face index out of range");
+        emit_triangle(scene, record, place, vertices[ia], vertices[ib], vertices[ic], tc);
+    }
+}
+
+// objectLoader.cpp:206-279 -- Wavefront OBJ subset: lines starting with a single
+// 'v' or 'f' token carry three numbers; '#' and 'o' lines are skipped; any other
+// byte is consumed one at a time; faces are 1-based; at most 1023 of each.
+void import_obj(const scene_object_t &record, scene_t *scene) {
+    TextCursor tc(resolve(record));
+    if (!tc.ok()) tc.fatal("cannot open mesh");
+
+    const size_t kMax = 1024;
+    std::vector<v3_t> vertices, faces;
+    while (!tc.at_end()) {
+        const char c = tc.token();
+        if (c == '#' || c == 'o') {
+            tc.skip_line();
+        } else if (c == 'v' || c == 'f') {
+            double v[3];
+            tc.vec3_bare(v);
+            std::vector<v3_t> &dst = (c == 'v') ? vertices : faces;
+            dst.push_back(v3_t{v[0], v[1], v[2]});
+            if (dst.size() >= kMax) tc.fatal("OBJ import holds at most 1023 vertices / faces");
+        }
+    }
+    if (faces.empty()) return;
+
+    const Placement place(record.import.position, record.import.rotation, record.import.scale);
+    for (const v3_t &f : faces) {
+        const int ia = (int)f.x - 1, ib = (int)f.y - 1, ic = (int)f.z - 1;
+        if (ia < 0 || ib < 0 || ic < 0 || (size_t)ia >= vertices.size() || (size_t)ib >= vertices.size() ||
+            (size_t)ic >= vertices.size())
+            tc.fatal("face index out of range");
+        emit_triangle(scene, record, place, vertices[ia], vertices[ib], vertices[ic], tc);
+    }
+}
+
+}  // namespace
+
+void ImportObject(scene_object_t importObject, scene_t *scene) {
+    if (importObject.import.format == IT_BLENDER) import_obj(importObject, scene);
+    else if (importObject.import.format == IT_PLY) import_ply(importObject, scene);
+}

@@ -1,0 +1,106 @@
+#include "scene_pack.h"
+
+#include <cstddef>
+#include <cstdlib>
+#include <cstring>
+
+// The C ABI node is the reference node, byte for byte (bvh.h:5-11).
+static_assert(sizeof(bvh_node_t) == sizeof(ctgpu_node), "node size");
+static_assert(offsetof(bvh_node_t, aabbMax) == offsetof(ctgpu_node, bmax), "node layout");
+static_assert(offsetof(bvh_node_t, leftNode) == offsetof(ctgpu_node, left), "node layout");
+static_assert(offsetof(bvh_node_t, firstTriangleIndex) == offsetof(ctgpu_node, first), "node layout");
+static_assert(offsetof(bvh_node_t, triangleCount) == offsetof(ctgpu_node, count), "node layout");
+static_assert(sizeof(light_t) == sizeof(ctgpu_light), "light size");
+static_assert(sizeof(material_t) == sizeof(ctgpu_material), "material size");
+
+namespace ct {
+
+PackedScene::~PackedScene() {
+    std::free(bvh.bvhNodes);
+    std::free(bvh.triangles.indexes);
+}
+
+static void flatten(PackedScene &p) {
+    const size_t n = p.triangles.size();
+    p.vertices.resize(n * 9);
+    for (size_t i = 0; i < n; i++) {
+        const triangle_t &t = p.triangles[i];
+        const double v[9] = {t.p1.x, t.p1.y, t.p1.z, t.p2.x, t.p2.y, t.p2.z, t.p3.x, t.p3.y, t.p3.z};
+        std::memcpy(&p.vertices[i * 9], v, sizeof v);
+    }
+    std::free(p.bvh.bvhNodes);
+    std::free(p.bvh.triangles.indexes);
+    p.bvh = InitializeBVHState(p.triangles.data(), (int)n);
+    BuildBVH(&p.bvh);
+    p.built = true;
+}
+
+void PackedScene::build_from(const scene_t *scene) {
+    triangles.clear();
+    materials.clear();
+    lights.clear();
+    for (int i = 0; i < scene->objectStack.index; i++) {
+        const scene_object_t &o = scene->objectStack.objects[i];
+        if (o.type != OT_TRIANGLE) continue;
+        triangles.push_back(o.triangle);
+        materials.push_back(ctgpu_material{o.material.color, o.material.specular, o.material.reflection});
+    }
+    for (int i = 0; i < scene->lightStack.index; i++) {
+        const light_t &l = scene->lightStack.lights[i];
+        ctgpu_light g;
+        std::memset(&g, 0, sizeof g);
+        g.type = (int32_t)l.type;
+        g.intensity = l.intensity;
+        g.position[0] = l.position.x; g.position[1] = l.position.y; g.position[2] = l.position.z;
+        g.direction[0] = l.direction.x; g.direction[1] = l.direction.y; g.direction[2] = l.direction.z;
+        lights.push_back(g);
+    }
+    flatten(*this);
+}
+
+void PackedScene::build_from_vertices(const double *verts, uint32_t n) {
+    triangles.assign(n, triangle_t{});
+    materials.assign(n, ctgpu_material{0x00ffffffu, -1, 0.0f});
+    lights.clear();
+    for (uint32_t i = 0; i < n; i++) {
+        const double *v = verts + (size_t)i * 9;
+        triangles[i].p1 = v3_t{v[0], v[1], v[2]};
+        triangles[i].p2 = v3_t{v[3], v[4], v[5]};
+        triangles[i].p3 = v3_t{v[6], v[7], v[8]};
+    }
+    flatten(*this);
+}
+
+ctgpu_scene_desc PackedScene::desc() const {
+    ctgpu_scene_desc d;
+    std::memset(&d, 0, sizeof d);
+    d.n_triangles = (uint32_t)triangles.size();
+    d.n_nodes = bvh.nodesUsed;
+    d.n_lights = (uint32_t)lights.size();
+    d.vertices = vertices.data();
+    d.materials = materials.data();
+    d.nodes = reinterpret_cast<const ctgpu_node *>(bvh.bvhNodes);
+    d.indexes = bvh.triangles.indexes;
+    d.lights = lights.data();
+    return d;
+}
+
+uint32_t PackedScene::tree_depth() const {
+    // explicit stack: (node, depth)
+    if (!built || triangles.empty()) return 0;
+    std::vector<std::pair<uint32_t, uint32_t>> todo{{0u, 1u}};
+    uint32_t deepest = 0;
+    while (!todo.empty()) {
+        auto [id, depth] = todo.back();
+        todo.pop_back();
+        if (depth > deepest) deepest = depth;
+        const bvh_node_t &n = bvh.bvhNodes[id];
+        if (n.triangleCount == 0) {
+            todo.push_back({n.leftNode, depth + 1});
+            todo.push_back({n.leftNode + 1, depth + 1});
+        }
+    }
+    return deepest;
+}
+
+}  // namespace ct

@@ -1,0 +1,37 @@
+// scene_pack.h -- turns a parsed scene_t into the flat arrays of ctgpu_scene_desc.
+// This is the work RayThread does once, on its first call (raythread.cpp:647-654:
+// GetSceneTriangles -> InitializeBVHState -> BuildBVH), plus the repacking the
+// C ABI asks for.
+#ifndef CT_SCENE_PACK_H
+#define CT_SCENE_PACK_H
+
+#include "cobbletrace_host.h"
+#include "ctgpu.h"
+
+#include <vector>
+
+namespace ct {
+
+struct PackedScene {
+    std::vector<triangle_t>     triangles;   // the copy the BVH is built over (raythread.cpp:621-639)
+    bvh_state_t                 bvh{};
+    std::vector<double>         vertices;    // [n][9]
+    std::vector<ctgpu_material> materials;   // [n]
+    std::vector<ctgpu_light>    lights;
+    bool                        built = false;
+
+    ~PackedScene();
+    PackedScene() = default;
+    PackedScene(const PackedScene &) = delete;
+    PackedScene &operator=(const PackedScene &) = delete;
+
+    // Gathers the OT_TRIANGLE objects in stack order, builds the BVH, fills the arrays.
+    void build_from(const scene_t *scene);
+    // Same from bare vertices (n x 9 doubles), default material; used by the BvhTest KAT.
+    void build_from_vertices(const double *verts, uint32_t n);
+    ctgpu_scene_desc desc() const;
+    uint32_t tree_depth() const;
+};
+
+}  // namespace ct
+#endif

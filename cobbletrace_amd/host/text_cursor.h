@@ -1,0 +1,57 @@
+// text_cursor.h -- in-memory tokenizer used by the scene and mesh loaders.
+//
+// Behavioural contract (what the reference's windowed reader does on the same
+// bytes, fileBuffer.cpp:21-258), restated over a whole-file buffer:
+//   * white space is ' ', '\t', '\r', '\n'                      (fileBuffer.cpp:37-44)
+//   * "end of input" is position > size, i.e. one position past the last byte is
+//     still readable                                            (fileBuffer.cpp:21-24)
+//     -- the byte seen there is what the reference's 4 KiB window still holds
+//     from the previous block, file[size-4096]; for files shorter than one
+//     window it is indeterminate in the reference and reads as NUL here.
+//   * numbers are accumulated in binary32 exactly as fileBuffer.cpp:160-207 does
+//     (see TextCursor::number).
+#ifndef CT_TEXT_CURSOR_H
+#define CT_TEXT_CURSOR_H
+
+#include <cstddef>
+#include <string>
+#include <vector>
+
+namespace ct {
+
+class TextCursor {
+public:
+    // Loads the whole file; on failure ok() is false.
+    explicit TextCursor(const std::string &path);
+
+    bool ok() const { return ok_; }
+    const std::string &path() const { return path_; }
+    bool at_end() const { return pos_ > data_.size(); }
+
+    void skip_space();
+    void skip_line();                    // to end of line, then over white space
+    char token();                        // next non-space byte (0 at end), consumed
+    void unget() { if (pos_ > 0) --pos_; }
+    void expect(char c);                 // token() must equal c, else fatal()
+    std::string quoted();                // "..." contents; empty at end of input
+    std::string bare_word();             // run of non-space bytes
+    bool boolean();                      // true | false, else fatal()
+    float number();                      // binary32 accumulate, see .cpp
+    void vec3_bracketed(double out[3]);  // [a, b, c]
+    void vec3_bare(double out[3]);       // a b c
+
+    [[noreturn]] void fatal(const std::string &what) const;
+
+private:
+    char peek() const;
+    void advance() { ++pos_; }
+    static bool is_space(char c) { return c == '\n' || c == '\r' || c == ' ' || c == '\t'; }
+
+    std::string path_;
+    std::vector<char> data_;
+    size_t pos_ = 0;
+    bool ok_ = false;
+};
+
+}  // namespace ct
+#endif

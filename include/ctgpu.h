@@ -1,0 +1,170 @@
+/*
+ * ctgpu.h -- C ABI of the MI355X ray-trace library (libctgpu.so).
+ *
+ * This is the boundary a host application binds to in place of CobbleTrace's
+ * Boss/Worker pool.  Plain C: opaque handle, POD descriptors, pointers + sizes,
+ * int status (0 = ok, <0 = error; text via ctgpu_last_error()).
+ *
+ *   entry point                 replaces (reference file:line)
+ *   --------------------------  ----------------------------------------------------------
+ *   ctgpu_upload_scene          GetSceneTriangles + InitializeBVHState hand-over of the
+ *                               triangle / node / index arrays   raythread.cpp:621-654, bvh.cpp:16-28
+ *   ctgpu_render                HandleUpdates dispatch + all RayTracePartition workers for one
+ *                               frame, i.e. the pixel loop -> TraceRay -> ClosestIntersection ->
+ *                               IntersectBVHClosest / ComputeLighting -> CanvasPutPixel
+ *                               raythread.cpp:437-543, 353-386, 197-228, 275-350, 176-184;
+ *                               bvh.cpp:147-222; color.h:18-126; draw2d.h:8-20
+ *   ctgpu_render_partition /    the row-band split of HandleUpdates (raythread.cpp:574-588)
+ *   ctgpu_assemble              re-cut into interleaved row tiles for N GPUs, and the merge of
+ *                               the per-GPU tiles into the caller's framebuffer
+ *   ctgpu_trace_rays            ClosestIntersection on caller-supplied rays (test / KAT hook)
+ *                               raythread.cpp:197-228
+ *   ctgpu_count_work            instrumented run returning node-visit / triangle-test counts
+ *                               (the reference has gprof only)
+ *
+ * Pixel format: uint32 0x00BBGGRR, row-major, top-down, pitch 4*width  (color.h:77-80,
+ * draw2d.h:8-20).  Pixels the reference never writes are never written here either.
+ */
+#ifndef CTGPU_H
+#define CTGPU_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CTGPU_ABI_VERSION 1
+
+typedef struct ctgpu_ctx ctgpu_ctx;
+
+/* ---- status codes ---- */
+#define CTGPU_OK              0
+#define CTGPU_ERR_ARG        -1   /* bad argument / descriptor                      */
+#define CTGPU_ERR_HIP        -2   /* a HIP runtime call failed                      */
+#define CTGPU_ERR_NO_SCENE   -3   /* render before upload                           */
+#define CTGPU_ERR_STACK      -4   /* traversal stack overflow (tree deeper than the
+                                     library's capacity, CTGPU_MAX_TREE_DEPTH)      */
+#define CTGPU_ERR_NO_DEVICE  -5
+
+#define CTGPU_MAX_TREE_DEPTH 64
+
+/* ---- scene (all arrays are copied; the caller keeps ownership) ---- */
+typedef struct ctgpu_material {      /* scenefile.h:25-29 */
+    uint32_t color;                  /* 0x00BBGGRR */
+    int32_t  specular;               /* -1 = no specular term */
+    float    reflection;
+} ctgpu_material;
+
+typedef struct ctgpu_node {          /* bvh.h:5-11, 64 bytes */
+    double   bmin[3], bmax[3];
+    uint32_t left;                   /* left child; right child = left + 1  */
+    uint32_t first;                  /* first slot in indexes[]             */
+    uint32_t count;                  /* >0 = leaf                           */
+    uint32_t pad_;
+} ctgpu_node;
+
+#define CTGPU_LIGHT_POINT       0    /* scenefile.h:13 */
+#define CTGPU_LIGHT_DIRECTIONAL 1
+#define CTGPU_LIGHT_AMBIENT     2
+typedef struct ctgpu_light {         /* scenefile.h:61-66, 56 bytes */
+    int32_t type;
+    float   intensity;
+    double  position[3];
+    double  direction[3];
+} ctgpu_light;
+
+typedef struct ctgpu_scene_desc {
+    uint32_t n_triangles;
+    uint32_t n_nodes;                /* nodesUsed */
+    uint32_t n_lights;
+    uint32_t pad_;
+    const double         *vertices;  /* [n_triangles][9]: p1 p2 p3 in scene-triangle order */
+    const ctgpu_material *materials; /* [n_triangles] */
+    const ctgpu_node     *nodes;     /* [n_nodes], node 0 = root */
+    const uint32_t       *indexes;   /* [n_triangles] leaf slot -> triangle */
+    const ctgpu_light    *lights;    /* [n_lights], file order */
+} ctgpu_scene_desc;
+
+/* ---- frame ---- */
+#define CTGPU_F_SUPERSAMPLE 1u       /* settings.supersampling, raythread.cpp:460-505 */
+#define CTGPU_F_SUBSAMPLE   2u       /* settings.subsampling,   raythread.cpp:512-531 */
+
+#define CTGPU_RNG_HASH 0             /* counter-based jitter, independent of thread count */
+#define CTGPU_RNG_LIBC 1             /* glibc rand() stream in the call order of ONE worker */
+
+typedef struct ctgpu_frame_desc {
+    int32_t  width, height;          /* bitmap size */
+    int32_t  num_threads;            /* T: rows rendered = T * (height / T)  (raythread.cpp:576) */
+    uint32_t flags;                  /* CTGPU_F_* */
+    double   cam_pos[3];             /* camera.position */
+    double   cam_rot[9];             /* camera.rotation, row-major */
+    int32_t  rng_mode;               /* CTGPU_RNG_* (used when supersampling) */
+    int32_t  max_depth;              /* reflection recursion limit; the reference passes 10 */
+    uint64_t rng_seed;               /* HASH: seed.  LIBC: srand() seed (reference default 1) */
+    uint64_t rng_offset;             /* LIBC: rand() calls already consumed by earlier frames */
+} ctgpu_frame_desc;
+
+typedef struct ctgpu_stats {
+    uint64_t rays_primary, rays_shadow, rays_reflect;   /* BVH traversals started */
+    uint64_t pixels_written;
+    uint64_t node_visits, triangle_tests;               /* only from ctgpu_count_work */
+    double   kernel_ms;                                 /* HIP-event time of the trace kernel(s) */
+    double   total_ms;                                  /* dispatch -> pixels in the destination */
+} ctgpu_stats;
+
+/* ---- partition of one frame over several GPUs ---- */
+typedef struct ctgpu_partition {
+    int32_t tile_rows;               /* rows per tile (>=1)                      */
+    int32_t part_index, part_count;  /* this GPU renders tiles t with t % count == index */
+} ctgpu_partition;
+
+/* ---- test hook ---- */
+typedef struct ctgpu_ray { double origin[3]; double direction[3]; float t; uint32_t pad_; } ctgpu_ray;
+typedef struct ctgpu_hit {
+    float    t;          /* ray.t after traversal (1e30f = nothing)   */
+    float    tclosest;   /* 4294967296.f when nothing was recorded    */
+    uint32_t triangle;   /* closestIndex (0 when nothing was recorded)*/
+    uint32_t found;      /* ray.t != 1e30f                            */
+} ctgpu_hit;
+
+/* ---- entry points ---- */
+int  ctgpu_abi_version(void);
+const char *ctgpu_last_error(void);
+int  ctgpu_device_count(int *count);
+
+int  ctgpu_create(int device, ctgpu_ctx **out);
+void ctgpu_destroy(ctgpu_ctx *ctx);
+
+int  ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *scene);
+
+/* One whole frame on this context's GPU into a caller-owned host framebuffer
+ * (width*height uint32).  Synchronous.  stats may be NULL. */
+int  ctgpu_render(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, uint32_t *host_fb, ctgpu_stats *stats);
+
+/* Multi-GPU building blocks (device pointers; `stream` is a hipStream_t or NULL).
+ * ctgpu_partition_pixels: number of uint32 a partition's compact tile buffer holds
+ *   (same for every part_index, so that a gather has equal counts).
+ * ctgpu_render_partition: trace this partition's tiles into d_tiles (asynchronous).
+ * ctgpu_assemble: merge part_count tile buffers laid out back to back in d_all_tiles
+ *   (as an RCCL gather / all-gather leaves them) into the device framebuffer d_fb
+ *   (width*height uint32, pre-filled by the caller with whatever unwritten pixels should show). */
+int  ctgpu_partition_pixels(const ctgpu_frame_desc *frame, const ctgpu_partition *part, uint64_t *count);
+int  ctgpu_render_partition(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, const ctgpu_partition *part,
+                            void *d_tiles, void *stream);
+int  ctgpu_assemble(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, const ctgpu_partition *part,
+                    const void *d_all_tiles, void *d_fb, void *stream);
+/* Ray counters accumulated by render calls since the last read (resets them). Synchronises. */
+int  ctgpu_read_counters(ctgpu_ctx *ctx, ctgpu_stats *stats);
+
+int  ctgpu_trace_rays(ctgpu_ctx *ctx, const ctgpu_ray *rays, uint64_t n, ctgpu_hit *hits);
+
+/* Instrumented render of the same frame (slower; no framebuffer): fills node_visits and
+ * triangle_tests besides the ray counts.  These are the V_r / Q_r sums of the roofline model. */
+int  ctgpu_count_work(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, ctgpu_stats *stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,84 @@
+/*
+ * ct_oracle.h -- CPU ORACLE for the CobbleTrace hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Nothing in the product (cobbletrace_amd/, include/) links, loads or calls this.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it,
+ * and only as the checker / the timed CPU baseline.
+ *
+ * It is a plain-C restatement of the reference's per-pixel loop, written from the
+ * reference's observable arithmetic, each function citing
+ * the reference lines it follows.  It deliberately keeps the reference's shape
+ * (recursive traversal, one OS thread per row band) and none of the GPU design.
+ *
+ * PARITY PIN: the reference cannot be compiled in this image without writing a
+ * stand-in for SDL.h (every translation unit includes it; SDL2 is not installed)
+ * and without patching raythread.cpp:119 (a hard error on g++ 11), so no
+ * oracle/_ref build of the renderer exists.  The oracle is pinned instead
+ * against the reference outputs recorded in SURVEY.md section 8(c) -- FNV-1a-64
+ * hashes of whole framebuffers of the compiled reference for the cube, import and
+ * bunny scenes (ss off at T=8/32, ss on at T=1 with glibc rand()), plus triangle,
+ * node and index hashes and the BvhTest known answer -- see tests/golden/
+ * reference_kat.json and tests/test_oracle_kat.py.  The header-only parts of the
+ * reference that DO compile on their own (mymath.h, color.h) are additionally
+ * compiled in place by oracle/Makefile into oracle/_ref/ and compared function
+ * by function (tests/test_oracle_vs_ref_headers.py).
+ *
+ * Descriptors are shared with include/ctgpu.h so that a test feeds the very same
+ * bytes to the oracle and to the HIP library.
+ */
+#ifndef CT_ORACLE_H
+#define CT_ORACLE_H
+
+#include "../include/ctgpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct cto_options {
+    int32_t os_threads;        /* 0: one thread per band (T threads, like the reference);
+                                  n>0: a pool of n threads pulling bands               */
+    int32_t shadow_early_exit; /* 0: shadow rays traverse fully (reference);
+                                  1: stop at the first ray.t update (what the GPU does;
+                                     same image, fewer visits -- used to cross-check
+                                     the GPU work counters)                            */
+    int32_t count_work;        /* accumulate node_visits / triangle_tests             */
+    int32_t band_first, band_count; /* render only bands [first, first+count); count 0 = all
+                                       (bounded CPU-baseline sample)                   */
+} cto_options;
+
+/* One frame, reference semantics, into fb (width*height uint32; only the pixels the
+ * reference writes are touched).  Returns 0, or <0 on bad arguments. */
+int cto_render(const ctgpu_scene_desc *scene, const ctgpu_frame_desc *frame,
+               const cto_options *opt, uint32_t *fb, ctgpu_stats *stats);
+
+/* ClosestIntersection on caller rays (raythread.cpp:197-228). */
+int cto_trace_rays(const ctgpu_scene_desc *scene, const ctgpu_ray *rays, uint64_t n, ctgpu_hit *hits);
+
+/* Building blocks exposed for unit tests. */
+int      cto_intersect_aabb(const double o[3], const double d[3], float ray_t,
+                            const double bmin[3], const double bmax[3]);          /* bvh.cpp:165-179 */
+int      cto_intersect_triangle(const double o[3], const double d[3], float *ray_t,
+                                const double tri[9]);                              /* bvh.cpp:147-163 */
+uint32_t cto_shade_value(uint32_t material_color, float intensity);               /* color.h:114-126 */
+void     cto_color_to_hsv(uint32_t color, float hsv[3]);                          /* color.h:114-120 */
+uint32_t cto_hsv_to_color(const float hsv[3]);                                    /* color.h:122-126 */
+uint32_t cto_blend_sample(uint32_t accumulated, uint32_t sample);                 /* raythread.cpp:482-498 */
+uint32_t cto_average_pair(uint32_t a, uint32_t b);                                /* raythread.cpp:517-523 */
+uint32_t cto_mix_reflection(uint32_t local, uint32_t reflected, float reflection);/* raythread.cpp:375-379 */
+void     cto_primary_direction(int32_t height, float px, float py, const double rot[9],
+                               double dir[3]);                                    /* raythread.cpp:186-194 */
+void     cto_camera_rotation(float yaw, float pitch, float roll, double rot[9]);  /* raythread.cpp:564-572 */
+/* jitter integers: the value rand() would return for call number k of a frame */
+int32_t  cto_hash_rand(uint64_t seed, uint64_t k);
+uint64_t cto_fnv1a64(const void *data, uint64_t n);
+
+/* BvhTest known answer (bvh.cpp:223-310): 256 triangles from glibc rand() with the
+ * default seed; the caller builds the BVH with the product builder and passes it in. */
+void cto_bvhtest_triangles(double verts[256 * 9]);
+int  cto_bvhtest_render(const ctgpu_scene_desc *scene, uint32_t *fb_640x640, uint64_t *hit_pixels);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
