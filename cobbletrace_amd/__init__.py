@@ -1,0 +1,19 @@
+"""cobbletrace_amd -- MI355X-native ray-trace hot path of CobbleTrace.
+
+The product is two native libraries:
+
+* ``csrc/libctgpu.so``  -- hand-written gfx950 kernels behind the C ABI of ``include/ctgpu.h``
+* ``host/libcthost.so`` -- C++ host layer with the reference's input API
+  (``InitSceneData`` / ``ParseSceneFile`` / ``ImportObject`` / ``BuildBVH``) and the
+  ``RayThread(env, scene)`` drop-in
+
+This Python package is plumbing for the test and bench harness only: ctypes bindings of
+those two libraries.  It never computes pixels itself and it raises if the HIP library
+is missing -- there is no CPU fallback.
+"""
+from .bindings import (  # noqa: F401
+    FrameDesc, Hit, Light, Material, Node, Partition, Ray, SceneDesc, Stats,
+    GpuContext, HostScene, NativeLibraryMissing,
+    F_SUPERSAMPLE, F_SUBSAMPLE, RNG_HASH, RNG_LIBC,
+    gpu_library, host_library, identity_rotation, repo_root,
+)

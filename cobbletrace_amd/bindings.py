@@ -1,0 +1,305 @@
+"""ctypes bindings of libctgpu.so (include/ctgpu.h) and libcthost.so (host/capi.cpp)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+# PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64.  A process can
+# only initialise ONE HIP runtime, and device pointers / streams handed over by torch
+# (bench.py's RCCL gather) must belong to the runtime libctgpu.so talks to.  Importing torch
+# first makes the dynamic loader bind libctgpu.so's NEEDED libamdhip64.so.7 to the copy
+# torch already mapped (same soname) instead of mapping /opt/rocm's next to it.
+try:  # plumbing only: nothing in this package computes with torch
+    import torch  # noqa: F401
+except Exception:  # pragma: no cover - torch-less installs use the system runtime
+    torch = None
+
+F_SUPERSAMPLE, F_SUBSAMPLE = 1, 2
+RNG_HASH, RNG_LIBC = 0, 1
+
+
+class NativeLibraryMissing(RuntimeError):
+    """A native library of the product is not built; nothing can be rendered."""
+
+
+def repo_root():
+    return os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ------------------------------------------------------------------ descriptors (ctgpu.h)
+class Material(C.Structure):
+    _fields_ = [("color", C.c_uint32), ("specular", C.c_int32), ("reflection", C.c_float)]
+
+
+class Node(C.Structure):
+    _fields_ = [("bmin", C.c_double * 3), ("bmax", C.c_double * 3), ("left", C.c_uint32),
+                ("first", C.c_uint32), ("count", C.c_uint32), ("pad_", C.c_uint32)]
+
+
+class Light(C.Structure):
+    _fields_ = [("type", C.c_int32), ("intensity", C.c_float), ("position", C.c_double * 3),
+                ("direction", C.c_double * 3)]
+
+
+class SceneDesc(C.Structure):
+    _fields_ = [("n_triangles", C.c_uint32), ("n_nodes", C.c_uint32), ("n_lights", C.c_uint32),
+                ("pad_", C.c_uint32), ("vertices", C.POINTER(C.c_double)), ("materials", C.POINTER(Material)),
+                ("nodes", C.POINTER(Node)), ("indexes", C.POINTER(C.c_uint32)), ("lights", C.POINTER(Light))]
+
+
+class FrameDesc(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("num_threads", C.c_int32), ("flags", C.c_uint32),
+                ("cam_pos", C.c_double * 3), ("cam_rot", C.c_double * 9), ("rng_mode", C.c_int32),
+                ("max_depth", C.c_int32), ("rng_seed", C.c_uint64), ("rng_offset", C.c_uint64)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("rays_primary", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_reflect", C.c_uint64),
+                ("pixels_written", C.c_uint64), ("node_visits", C.c_uint64), ("triangle_tests", C.c_uint64),
+                ("kernel_ms", C.c_double), ("total_ms", C.c_double)]
+
+    @property
+    def rays(self):
+        return self.rays_primary + self.rays_shadow + self.rays_reflect
+
+
+class Partition(C.Structure):
+    _fields_ = [("tile_rows", C.c_int32), ("part_index", C.c_int32), ("part_count", C.c_int32)]
+
+
+class Ray(C.Structure):
+    _fields_ = [("origin", C.c_double * 3), ("direction", C.c_double * 3), ("t", C.c_float), ("pad_", C.c_uint32)]
+
+
+class Hit(C.Structure):
+    _fields_ = [("t", C.c_float), ("tclosest", C.c_float), ("triangle", C.c_uint32), ("found", C.c_uint32)]
+
+
+RAY_DTYPE = np.dtype([("origin", "<f8", 3), ("direction", "<f8", 3), ("t", "<f4"), ("pad_", "<u4")])
+HIT_DTYPE = np.dtype([("t", "<f4"), ("tclosest", "<f4"), ("triangle", "<u4"), ("found", "<u4")])
+
+
+def identity_rotation():
+    """camera.rotation at yaw = pitch = roll = 0: identity with [2][0] = -0.0 (raythread.cpp:564-572)."""
+    return (C.c_double * 9)(1.0, 0.0, 0.0, 0.0, 1.0, 0.0, -0.0, 0.0, 1.0)
+
+
+# ------------------------------------------------------------------ library loading
+_GPU_SYMBOLS = {
+    # name: (restype, argtypes)
+    "ctgpu_abi_version": (C.c_int, []),
+    "ctgpu_last_error": (C.c_char_p, []),
+    "ctgpu_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "ctgpu_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "ctgpu_destroy": (None, [C.c_void_p]),
+    "ctgpu_upload_scene": (C.c_int, [C.c_void_p, C.POINTER(SceneDesc)]),
+    "ctgpu_render": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.c_void_p, C.POINTER(Stats)]),
+    "ctgpu_partition_pixels": (C.c_int, [C.POINTER(FrameDesc), C.POINTER(Partition), C.POINTER(C.c_uint64)]),
+    "ctgpu_render_partition": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.POINTER(Partition), C.c_void_p, C.c_void_p]),
+    "ctgpu_assemble": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.POINTER(Partition), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ctgpu_read_counters": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
+    "ctgpu_trace_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "ctgpu_count_work": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.POINTER(Stats)]),
+    "ctgpu_rand_stream": (C.c_int, [C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p]),
+}
+
+_HOST_SYMBOLS = {
+    "cth_load_scene": (C.c_void_p, [C.c_char_p]),
+    "cth_scene_from_vertices": (C.c_void_p, [C.c_void_p, C.c_uint32]),
+    "cth_free_scene": (None, [C.c_void_p]),
+    "cth_object_count": (C.c_int, [C.c_void_p]),
+    "cth_light_count": (C.c_int, [C.c_void_p]),
+    "cth_get_settings": (None, [C.c_void_p] + [C.POINTER(C.c_int)] * 4),
+    "cth_set_settings": (None, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "cth_get_camera": (None, [C.c_void_p, C.POINTER(C.c_double)]),
+    "cth_get_rotation": (None, [C.c_void_p, C.POINTER(C.c_double)]),
+    "cth_scene_desc": (C.c_int, [C.c_void_p, C.POINTER(SceneDesc)]),
+    "cth_tree_depth": (C.c_uint32, [C.c_void_p]),
+    "cth_triangle_hash": (C.c_uint64, [C.c_void_p]),
+    "cth_node_hash": (C.c_uint64, [C.c_void_p]),
+    "cth_index_hash": (C.c_uint64, [C.c_void_p]),
+    "cth_fnv1a64": (C.c_uint64, [C.c_void_p, C.c_uint64]),
+    "cth_raythread_options": (None, [C.c_int, C.c_uint64, C.c_int]),
+    "cth_raythread_reset": (None, []),
+    "cth_raythread_frames": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_char_p]),
+    "cth_last_frame_stats": (None, [C.POINTER(Stats)]),
+}
+
+_cache = {}
+
+
+def _load(path, symbols, what):
+    if path in _cache:
+        return _cache[path]
+    if not os.path.exists(path):
+        raise NativeLibraryMissing(
+            "%s not found at %s -- build it first (python -c 'import __graft_entry__ as g; g.build()')" % (what, path))
+    lib = C.CDLL(path)
+    for name, (restype, argtypes) in symbols.items():
+        fn = getattr(lib, name)        # AttributeError here = the library does not export what the header declares
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _cache[path] = lib
+    return lib
+
+
+def gpu_library_path():
+    return os.environ.get("CTGPU_LIBRARY", os.path.join(repo_root(), "cobbletrace_amd", "csrc", "libctgpu.so"))
+
+
+def host_library_path():
+    return os.path.join(repo_root(), "cobbletrace_amd", "host", "libcthost.so")
+
+
+def gpu_library():
+    return _load(gpu_library_path(), _GPU_SYMBOLS, "HIP library libctgpu.so")
+
+
+def host_library():
+    return _load(host_library_path(), _HOST_SYMBOLS, "host library libcthost.so")
+
+
+# ------------------------------------------------------------------ host scene
+class HostScene:
+    """A scene parsed and BVH-built by the C++ host layer."""
+
+    def __init__(self, path=None, vertices=None):
+        self.lib = host_library()
+        if path is not None:
+            if not os.path.exists(path):
+                raise FileNotFoundError(path)
+            self.handle = C.c_void_p(self.lib.cth_load_scene(os.fsencode(path)))
+        else:
+            v = np.ascontiguousarray(vertices, dtype=np.float64).reshape(-1, 9)
+            self._keep = v
+            self.handle = C.c_void_p(self.lib.cth_scene_from_vertices(v.ctypes.data, v.shape[0]))
+        self._desc = None
+
+    def close(self):
+        if self.handle:
+            self.lib.cth_free_scene(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def desc(self):
+        if self._desc is None:
+            d = SceneDesc()
+            self.lib.cth_scene_desc(self.handle, C.byref(d))
+            self._desc = d
+        return self._desc
+
+    @property
+    def settings(self):
+        vals = [C.c_int() for _ in range(4)]
+        self.lib.cth_get_settings(self.handle, *[C.byref(v) for v in vals])
+        return dict(numberOfThreads=vals[0].value, subsampling=bool(vals[1].value), wireframe=bool(vals[2].value),
+                    supersampling=bool(vals[3].value))
+
+    def set_settings(self, threads=0, subsampling=-1, supersampling=-1):
+        self.lib.cth_set_settings(self.handle, int(threads), int(subsampling), int(supersampling))
+
+    @property
+    def camera(self):
+        p = (C.c_double * 3)()
+        self.lib.cth_get_camera(self.handle, p)
+        return tuple(p)
+
+    def frame(self, width, height, threads=None, supersampling=None, subsampling=None, rng_mode=RNG_HASH,
+              rng_seed=0, rng_offset=0, rotation=None, max_depth=10):
+        """FrameDesc for this scene's camera; unspecified settings come from the scene file."""
+        s = self.settings
+        f = FrameDesc()
+        f.width, f.height = width, height
+        f.num_threads = s["numberOfThreads"] if threads is None else threads
+        ss = s["supersampling"] if supersampling is None else supersampling
+        sub = s["subsampling"] if subsampling is None else subsampling
+        f.flags = (F_SUPERSAMPLE if ss else 0) | (F_SUBSAMPLE if sub else 0)
+        f.cam_pos = (C.c_double * 3)(*self.camera)
+        f.cam_rot = rotation if rotation is not None else identity_rotation()
+        f.rng_mode, f.rng_seed, f.rng_offset, f.max_depth = rng_mode, rng_seed, rng_offset, max_depth
+        return f
+
+    # arrays as numpy views (owned by the handle)
+    def nodes(self):
+        d = self.desc
+        return np.ctypeslib.as_array(C.cast(d.nodes, C.POINTER(C.c_uint8)), shape=(d.n_nodes, 64))
+
+    def indexes(self):
+        d = self.desc
+        return np.ctypeslib.as_array(d.indexes, shape=(d.n_triangles,))
+
+    def vertices(self):
+        d = self.desc
+        return np.ctypeslib.as_array(d.vertices, shape=(d.n_triangles, 9))
+
+
+# ------------------------------------------------------------------ GPU context
+class GpuContext:
+    """One ctgpu_ctx: a scene resident on one MI355X."""
+
+    def __init__(self, device=0):
+        self.lib = gpu_library()
+        h = C.c_void_p()
+        self._check(self.lib.ctgpu_create(device, C.byref(h)))
+        self.handle = h
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError("ctgpu error %d: %s" % (rc, (self.lib.ctgpu_last_error() or b"").decode()))
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.ctgpu_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, scene_desc):
+        self._check(self.lib.ctgpu_upload_scene(self.handle, C.byref(scene_desc)))
+
+    def render(self, frame, fb=None):
+        """Whole frame -> (uint32 [H, W] array, Stats)."""
+        if fb is None:
+            fb = np.zeros((frame.height, frame.width), dtype=np.uint32)
+        st = Stats()
+        self._check(self.lib.ctgpu_render(self.handle, C.byref(frame), fb.ctypes.data, C.byref(st)))
+        return fb, st
+
+    def count_work(self, frame):
+        st = Stats()
+        self._check(self.lib.ctgpu_count_work(self.handle, C.byref(frame), C.byref(st)))
+        return st
+
+    def trace_rays(self, rays):
+        rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+        hits = np.zeros(rays.shape[0], dtype=HIT_DTYPE)
+        self._check(self.lib.ctgpu_trace_rays(self.handle, rays.ctypes.data, rays.shape[0], hits.ctypes.data))
+        return hits
+
+    def partition_pixels(self, frame, part):
+        n = C.c_uint64()
+        self._check(self.lib.ctgpu_partition_pixels(C.byref(frame), C.byref(part), C.byref(n)))
+        return n.value
+
+    def render_partition(self, frame, part, d_tiles_ptr, stream_ptr=None):
+        self._check(self.lib.ctgpu_render_partition(self.handle, C.byref(frame), C.byref(part), C.c_void_p(d_tiles_ptr),
+                                                    C.c_void_p(stream_ptr or 0)))
+
+    def assemble(self, frame, part, d_all_tiles_ptr, d_fb_ptr, stream_ptr=None):
+        self._check(self.lib.ctgpu_assemble(self.handle, C.byref(frame), C.byref(part), C.c_void_p(d_all_tiles_ptr),
+                                            C.c_void_p(d_fb_ptr), C.c_void_p(stream_ptr or 0)))
+
+    def read_counters(self):
+        st = Stats()
+        self._check(self.lib.ctgpu_read_counters(self.handle, C.byref(st)))
+        return st

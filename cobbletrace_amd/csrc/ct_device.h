@@ -1,0 +1,198 @@
+// ct_device.h -- device-side data layout and exact-arithmetic building blocks (gfx950).
+//
+// Arithmetic contract (D = binary64 op, F = rounded to binary32):
+// every function below performs the reference's operations in the reference's order
+// and precision.  The translation unit is compiled with -ffp-contract=off so no
+// mul+add pair is fused; f64 divide / sqrt are the correctly rounded expansions.
+#ifndef CT_DEVICE_H
+#define CT_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ctd {
+
+// ---------------------------------------------------------------- HBM layout
+// One record per INNER node of the reference tree, 128-byte aligned so a visit is a
+// single L2 line: both children's boxes (the reference tests a child's box when it
+// enters the child, bvh.cpp:202; testing both when the parent is opened is the same
+// arithmetic on the same operands -- the right child's `tmin < ray.t` term is
+// re-evaluated with the then-current ray.t when it is popped).
+struct alignas(128) WideNode {
+    double lmin[3], lmax[3];      // left child box   (bvh_node_t.aabbMin/aabbMax)
+    double rmin[3], rmax[3];      // right child box
+    uint32_t lref, rref;          // child reference: inner -> WideNode index
+                                  //                  leaf  -> kLeafBit | first slot in TriRecord[]
+    uint32_t pad_[6];
+};
+static_assert(sizeof(WideNode) == 128, "WideNode must be one 128-byte line");
+
+// One record per triangle, stored in LEAF ORDER (the order of bvh indexes[]), so a leaf
+// is a contiguous run and no index indirection is needed while traversing.
+// e1 = p2 - p1 and e2 = p3 - p1 are the D differences the reference recomputes on every
+// test (bvh.cpp:148-149); storing them is bit-identical.
+struct alignas(16) TriRecord {
+    double p1[3], e1[3], e2[3];
+    uint32_t triangle;            // index in scene-triangle order (closestIndex value)
+    uint32_t remaining;           // triangles from this slot to the end of its leaf (>=1)
+};
+static_assert(sizeof(TriRecord) == 80, "TriRecord is five 16-byte loads");
+
+static constexpr uint32_t kLeafBit = 0x80000000u;
+static constexpr uint32_t kNoNode = 0xffffffffu;
+
+struct Material { uint32_t color; int32_t specular; float reflection; };
+struct Light { int32_t type; float intensity; double position[3]; double direction[3]; };
+
+// ---------------------------------------------------------------- vectors
+struct d3 { double x, y, z; };
+
+__device__ __forceinline__ d3 make_d3(double x, double y, double z) { d3 r; r.x = x; r.y = y; r.z = z; return r; }
+__device__ __forceinline__ d3 load_d3(const double *p) { return make_d3(p[0], p[1], p[2]); }
+__device__ __forceinline__ d3 operator+(d3 a, d3 b) { return make_d3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ d3 operator-(d3 a, d3 b) { return make_d3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ d3 operator-(d3 a) { return make_d3(-a.x, -a.y, -a.z); }
+__device__ __forceinline__ d3 scale(double s, d3 a) { return make_d3(s * a.x, s * a.y, s * a.z); }
+// mymath.h:229-232 -- D products, D sums left to right, result F
+__device__ __forceinline__ float dotf(d3 a, d3 b) { return (float)(a.x * b.x + a.y * b.y + a.z * b.z); }
+// mymath.h:213-216 -- F(sqrt_D(...))
+__device__ __forceinline__ float lengthf(d3 a) { return (float)__builtin_sqrt(a.x * a.x + a.y * a.y + a.z * a.z); }
+// mymath.h:234-242
+__device__ __forceinline__ d3 cross(d3 a, d3 b) {
+    return make_d3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+// the reference's min/max macros (mymath.h:11-17): NaN in `a` selects b
+__device__ __forceinline__ float lesser(float a, float b) { return (a < b) ? a : b; }
+__device__ __forceinline__ float greater(float a, float b) { return (a > b) ? a : b; }
+
+static constexpr float kNoHit = 1e30f;
+static constexpr float kFarAway = 4294967296.0f;
+static constexpr uint32_t kBackground = 0x333333u;
+
+// ---------------------------------------------------------------- slab test (bvh.cpp:165-179)
+// Returns the F entry/exit parameters; the caller applies
+//   tmax >= tmin && tmin < ray.t && tmax > 0.
+__device__ __forceinline__ void slab(const d3 &o, const d3 &d, const double *bmin, const double *bmax,
+                                     float &tmin, float &tmax) {
+    const float tx1 = (float)((bmin[0] - o.x) / d.x);
+    const float tx2 = (float)((bmax[0] - o.x) / d.x);
+    tmin = lesser(tx1, tx2);
+    tmax = greater(tx1, tx2);
+    const float ty1 = (float)((bmin[1] - o.y) / d.y);
+    const float ty2 = (float)((bmax[1] - o.y) / d.y);
+    tmin = greater(tmin, lesser(ty1, ty2));
+    tmax = lesser(tmax, greater(ty1, ty2));
+    const float tz1 = (float)((bmin[2] - o.z) / d.z);
+    const float tz2 = (float)((bmax[2] - o.z) / d.z);
+    tmin = greater(tmin, lesser(tz1, tz2));
+    tmax = lesser(tmax, greater(tz1, tz2));
+}
+
+// ---------------------------------------------------------------- triangle test (bvh.cpp:147-163)
+// Returns true exactly when the reference's IntersectTriangle returns true; ray_t is
+// lowered only when t > 0.0001f.
+__device__ __forceinline__ bool triangle_test(const d3 &o, const d3 &d, float &ray_t, const d3 &p1, const d3 &e1,
+                                              const d3 &e2) {
+    const d3 h = cross(d, e2);
+    const float a = dotf(e1, h);
+    if (a > -0.0001f && a < 0.0001f) return false;
+    const float f = 1.0f / a;
+    const d3 s = o - p1;
+    const float u = f * dotf(s, h);
+    if (u < 0 || u > 1) return false;
+    const d3 q = cross(s, e1);
+    const float v = f * dotf(d, q);
+    if (v < 0 || u + v > 1) return false;
+    const float t = f * dotf(e2, q);
+    if (t > 0.0001f) ray_t = lesser(ray_t, t);
+    return true;
+}
+
+// ---------------------------------------------------------------- colour (color.h:18-126)
+__device__ __forceinline__ uint32_t pack_u8(uint32_t r, uint32_t g, uint32_t b) { return (b << 16) | (g << 8) | r; }
+// float -> uint8 conversion of a non-negative value, truncating (values here are in [0,255])
+__device__ __forceinline__ uint32_t to_u8(float c) { return (uint32_t)(int)c & 0xffu; }
+__device__ __forceinline__ uint32_t to_u8(double c) { return (uint32_t)(int)c & 0xffu; }
+
+// ColorToHsv . (v := value) . HsvToColor   (color.h:114-126, 49-75, 18-45)
+__device__ __forceinline__ uint32_t shade_value(uint32_t material_color, float value) {
+    const float r = (float)(material_color & 0xff) / 255.0f;
+    const float g = (float)((material_color >> 8) & 0xff) / 255.0f;
+    const float b = (float)((material_color >> 16) & 0xff) / 255.0f;
+    const float hi = greater(r, greater(g, b));
+    const float lo = lesser(r, lesser(g, b));
+    const float delta = hi - lo;
+    float h = -1.0f, s = 0.0f;
+    if (hi != 0.0f) {
+        s = delta / hi;
+        if (r == hi) h = (g - b) / delta;
+        else if (g == hi) h = 2.0f + (b - r) / delta;
+        else h = 4.0f + (r - g) / delta;
+        h = (float)((double)h * 60.0);
+        if (h < 0) h = (float)((double)h + 360.0);
+    }
+    float cr, cg, cb;
+    if (s == 0) {
+        cr = cg = cb = value;
+    } else {
+        h = (float)((double)h / 60.0);
+        const int sector = (int)floorf(h);
+        const float frac = h - (float)sector;
+        const float aa = value * (1.0f - s);
+        const float bb = value * (1.0f - (s * frac));
+        const float cc = value * (1.0f - (s * (1.0f - frac)));
+        cr = cg = cb = 0.0f;
+        switch (sector) {
+            case 0: cr = value; cg = cc; cb = aa; break;
+            case 1: cr = bb; cg = value; cb = aa; break;
+            case 2: cr = aa; cg = value; cb = cc; break;
+            case 3: cr = aa; cg = bb; cb = value; break;
+            case 4: cr = cc; cg = aa; cb = value; break;
+            case 5: cr = value; cg = aa; cb = bb; break;
+        }
+    }
+    return pack_u8(to_u8(lesser(cr * 255.0f, 255.0f)), to_u8(lesser(cg * 255.0f, 255.0f)),
+                   to_u8(lesser(cb * 255.0f, 255.0f)));
+}
+
+// supersample running blend (raythread.cpp:482-498)
+__device__ __forceinline__ uint32_t blend_channel(uint32_t acc, uint32_t smp) {
+    float c = (float)acc;
+    c -= (c / 8.0f);
+    c += ((float)smp / 8.0f);
+    return to_u8(c);
+}
+__device__ __forceinline__ uint32_t blend_sample(uint32_t acc, uint32_t smp) {
+    return pack_u8(blend_channel(acc & 0xff, smp & 0xff), blend_channel((acc >> 8) & 0xff, (smp >> 8) & 0xff),
+                   blend_channel((acc >> 16) & 0xff, (smp >> 16) & 0xff));
+}
+// subsample in-between pixel (raythread.cpp:517-523)
+__device__ __forceinline__ uint32_t average_channel(uint32_t a, uint32_t b) {
+    return to_u8(lesser(((float)a + (float)b) / 2.0f, 255.0f));
+}
+__device__ __forceinline__ uint32_t average_pair(uint32_t a, uint32_t b) {
+    return pack_u8(average_channel(a & 0xff, b & 0xff), average_channel((a >> 8) & 0xff, (b >> 8) & 0xff),
+                   average_channel((a >> 16) & 0xff, (b >> 16) & 0xff));
+}
+// reflection mix (raythread.cpp:375-379)
+__device__ __forceinline__ uint32_t mix_channel(uint32_t l, uint32_t r, double keep, double take) {
+    return to_u8(keep * (double)l + take * (double)r);
+}
+__device__ __forceinline__ uint32_t mix_reflection(uint32_t local, uint32_t reflected, float reflection) {
+    const double keep = (double)(1.0f - reflection), take = (double)reflection;
+    return pack_u8(mix_channel(local & 0xff, reflected & 0xff, keep, take),
+                   mix_channel((local >> 8) & 0xff, (reflected >> 8) & 0xff, keep, take),
+                   mix_channel((local >> 16) & 0xff, (reflected >> 16) & 0xff, keep, take));
+}
+
+// jitter integers, counter based (CTGPU_RNG_HASH); same function as the oracle's
+__device__ __forceinline__ int32_t hash_rand(uint64_t seed, uint64_t k) {
+    uint64_t z = (seed + 1u) * 0x9E3779B97F4A7C15ull + k;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (int32_t)(z >> 33);
+}
+
+}  // namespace ctd
+#endif

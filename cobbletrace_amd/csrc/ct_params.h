@@ -1,0 +1,58 @@
+// ct_params.h -- kernel argument block and launcher prototypes shared by ct_kernels.hip
+// (device) and ctgpu_api.hip (host side of the C ABI).
+#ifndef CT_PARAMS_H
+#define CT_PARAMS_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "ctgpu.h"
+#include "ct_device.h"
+
+namespace ctd {
+
+struct FrameParams {
+    // scene (device pointers)
+    const WideNode  *nodes;
+    const TriRecord *tris;
+    const Material  *materials;
+    const Light     *lights;
+    uint32_t n_lights;
+    uint32_t root_ref;            // WideNode index, or kLeafBit|0 when the whole tree is one leaf
+    uint32_t slot_of_triangle0;   // TriRecord slot holding scene triangle 0
+    uint32_t stack_depth;         // LDS stack entries per lane
+    double   root_min[3], root_max[3];
+
+    // frame
+    int32_t  width, height, half; // bitmap size; half = height/2
+    uint32_t square;              // 2*half: columns (and at most rows) of the rendered square
+    uint32_t rendered_rows;       // T * (height/T)
+    uint32_t rows_per_band;       // height/T
+    uint32_t subsample;
+    float    inv_height;          // 1.f/(float)height
+    int32_t  max_depth;
+    double   cam[3], rot[9];
+    int32_t  rng_mode;
+    uint32_t traced_rows;         // LIBC: number of traced rows (row ordinals)
+    uint64_t rng_seed;
+    const int32_t *rand_table;    // LIBC: rand() values in single-worker call order
+    const int32_t *row_ordinal;   // LIBC: traced-row ordinal per frame row
+
+    // partition
+    uint32_t tile_rows, part_index, part_count;
+    uint32_t local_rows;          // rows of one partition's compact buffer (equal for all partitions)
+
+    // divergence policy: run phase A/B/C once this many lanes wait for it
+    int32_t thresh_a, thresh_b, thresh_c;
+
+    // outputs
+    uint32_t *out;                         // [local_rows][square]
+    unsigned long long *counters;          // primary, shadow, reflect, visits, tests
+    uint32_t *overflow;                    // set to 1 on traversal-stack overflow
+};
+
+void launch_trace_tiles(const FrameParams &P, uint32_t n_tiles, bool ss, bool reflect, bool count, hipStream_t stream);
+void launch_trace_ray_list(const FrameParams &P, const ctgpu_ray *rays, uint64_t n, ctgpu_hit *hits, hipStream_t stream);
+void launch_assemble(const FrameParams &P, const uint32_t *all_tiles, uint32_t *fb, hipStream_t stream);
+
+}  // namespace ctd
+#endif

@@ -1,0 +1,562 @@
+// ctgpu_api.hip -- host side of the C ABI declared in include/ctgpu.h.
+//
+// Owns the device copies of the scene (re-laid-out for coalesced 128-byte node lines and
+// leaf-ordered triangle records, see ct_device.h), the per-frame scratch buffers, and the
+// launches of ct_kernels.hip.  No compute happens on the host: without a HIP device every
+// entry point that needs one returns an error.
+#include "ct_params.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace ctd;
+
+// ------------------------------------------------------------------ error plumbing
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(CTGPU_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));  \
+    } while (0)
+
+// ------------------------------------------------------------------ context
+template <typename T>
+struct DeviceArray {
+    T *ptr = nullptr;
+    size_t count = 0;
+    hipError_t resize(size_t n) {
+        if (n <= count && ptr) return hipSuccess;
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr; count = 0;
+        hipError_t e = hipMalloc((void **)&ptr, std::max<size_t>(n, 1) * sizeof(T));
+        if (e == hipSuccess) count = n;
+        return e;
+    }
+    void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; count = 0; }
+};
+
+struct ctgpu_ctx {
+    int device = 0;
+    bool has_scene = false;
+    bool has_reflection = false;
+    uint32_t n_triangles = 0, n_lights = 0, tree_depth = 0;
+    uint32_t root_ref = 0, slot_of_triangle0 = 0;
+    double root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
+
+    DeviceArray<WideNode> nodes;
+    DeviceArray<TriRecord> tris;
+    DeviceArray<Material> materials;
+    DeviceArray<Light> lights;
+
+    DeviceArray<uint32_t> tiles;       // compact tile buffer of a whole-frame render
+    DeviceArray<uint32_t> fb;          // device framebuffer of ctgpu_render
+    DeviceArray<unsigned long long> counters;   // 8 words
+    DeviceArray<uint32_t> overflow;    // 1 word
+    DeviceArray<int32_t> rand_table;   // LIBC jitter stream
+    DeviceArray<int32_t> row_ordinal;
+    uint64_t rand_key[4] = {~0ull, ~0ull, ~0ull, ~0ull};   // (seed, offset, count, rows) of the cached table
+
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int thresh[3] = {40, 20, 12};
+};
+
+// ------------------------------------------------------------------ glibc rand() stream
+// The reference draws its supersample jitter from libc rand() (raythread.cpp:470-471).
+// glibc's default generator is the TYPE_3 additive-feedback generator of random_r.c
+// (glibc 2.35): state r[0..33] seeded by the Lehmer sequence 16807*x mod (2^31-1),
+// 310 outputs discarded, then o_k = (r[k-31] + r[k-3]) >> 1 on 32-bit words.
+extern "C" int ctgpu_rand_stream(uint32_t seed, uint64_t offset, uint64_t n, int32_t *out) {
+    if (!out && n) return fail(CTGPU_ERR_ARG, "ctgpu_rand_stream: null output");
+    if (seed == 0) seed = 1;
+    uint32_t r[34];
+    r[0] = seed;
+    for (int i = 1; i < 31; i++) {
+        const int32_t prev = (int32_t)r[i - 1];
+        const int32_t hi = prev / 127773, lo = prev % 127773;
+        int32_t word = 16807 * lo - 2836 * hi;
+        if (word < 0) word += 2147483647;
+        r[i] = (uint32_t)word;
+    }
+    for (int i = 31; i < 34; i++) r[i] = r[i - 31];
+    // ring of the last 34 words
+    uint32_t ring[34];
+    for (int i = 0; i < 34; i++) ring[i] = r[i];
+    uint64_t produced = 34;
+    auto next = [&]() -> uint32_t {
+        const uint32_t v = ring[(produced - 31) % 34] + ring[(produced - 3) % 34];
+        ring[produced % 34] = v;
+        produced++;
+        return v;
+    };
+    for (int i = 34; i < 344; i++) (void)next();
+    for (uint64_t i = 0; i < offset; i++) (void)next();
+    for (uint64_t i = 0; i < n; i++) out[i] = (int32_t)(next() >> 1);
+    return CTGPU_OK;
+}
+
+// ------------------------------------------------------------------ basic entry points
+extern "C" int ctgpu_abi_version(void) { return CTGPU_ABI_VERSION; }
+extern "C" const char *ctgpu_last_error(void) { return g_last_error.c_str(); }
+
+extern "C" int ctgpu_device_count(int *count) {
+    if (!count) return fail(CTGPU_ERR_ARG, "ctgpu_device_count: null argument");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(CTGPU_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = n;
+    return CTGPU_OK;
+}
+
+extern "C" int ctgpu_create(int device, ctgpu_ctx **out) {
+    if (!out) return fail(CTGPU_ERR_ARG, "ctgpu_create: null argument");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(CTGPU_ERR_NO_DEVICE, "no HIP device is visible");
+    if (device < 0 || device >= n) return fail(CTGPU_ERR_ARG, "device %d out of range (0..%d)", device, n - 1);
+    HIP_TRY(hipSetDevice(device));
+    ctgpu_ctx *ctx = new ctgpu_ctx();
+    ctx->device = device;
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&ctx->ev0));
+    HIP_TRY(hipEventCreate(&ctx->ev1));
+    HIP_TRY(ctx->counters.resize(8));
+    HIP_TRY(ctx->overflow.resize(1));
+    HIP_TRY(hipMemset(ctx->counters.ptr, 0, 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(ctx->overflow.ptr, 0, sizeof(uint32_t)));
+    if (const char *t = std::getenv("CTGPU_THRESH")) {   // tuning knob: "a,b,c"
+        int a, b, c;
+        if (std::sscanf(t, "%d,%d,%d", &a, &b, &c) == 3) { ctx->thresh[0] = a; ctx->thresh[1] = b; ctx->thresh[2] = c; }
+    }
+    *out = ctx;
+    return CTGPU_OK;
+}
+
+extern "C" void ctgpu_destroy(ctgpu_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->nodes.release(); ctx->tris.release(); ctx->materials.release(); ctx->lights.release();
+    ctx->tiles.release(); ctx->fb.release(); ctx->counters.release(); ctx->overflow.release();
+    ctx->rand_table.release(); ctx->row_ordinal.release();
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+// ------------------------------------------------------------------ scene upload
+extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
+    if (!ctx || !s) return fail(CTGPU_ERR_ARG, "ctgpu_upload_scene: null argument");
+    if (s->n_triangles == 0 || s->n_nodes == 0 || !s->vertices || !s->materials || !s->nodes || !s->indexes)
+        return fail(CTGPU_ERR_ARG, "ctgpu_upload_scene: empty scene or null array");
+    if (s->n_lights && !s->lights) return fail(CTGPU_ERR_ARG, "ctgpu_upload_scene: null light array");
+    if (s->n_nodes > 2u * s->n_triangles) return fail(CTGPU_ERR_ARG, "ctgpu_upload_scene: more nodes than 2N-1");
+    HIP_TRY(hipSetDevice(ctx->device));
+
+    const uint32_t N = s->n_triangles, M = s->n_nodes;
+    // validate the tree before trusting it on the device: child links and leaf ranges in range
+    for (uint32_t i = 0; i < M; i++) {
+        const ctgpu_node &n = s->nodes[i];
+        if (n.count == 0) {
+            if (n.left == 0 || (uint64_t)n.left + 1 >= M) return fail(CTGPU_ERR_ARG, "node %u: child link out of range", i);
+        } else if ((uint64_t)n.first + n.count > N) {
+            return fail(CTGPU_ERR_ARG, "node %u: leaf range out of range", i);
+        }
+    }
+    for (uint32_t i = 0; i < N; i++)
+        if (s->indexes[i] >= N) return fail(CTGPU_ERR_ARG, "indexes[%u] out of range", i);
+
+    // inner nodes get consecutive WideNode slots in reference order
+    std::vector<uint32_t> wide_of(M, kNoNode);
+    uint32_t n_wide = 0;
+    for (uint32_t i = 0; i < M; i++)
+        if (s->nodes[i].count == 0) wide_of[i] = n_wide++;
+
+    auto child_ref = [&](uint32_t id) -> uint32_t {
+        const ctgpu_node &c = s->nodes[id];
+        return c.count ? (kLeafBit | c.first) : wide_of[id];
+    };
+
+    std::vector<WideNode> wide(std::max<uint32_t>(n_wide, 1));
+    std::memset(wide.data(), 0, wide.size() * sizeof(WideNode));
+    for (uint32_t i = 0; i < M; i++) {
+        const ctgpu_node &n = s->nodes[i];
+        if (n.count) continue;
+        WideNode &w = wide[wide_of[i]];
+        const ctgpu_node &l = s->nodes[n.left], &r = s->nodes[n.left + 1];
+        std::memcpy(w.lmin, l.bmin, 24); std::memcpy(w.lmax, l.bmax, 24);
+        std::memcpy(w.rmin, r.bmin, 24); std::memcpy(w.rmax, r.bmax, 24);
+        w.lref = child_ref(n.left);
+        w.rref = child_ref(n.left + 1);
+    }
+
+    // leaf-ordered triangle records; a tree walk gives depth and the leaf extents
+    std::vector<TriRecord> recs(N);
+    std::vector<uint32_t> remaining(N, 1);
+    uint32_t depth = 0;
+    {
+        std::vector<std::pair<uint32_t, uint32_t>> todo;
+        todo.push_back({0u, 1u});
+        size_t visited = 0;
+        while (!todo.empty()) {
+            const auto [id, d] = todo.back();
+            todo.pop_back();
+            if (++visited > M) return fail(CTGPU_ERR_ARG, "node links form a cycle");
+            depth = std::max(depth, d);
+            const ctgpu_node &n = s->nodes[id];
+            if (n.count) {
+                for (uint32_t k = 0; k < n.count; k++) remaining[n.first + k] = n.count - k;
+            } else {
+                todo.push_back({n.left, d + 1});
+                todo.push_back({n.left + 1, d + 1});
+            }
+        }
+    }
+    if (depth > CTGPU_MAX_TREE_DEPTH) return fail(CTGPU_ERR_STACK, "tree depth %u exceeds %d", depth, CTGPU_MAX_TREE_DEPTH);
+
+    uint32_t slot0 = 0;
+    for (uint32_t slot = 0; slot < N; slot++) {
+        const uint32_t tri = s->indexes[slot];
+        const double *v = s->vertices + (size_t)tri * 9;
+        TriRecord &t = recs[slot];
+        for (int c = 0; c < 3; c++) {
+            t.p1[c] = v[c];
+            t.e1[c] = v[3 + c] - v[c];      // p2 - p1, as bvh.cpp:148
+            t.e2[c] = v[6 + c] - v[c];      // p3 - p1, as bvh.cpp:149
+        }
+        t.triangle = tri;
+        t.remaining = remaining[slot];
+        if (tri == 0) slot0 = slot;
+    }
+
+    bool reflective = false;
+    for (uint32_t i = 0; i < N; i++) reflective = reflective || (s->materials[i].reflection > 0);
+
+    HIP_TRY(ctx->nodes.resize(wide.size()));
+    HIP_TRY(ctx->tris.resize(N));
+    HIP_TRY(ctx->materials.resize(N));
+    HIP_TRY(ctx->lights.resize(std::max<uint32_t>(s->n_lights, 1)));
+    HIP_TRY(hipMemcpy(ctx->nodes.ptr, wide.data(), wide.size() * sizeof(WideNode), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(ctx->tris.ptr, recs.data(), (size_t)N * sizeof(TriRecord), hipMemcpyHostToDevice));
+    static_assert(sizeof(Material) == sizeof(ctgpu_material), "material layout");
+    static_assert(sizeof(Light) == sizeof(ctgpu_light), "light layout");
+    HIP_TRY(hipMemcpy(ctx->materials.ptr, s->materials, (size_t)N * sizeof(Material), hipMemcpyHostToDevice));
+    if (s->n_lights)
+        HIP_TRY(hipMemcpy(ctx->lights.ptr, s->lights, (size_t)s->n_lights * sizeof(Light), hipMemcpyHostToDevice));
+
+    ctx->n_triangles = N;
+    ctx->n_lights = s->n_lights;
+    ctx->tree_depth = depth;
+    ctx->root_ref = s->nodes[0].count ? (kLeafBit | s->nodes[0].first) : wide_of[0];
+    ctx->slot_of_triangle0 = slot0;
+    std::memcpy(ctx->root_min, s->nodes[0].bmin, 24);
+    std::memcpy(ctx->root_max, s->nodes[0].bmax, 24);
+    ctx->has_reflection = reflective;
+    ctx->has_scene = true;
+    return CTGPU_OK;
+}
+
+// ------------------------------------------------------------------ frame geometry
+namespace {
+
+struct Geometry {
+    int32_t half;
+    uint32_t square, rows_per_band, rendered_rows;
+};
+
+int check_frame(const ctgpu_frame_desc *f) {
+    if (!f) return fail(CTGPU_ERR_ARG, "null frame descriptor");
+    if (f->width <= 0 || f->height <= 1 || f->width > 65536 || f->height > 65536)
+        return fail(CTGPU_ERR_ARG, "bitmap size %dx%d not supported", f->width, f->height);
+    if (f->num_threads <= 0 || f->num_threads > f->height)
+        return fail(CTGPU_ERR_ARG, "num_threads %d must be in 1..height", f->num_threads);
+    if (f->rng_mode != CTGPU_RNG_HASH && f->rng_mode != CTGPU_RNG_LIBC) return fail(CTGPU_ERR_ARG, "unknown rng_mode");
+    if (f->max_depth < 0 || f->max_depth > 10) return fail(CTGPU_ERR_ARG, "max_depth must be 0..10");
+    return CTGPU_OK;
+}
+
+Geometry geometry(const ctgpu_frame_desc *f) {
+    Geometry g;
+    g.half = f->height / 2;
+    g.square = (uint32_t)(2 * g.half);
+    g.rows_per_band = (uint32_t)(f->height / f->num_threads);
+    g.rendered_rows = (uint32_t)f->num_threads * g.rows_per_band;
+    return g;
+}
+
+int check_partition(const ctgpu_partition *p) {
+    if (!p) return fail(CTGPU_ERR_ARG, "null partition");
+    if (p->tile_rows < 1 || p->part_count < 1 || p->part_index < 0 || p->part_index >= p->part_count)
+        return fail(CTGPU_ERR_ARG, "bad partition (tile_rows %d, part %d of %d)", p->tile_rows, p->part_index, p->part_count);
+    return CTGPU_OK;
+}
+
+uint32_t local_rows_of(const Geometry &g, const ctgpu_partition *p) {
+    const uint32_t tiles = (g.rendered_rows + (uint32_t)p->tile_rows - 1u) / (uint32_t)p->tile_rows;
+    const uint32_t per_part = (tiles + (uint32_t)p->part_count - 1u) / (uint32_t)p->part_count;
+    return per_part * (uint32_t)p->tile_rows;
+}
+
+// rows a frame traces, in single-worker order (for the LIBC jitter stream)
+void traced_row_ordinals(const ctgpu_frame_desc *f, const Geometry &g, std::vector<int32_t> &ordinal, uint32_t &n) {
+    ordinal.assign(std::max<uint32_t>(g.rendered_rows, 1), -1);
+    n = 0;
+    const bool sub = (f->flags & CTGPU_F_SUBSAMPLE) != 0;
+    for (uint32_t y = 0; y < g.rendered_rows; y++) {
+        const uint32_t off = y % g.rows_per_band;
+        const bool traced = !sub || ((off & 1u) == 0u) || (off == g.rows_per_band - 1u);
+        if (traced) ordinal[y] = (int32_t)n++;
+    }
+}
+
+int fill_params(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, const ctgpu_partition *part, bool count_mode,
+                FrameParams &P) {
+    const Geometry g = geometry(f);
+    std::memset(&P, 0, sizeof P);
+    P.nodes = ctx->nodes.ptr; P.tris = ctx->tris.ptr; P.materials = ctx->materials.ptr; P.lights = ctx->lights.ptr;
+    P.n_lights = ctx->n_lights;
+    P.root_ref = ctx->root_ref;
+    P.slot_of_triangle0 = ctx->slot_of_triangle0;
+    // pending right siblings never exceed the tree depth; COUNT mode also parks rejected ones
+    P.stack_depth = std::max<uint32_t>(ctx->tree_depth, 2);
+    (void)count_mode;
+    std::memcpy(P.root_min, ctx->root_min, 24);
+    std::memcpy(P.root_max, ctx->root_max, 24);
+    P.width = f->width; P.height = f->height; P.half = g.half;
+    P.square = g.square; P.rendered_rows = g.rendered_rows; P.rows_per_band = g.rows_per_band;
+    P.subsample = (f->flags & CTGPU_F_SUBSAMPLE) ? 1u : 0u;
+    P.inv_height = 1.0f / (float)f->height;
+    P.max_depth = f->max_depth;
+    std::memcpy(P.cam, f->cam_pos, 24);
+    std::memcpy(P.rot, f->cam_rot, 72);
+    P.rng_mode = f->rng_mode;
+    P.rng_seed = f->rng_seed;
+    P.tile_rows = (uint32_t)part->tile_rows; P.part_index = (uint32_t)part->part_index; P.part_count = (uint32_t)part->part_count;
+    P.local_rows = local_rows_of(g, part);
+    P.thresh_a = ctx->thresh[0]; P.thresh_b = ctx->thresh[1]; P.thresh_c = ctx->thresh[2];
+    P.counters = ctx->counters.ptr;
+    P.overflow = ctx->overflow.ptr;
+
+    if ((f->flags & CTGPU_F_SUPERSAMPLE) && f->rng_mode == CTGPU_RNG_LIBC) {
+        std::vector<int32_t> ordinal;
+        uint32_t n_rows = 0;
+        traced_row_ordinals(f, g, ordinal, n_rows);
+        const uint64_t n = (uint64_t)g.square * n_rows * 32u;
+        const uint64_t key[4] = {f->rng_seed, f->rng_offset, n, ((uint64_t)n_rows << 32) | g.rendered_rows | ((uint64_t)P.subsample << 63)};
+        if (std::memcmp(key, ctx->rand_key, sizeof key) != 0) {
+            std::vector<int32_t> table(std::max<uint64_t>(n, 1));
+            int rc = ctgpu_rand_stream((uint32_t)f->rng_seed, f->rng_offset, n, table.data());
+            if (rc) return rc;
+            HIP_TRY(ctx->rand_table.resize(table.size()));
+            HIP_TRY(ctx->row_ordinal.resize(ordinal.size()));
+            HIP_TRY(hipMemcpy(ctx->rand_table.ptr, table.data(), table.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(ctx->row_ordinal.ptr, ordinal.data(), ordinal.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            std::memcpy(ctx->rand_key, key, sizeof key);
+        }
+        P.rand_table = ctx->rand_table.ptr;
+        P.row_ordinal = ctx->row_ordinal.ptr;
+        P.traced_rows = n_rows;
+    }
+    return CTGPU_OK;
+}
+
+uint32_t tile_count(const FrameParams &P) { return ((P.square + 7u) / 8u) * ((P.local_rows + 7u) / 8u); }
+
+int check_overflow(ctgpu_ctx *ctx) {
+    uint32_t flag = 0;
+    HIP_TRY(hipMemcpy(&flag, ctx->overflow.ptr, sizeof flag, hipMemcpyDeviceToHost));
+    if (flag) {
+        HIP_TRY(hipMemset(ctx->overflow.ptr, 0, sizeof flag));
+        return fail(CTGPU_ERR_STACK, "traversal stack overflow (tree depth %u)", ctx->tree_depth);
+    }
+    return CTGPU_OK;
+}
+
+int read_counters(ctgpu_ctx *ctx, ctgpu_stats *st) {
+    unsigned long long c[8];
+    HIP_TRY(hipMemcpy(c, ctx->counters.ptr, sizeof c, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(ctx->counters.ptr, 0, sizeof c));
+    if (st) {
+        st->rays_primary = c[0]; st->rays_shadow = c[1]; st->rays_reflect = c[2];
+        st->node_visits = c[3]; st->triangle_tests = c[4];
+    }
+    return CTGPU_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ multi-GPU building blocks
+extern "C" int ctgpu_partition_pixels(const ctgpu_frame_desc *frame, const ctgpu_partition *part, uint64_t *count) {
+    if (!count) return fail(CTGPU_ERR_ARG, "ctgpu_partition_pixels: null argument");
+    int rc = check_frame(frame); if (rc) return rc;
+    rc = check_partition(part); if (rc) return rc;
+    const Geometry g = geometry(frame);
+    *count = (uint64_t)local_rows_of(g, part) * g.square;
+    return CTGPU_OK;
+}
+
+extern "C" int ctgpu_render_partition(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, const ctgpu_partition *part,
+                                      void *d_tiles, void *stream) {
+    if (!ctx || !d_tiles) return fail(CTGPU_ERR_ARG, "ctgpu_render_partition: null argument");
+    if (!ctx->has_scene) return fail(CTGPU_ERR_NO_SCENE, "no scene uploaded");
+    int rc = check_frame(frame); if (rc) return rc;
+    rc = check_partition(part); if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    FrameParams P;
+    rc = fill_params(ctx, frame, part, false, P); if (rc) return rc;
+    P.out = (uint32_t *)d_tiles;
+    const bool ss = (frame->flags & CTGPU_F_SUPERSAMPLE) != 0;
+    launch_trace_tiles(P, tile_count(P), ss, ctx->has_reflection && frame->max_depth > 0, false, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return CTGPU_OK;
+}
+
+extern "C" int ctgpu_assemble(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, const ctgpu_partition *part,
+                              const void *d_all_tiles, void *d_fb, void *stream) {
+    if (!ctx || !d_all_tiles || !d_fb) return fail(CTGPU_ERR_ARG, "ctgpu_assemble: null argument");
+    int rc = check_frame(frame); if (rc) return rc;
+    rc = check_partition(part); if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    FrameParams P;
+    ctgpu_frame_desc plain = *frame;
+    plain.flags &= ~CTGPU_F_SUPERSAMPLE;            // the jitter table is not needed here
+    rc = fill_params(ctx, &plain, part, false, P); if (rc) return rc;
+    launch_assemble(P, (const uint32_t *)d_all_tiles, (uint32_t *)d_fb, (hipStream_t)stream);
+    HIP_TRY(hipGetLastError());
+    return CTGPU_OK;
+}
+
+extern "C" int ctgpu_read_counters(ctgpu_ctx *ctx, ctgpu_stats *stats) {
+    if (!ctx || !stats) return fail(CTGPU_ERR_ARG, "ctgpu_read_counters: null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipDeviceSynchronize());
+    std::memset(stats, 0, sizeof *stats);
+    int rc = read_counters(ctx, stats); if (rc) return rc;
+    return check_overflow(ctx);
+}
+
+// ------------------------------------------------------------------ whole frame on one GPU
+extern "C" int ctgpu_render(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, uint32_t *host_fb, ctgpu_stats *stats) {
+    if (!ctx || !host_fb) return fail(CTGPU_ERR_ARG, "ctgpu_render: null argument");
+    if (!ctx->has_scene) return fail(CTGPU_ERR_NO_SCENE, "no scene uploaded");
+    int rc = check_frame(frame); if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const auto t0 = std::chrono::steady_clock::now();
+
+    const ctgpu_partition whole = {8, 0, 1};
+    const Geometry g = geometry(frame);
+    FrameParams P;
+    rc = fill_params(ctx, frame, &whole, false, P); if (rc) return rc;
+    HIP_TRY(ctx->tiles.resize((size_t)P.local_rows * P.square));
+    HIP_TRY(ctx->fb.resize((size_t)frame->width * frame->height));
+    P.out = ctx->tiles.ptr;
+
+    const bool ss = (frame->flags & CTGPU_F_SUPERSAMPLE) != 0;
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    launch_trace_tiles(P, tile_count(P), ss, ctx->has_reflection && frame->max_depth > 0, false, ctx->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    launch_assemble(P, ctx->tiles.ptr, ctx->fb.ptr, ctx->stream);
+    HIP_TRY(hipGetLastError());
+
+    // copy back exactly the rectangle the reference writes: rendered rows x square columns,
+    // clipped to the bitmap (raythread.cpp:176-184, draw2d.h:8-20)
+    const int row_hi = frame->height / 2 + g.half;                        // y = -half
+    const int row_lo = frame->height / 2 + g.half - (int)g.rendered_rows + 1;
+    const int r0 = std::max(row_lo, 0), r1 = std::min(row_hi, frame->height - 1);
+    const int c0 = std::max(frame->width / 2 - g.half, 0), c1 = std::min(frame->width / 2 + g.half - 1, frame->width - 1);
+    if (r1 >= r0 && c1 >= c0) {
+        const size_t off = (size_t)r0 * frame->width + c0;
+        HIP_TRY(hipMemcpy2DAsync(host_fb + off, (size_t)frame->width * 4, ctx->fb.ptr + off, (size_t)frame->width * 4,
+                                 (size_t)(c1 - c0 + 1) * 4, (size_t)(r1 - r0 + 1), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    const auto t1 = std::chrono::steady_clock::now();
+
+    ctgpu_stats st;
+    std::memset(&st, 0, sizeof st);
+    rc = read_counters(ctx, &st); if (rc) return rc;
+    rc = check_overflow(ctx); if (rc) return rc;
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    st.kernel_ms = ms;
+    st.total_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    st.pixels_written = (r1 >= r0 && c1 >= c0) ? (uint64_t)(r1 - r0 + 1) * (uint64_t)(c1 - c0 + 1) : 0;
+    if (stats) *stats = st;
+    return CTGPU_OK;
+}
+
+extern "C" int ctgpu_count_work(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, ctgpu_stats *stats) {
+    if (!ctx || !stats) return fail(CTGPU_ERR_ARG, "ctgpu_count_work: null argument");
+    if (!ctx->has_scene) return fail(CTGPU_ERR_NO_SCENE, "no scene uploaded");
+    int rc = check_frame(frame); if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const ctgpu_partition whole = {8, 0, 1};
+    FrameParams P;
+    rc = fill_params(ctx, frame, &whole, true, P); if (rc) return rc;
+    HIP_TRY(ctx->tiles.resize((size_t)P.local_rows * P.square));
+    P.out = ctx->tiles.ptr;
+    HIP_TRY(hipMemsetAsync(ctx->counters.ptr, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    const bool ss = (frame->flags & CTGPU_F_SUPERSAMPLE) != 0;
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    launch_trace_tiles(P, tile_count(P), ss, ctx->has_reflection && frame->max_depth > 0, true, ctx->stream);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    std::memset(stats, 0, sizeof *stats);
+    rc = read_counters(ctx, stats); if (rc) return rc;
+    rc = check_overflow(ctx); if (rc) return rc;
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    stats->kernel_ms = ms;
+    return CTGPU_OK;
+}
+
+// ------------------------------------------------------------------ test hook
+extern "C" int ctgpu_trace_rays(ctgpu_ctx *ctx, const ctgpu_ray *rays, uint64_t n, ctgpu_hit *hits) {
+    if (!ctx || (n && (!rays || !hits))) return fail(CTGPU_ERR_ARG, "ctgpu_trace_rays: null argument");
+    if (!ctx->has_scene) return fail(CTGPU_ERR_NO_SCENE, "no scene uploaded");
+    if (n == 0) return CTGPU_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    ctgpu_frame_desc f;
+    std::memset(&f, 0, sizeof f);
+    f.width = 8; f.height = 8; f.num_threads = 1; f.max_depth = 0;
+    f.cam_rot[0] = f.cam_rot[4] = f.cam_rot[8] = 1.0;
+    const ctgpu_partition whole = {8, 0, 1};
+    FrameParams P;
+    int rc = fill_params(ctx, &f, &whole, false, P); if (rc) return rc;
+    ctgpu_ray *d_rays = nullptr;
+    ctgpu_hit *d_hits = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_rays, n * sizeof(ctgpu_ray)));
+    hipError_t e = hipMalloc((void **)&d_hits, n * sizeof(ctgpu_hit));
+    if (e != hipSuccess) { (void)hipFree(d_rays); return fail(CTGPU_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
+    e = hipMemcpy(d_rays, rays, n * sizeof(ctgpu_ray), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        launch_trace_ray_list(P, d_rays, n, d_hits, ctx->stream);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(hits, d_hits, n * sizeof(ctgpu_hit), hipMemcpyDeviceToHost);
+    (void)hipFree(d_rays);
+    (void)hipFree(d_hits);
+    if (e != hipSuccess) return fail(CTGPU_ERR_HIP, "ctgpu_trace_rays: %s", hipGetErrorString(e));
+    return check_overflow(ctx);
+}

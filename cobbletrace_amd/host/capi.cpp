@@ -123,6 +123,39 @@ uint64_t cth_index_hash(void *p) {
     return f.h;
 }
 
+// ---- RayThread driven from the harness: the caller's buffer becomes env->bitmap->memory
+void cth_raythread_options(int rng_mode, uint64_t seed, int device) {
+    const ct_raythread_options o{rng_mode, seed, device};
+    RayThreadSetOptions(&o);
+}
+
+void cth_raythread_reset(void) { RayThreadReset(); }
+
+// First call renders; each byte of `keys` is then delivered as one key-down event followed
+// by one more RayThread call (one frame per key).  Returns the number of RayThread calls.
+int cth_raythread_frames(void *p, int width, int height, uint32_t *fb, const char *keys) {
+    Handle *h = H(p);
+    h->bitmap = bitmapSettings_t{fb, width, height, nullptr};
+    h->events.assign(64, event_t{});
+    std::memset(&h->env, 0, sizeof h->env);
+    h->env.bitmap = &h->bitmap;
+    h->env.clientWidth = width * 2;
+    h->env.clientHeight = height * 2;
+    h->env.events.queue = h->events.data();
+    h->env.events.capacity = (uint32_t)h->events.size();
+    int calls = 0;
+    RayThread(&h->env, &h->scene);
+    calls++;
+    for (const char *k = keys; k && *k; k++) {
+        AddEvent(&h->env.events, event_t{ET_KEY_DOWN, EM_NONE, v2_t{0, 0}, (uint32_t)(unsigned char)*k});
+        RayThread(&h->env, &h->scene);
+        calls++;
+    }
+    return calls;
+}
+
+void cth_get_rotation(void *p, double rot[9]) { std::memcpy(rot, H(p)->scene.camera.rotation.data, 72); }
+
 uint64_t cth_fnv1a64(const void *data, uint64_t n) {
     ct::Fnv64 f;
     f.bytes(data, (size_t)n);

@@ -1,0 +1,80 @@
+// main_headless.cpp -- the reference's application shell (cobbletrace.cpp:26-125) without
+// SDL: parse the scene, allocate the bitmap, call RayThread once per "frame", write the
+// result as a binary PPM instead of blitting it.  The bitmap size, fixed at 640x640 in the
+// reference (cobbletrace.cpp:14-15), is a command-line option here.
+#include "cobbletrace_host.h"
+#include "ctgpu.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+static void usage() {
+    std::fprintf(stderr,
+                 "cobbletrace_headless scenefile [--width W] [--height H] [--out image.ppm]\n"
+                 "                     [--rng hash|libc] [--seed N] [--device N] [--keys wasd...]\n\n"
+                 "To run cobbletrace provide a scene file.  See assets/scene_file_1.json for an example.\n");
+    std::exit(0);
+}
+
+int main(int argc, char **argv) {
+    if (argc < 2) usage();
+    int width = 640, height = 640;
+    std::string out = "cobbletrace.ppm", keys;
+    ct_raythread_options opt{CTGPU_RNG_HASH, 0, 0};
+    for (int i = 2; i < argc; i++) {
+        const std::string a = argv[i];
+        auto need = [&](const char *name) -> const char * {
+            if (i + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", name); std::exit(1); }
+            return argv[++i];
+        };
+        if (a == "--width") width = std::atoi(need("--width"));
+        else if (a == "--height") height = std::atoi(need("--height"));
+        else if (a == "--out") out = need("--out");
+        else if (a == "--rng") opt.rng_mode = std::strcmp(need("--rng"), "libc") == 0 ? CTGPU_RNG_LIBC : CTGPU_RNG_HASH;
+        else if (a == "--seed") opt.rng_seed = std::strtoull(need("--seed"), nullptr, 10);
+        else if (a == "--device") opt.device = std::atoi(need("--device"));
+        else if (a == "--keys") keys = need("--keys");
+        else usage();
+    }
+
+    scene_t scene;
+    std::memset(&scene, 0, sizeof scene);
+    InitSceneData(&scene);
+    ParseSceneFile(argv[1], &scene);
+    if (scene.settings.wireframe) {
+        std::fprintf(stderr, "wireframe scenes use the rasteriser, which this build does not provide\n");
+        return 1;
+    }
+
+    std::vector<uint32_t> pixels((size_t)width * height, 0u);   // calloc, cobbletrace.cpp:57
+    bitmapSettings_t bitmap{pixels.data(), width, height, nullptr};
+    std::vector<event_t> ring(1000);                            // EVENT_QUEUE_SIZE
+    environment_t env{};
+    env.bitmap = &bitmap;
+    env.clientWidth = width * 2;
+    env.clientHeight = height * 2;
+    env.events.queue = ring.data();
+    env.events.capacity = (uint32_t)ring.size();
+
+    RayThreadSetOptions(&opt);
+    RayThread(&env, &scene);                                    // first frame
+    for (char k : keys) {                                       // one frame per key, like one SDL_KEYDOWN each
+        AddEvent(&env.events, event_t{ET_KEY_DOWN, EM_NONE, v2_t{0, 0}, (uint32_t)k});
+        RayThread(&env, &scene);
+    }
+
+    FILE *f = std::fopen(out.c_str(), "wb");
+    if (!f) { std::perror(out.c_str()); return 1; }
+    std::fprintf(f, "P6\n%d %d\n255\n", width, height);
+    for (uint32_t p : pixels) {
+        const unsigned char rgb[3] = {(unsigned char)(p & 0xff), (unsigned char)((p >> 8) & 0xff),
+                                      (unsigned char)((p >> 16) & 0xff)};
+        std::fwrite(rgb, 1, 3, f);
+    }
+    std::fclose(f);
+    std::fprintf(stderr, "wrote %s (%dx%d)\n", out.c_str(), width, height);
+    return 0;
+}

@@ -1,0 +1,197 @@
+// ray_thread.cpp -- RayThread(env, scene): the drop-in for the reference's Boss/Worker
+// ray tracer (raythread.h:5, raythread.cpp:641-667), driving the HIP library through the
+// C ABI of include/ctgpu.h.
+//
+// Kept from the reference's boss: lazy one-time set-up on the first call (triangle
+// gather + BVH build, raythread.cpp:647-654), keyboard camera control (:388-434), the
+// "re-render only when something changed" rule (:546-562), the yaw/pitch/roll matrix in
+// binary32 (:564-572), and always returning true.  Replaced: the worker pool and its
+// status polling -- a frame is one synchronous GPU dispatch, so a call that has work to
+// do returns with the pixels already in env->bitmap->memory.
+#include "cobbletrace_host.h"
+#include "ctgpu.h"
+#include "scene_pack.h"
+
+#include <dlfcn.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+namespace {
+
+// ---- the C ABI, resolved at run time so this layer builds and loads without ROCm
+struct GpuApi {
+    void *lib = nullptr;
+    decltype(&ctgpu_abi_version) abi_version = nullptr;
+    decltype(&ctgpu_last_error) last_error = nullptr;
+    decltype(&ctgpu_create) create = nullptr;
+    decltype(&ctgpu_destroy) destroy = nullptr;
+    decltype(&ctgpu_upload_scene) upload_scene = nullptr;
+    decltype(&ctgpu_render) render = nullptr;
+};
+
+[[noreturn]] void die(const char *what, const char *detail) {
+    std::fprintf(stderr, "cobbletrace: %s: %s\n", what, detail ? detail : "");
+    std::exit(2);     // the reference's fatal path (raythread.cpp:608)
+}
+
+std::string library_beside_this_one() {
+    Dl_info info;
+    if (!dladdr((void *)&library_beside_this_one, &info) || !info.dli_fname) return "libctgpu.so";
+    std::string here(info.dli_fname);
+    const size_t slash = here.find_last_of('/');
+    const std::string dir = (slash == std::string::npos) ? std::string(".") : here.substr(0, slash);
+    return dir + "/../csrc/libctgpu.so";
+}
+
+GpuApi &gpu() {
+    static GpuApi api;
+    if (api.lib) return api;
+    const char *override_path = std::getenv("CTGPU_LIBRARY");
+    const std::string path = override_path ? std::string(override_path) : library_beside_this_one();
+    api.lib = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+    if (!api.lib) die("cannot load the HIP ray-trace library", dlerror());
+#define RESOLVE(field, symbol)                                                   \
+    api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.lib, symbol));   \
+    if (!api.field) die("missing symbol in libctgpu.so", symbol)
+    RESOLVE(abi_version, "ctgpu_abi_version");
+    RESOLVE(last_error, "ctgpu_last_error");
+    RESOLVE(create, "ctgpu_create");
+    RESOLVE(destroy, "ctgpu_destroy");
+    RESOLVE(upload_scene, "ctgpu_upload_scene");
+    RESOLVE(render, "ctgpu_render");
+#undef RESOLVE
+    if (api.abi_version() != CTGPU_ABI_VERSION) die("libctgpu.so ABI mismatch", path.c_str());
+    return api;
+}
+
+struct BossState {
+    bool initialised = false;
+    bool changes_pending = true;          // the first call renders (raythread.cpp:547)
+    float yaw = 0, pitch = 0, roll = 0;
+    ct::PackedScene *packed = nullptr;
+    ctgpu_ctx *ctx = nullptr;
+    uint64_t rand_consumed = 0;           // LIBC jitter mode: rand() calls used by earlier frames
+    ct_raythread_options options{CTGPU_RNG_HASH, 0, 0};
+    ctgpu_stats last_stats{};
+};
+
+BossState &boss() {
+    static BossState s;
+    return s;
+}
+
+// raythread.cpp:388-434
+bool drain_keyboard(environment_t *env, BossState &b, v3_t *pos) {
+    bool changed = false;
+    const float step = (float)(M_PI_4 / 4);
+    if (!env->events.queue) return false;
+    for (event_t *e = ReadEvent(&env->events); e; e = ReadEvent(&env->events)) {
+        if (e->type != ET_KEY_DOWN) continue;
+        switch (e->value) {
+            case 'w': pos->y += 0.1; changed = true; break;
+            case 's': pos->y -= 0.1; changed = true; break;
+            case 'd': pos->x += 0.1; changed = true; break;
+            case 'a': pos->x -= 0.1; changed = true; break;
+            case 'i': pos->z += 0.1; changed = true; break;
+            case 'o': pos->z -= 0.1; changed = true; break;
+            case 'r': b.roll = (float)((double)b.roll + (M_PI_4 / 4)); changed = true; break;
+            case 'y': b.yaw = (float)((double)b.yaw + (M_PI_4 / 4)); changed = true; break;
+            case 'p': b.pitch = (float)((double)b.pitch + (M_PI_4 / 4)); changed = true; break;
+            case 'c': *pos = v3_t{0, 0, 0}; b.yaw = b.pitch = b.roll = 0; changed = true; break;
+            case 'm':
+                std::fprintf(stderr, "camera position: %f %f %f\n", pos->x, pos->y, pos->z);
+                changed = true;
+                break;
+            default: break;
+        }
+    }
+    (void)step;
+    return changed;
+}
+
+// raythread.cpp:564-572: products of binary32 cos/sin, stored to double
+void camera_matrix(const BossState &b, m3x3_t *m) {
+    const float cy = std::cos(b.yaw), sy = std::sin(b.yaw);
+    const float cp = std::cos(b.pitch), sp = std::sin(b.pitch);
+    const float cr = std::cos(b.roll), sr = std::sin(b.roll);
+    m->data[0][0] = cy * cp;
+    m->data[0][1] = cy * sp * sr - sy * cr;
+    m->data[0][2] = cy * sp * cr + sy * sr;
+    m->data[1][0] = sy * cp;
+    m->data[1][1] = sy * sp * sr + cy * cr;
+    m->data[1][2] = sy * sp * cr - cy * sr;
+    m->data[2][0] = -sy;
+    m->data[2][1] = cp * sr;
+    m->data[2][2] = cp * cr;
+}
+
+}  // namespace
+
+void RayThreadSetOptions(const ct_raythread_options *opt) {
+    if (opt) boss().options = *opt;
+}
+
+void RayThreadReset(void) {
+    BossState &b = boss();
+    if (b.ctx) gpu().destroy(b.ctx);
+    delete b.packed;
+    const ct_raythread_options keep = b.options;
+    b = BossState();
+    b.options = keep;
+}
+
+extern "C" void cth_last_frame_stats(ctgpu_stats *out) { if (out) *out = boss().last_stats; }
+
+bool RayThread(environment_t *env, scene_t *scene) {
+    BossState &b = boss();
+    GpuApi &api = gpu();
+
+    if (!b.initialised) {
+        b.packed = new ct::PackedScene();
+        b.packed->build_from(scene);
+        if (api.create(b.options.device, &b.ctx) != CTGPU_OK) die("ctgpu_create", api.last_error());
+        const ctgpu_scene_desc desc = b.packed->desc();
+        if (api.upload_scene(b.ctx, &desc) != CTGPU_OK) die("ctgpu_upload_scene", api.last_error());
+        b.initialised = true;
+    }
+
+    // HandleUpdates (raythread.cpp:546-593)
+    b.changes_pending = drain_keyboard(env, b, &scene->camera.position) || b.changes_pending;
+    if (!b.changes_pending) return true;
+    b.changes_pending = false;
+    camera_matrix(b, &scene->camera.rotation);
+
+    ctgpu_frame_desc frame;
+    std::memset(&frame, 0, sizeof frame);
+    frame.width = env->bitmap->width;
+    frame.height = env->bitmap->height;
+    frame.num_threads = scene->settings.numberOfThreads;
+    frame.flags = (scene->settings.supersampling ? CTGPU_F_SUPERSAMPLE : 0u) |
+                  (scene->settings.subsampling ? CTGPU_F_SUBSAMPLE : 0u);
+    frame.cam_pos[0] = scene->camera.position.x;
+    frame.cam_pos[1] = scene->camera.position.y;
+    frame.cam_pos[2] = scene->camera.position.z;
+    std::memcpy(frame.cam_rot, scene->camera.rotation.data, sizeof frame.cam_rot);
+    frame.rng_mode = b.options.rng_mode;
+    frame.rng_seed = (b.options.rng_mode == CTGPU_RNG_LIBC && b.options.rng_seed == 0) ? 1 : b.options.rng_seed;
+    frame.rng_offset = b.rand_consumed;
+    frame.max_depth = 10;                 // TraceRay(..., 10, ...) raythread.cpp:474,508
+
+    ctgpu_stats stats;
+    if (api.render(b.ctx, &frame, (uint32_t *)env->bitmap->memory, &stats) != CTGPU_OK)
+        die("ctgpu_render", api.last_error());
+    b.last_stats = stats;
+    if (scene->settings.supersampling) {
+        // one worker's rand() calls per frame: every column of the square x every traced row
+        // (the off-bitmap row included) x 16 samples x (rx, ry)   raythread.cpp:455-471
+        const uint64_t half = (uint64_t)(frame.height / 2), q = (uint64_t)(frame.height / frame.num_threads);
+        uint64_t traced_per_band = q;
+        if (scene->settings.subsampling) traced_per_band = (q + 1) / 2 + ((q % 2 == 0 && q >= 2) ? 1 : 0);
+        b.rand_consumed += 2 * half * traced_per_band * (uint64_t)frame.num_threads * 32u;
+    }
+    return true;
+}

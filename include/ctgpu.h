@@ -164,6 +164,10 @@ int  ctgpu_trace_rays(ctgpu_ctx *ctx, const ctgpu_ray *rays, uint64_t n, ctgpu_h
  * triangle_tests besides the ray counts.  These are the V_r / Q_r sums of the roofline model. */
 int  ctgpu_count_work(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, ctgpu_stats *stats);
 
+/* The jitter stream CTGPU_RNG_LIBC uses: glibc 2.35 rand() after srand(seed), skipping the
+ * first `offset` values (host-side; exported so a test can compare it with libc itself). */
+int  ctgpu_rand_stream(uint32_t seed, uint64_t offset, uint64_t n, int32_t *out);
+
 #ifdef __cplusplus
 }
 #endif

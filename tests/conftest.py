@@ -1,0 +1,72 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def native_build():
+    """Build whatever is missing (a no-op when the .so files travelled with the snapshot)."""
+    import __graft_entry__ as entry
+    needed = [os.path.join(ROOT, "cobbletrace_amd", "csrc", "libctgpu.so"),
+              os.path.join(ROOT, "cobbletrace_amd", "host", "libcthost.so"),
+              os.path.join(ROOT, "oracle", "libctoracle.so")]
+    if not all(os.path.exists(p) for p in needed):
+        entry.build()
+    entry.prepare_assets()
+    return entry
+
+
+@pytest.fixture(scope="session")
+def assets():
+    return os.path.join(ROOT, "assets")
+
+
+@pytest.fixture(scope="session")
+def scenes(assets, native_build):
+    """Parsed + BVH-built scenes, cached for the session (cwd-independent paths)."""
+    import cobbletrace_amd as ca
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            if name == "dragon":
+                native_build.prepare_assets(need_dragon=True)
+            path = {"cube": "scene_file_cube.json", "import": "scene_import.json",
+                    "bunny": "scene_import_bunny.json", "dragon": "scene_import_dragon.json"}[name]
+            cache[name] = ca.HostScene(os.path.join(assets, path))
+        return cache[name]
+
+    return get
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx(scenes):
+    """One ctgpu context per scene, cached (GPU tests only)."""
+    import cobbletrace_amd as ca
+    cache = {}
+
+    def get(name):
+        if name not in cache:
+            ctx = ca.GpuContext(0)
+            ctx.upload(scenes(name).desc)
+            cache[name] = ctx
+        return cache[name]
+
+    yield get
+    for ctx in cache.values():
+        ctx.close()
+
+
+def channel_diff(a, b):
+    import numpy as np
+    shifts = np.array([0, 8, 16])
+    return np.abs(((a[..., None] >> shifts) & 255).astype(np.int32) - ((b[..., None] >> shifts) & 255).astype(np.int32))

@@ -1,0 +1,206 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same
+inputs.  Bar: <= 1 LSB per 8-bit channel (BASELINE.json); index / t of individual hits exact
+(the only non-exact operation on the path is pow(), SURVEY.md 7 "hard parts")."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import cobbletrace_amd as ca
+from conftest import channel_diff
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle():
+    from oracle import oracle
+    return oracle
+
+
+def _compare(gpu_fb, cpu_fb, what):
+    diff = channel_diff(gpu_fb, cpu_fb)
+    n_diff = int((gpu_fb != cpu_fb).sum())
+    print("%s: max channel diff %d, pixels differing %d of %d" % (what, diff.max(), n_diff, gpu_fb.size))
+    assert diff.max() <= 1, "%s: %d LSB off" % (what, diff.max())      # tolerance: 1 LSB / channel
+    return n_diff
+
+
+def _random_rays(scene, n, seed):
+    rng = np.random.default_rng(seed)
+    v = scene.vertices()
+    lo, hi = v.reshape(-1, 3).min(0), v.reshape(-1, 3).max(0)
+    centre, span = (lo + hi) / 2, (hi - lo).max()
+    rays = np.zeros(n, dtype=ca.bindings.RAY_DTYPE)
+    origin = centre + rng.normal(size=(n, 3)) * span * 1.5
+    target = lo + rng.random((n, 3)) * (hi - lo)
+    rays["origin"] = origin
+    rays["direction"] = target - origin
+    rays["t"] = np.float32(1e30)
+    # a few degenerate ones: axis-parallel directions (zero components -> inf/NaN slabs), t = 0 starts
+    rays["direction"][: n // 50, 0] = 0.0
+    rays["direction"][n // 50: n // 25, 1] = 0.0
+    rays["t"][n // 25: n // 20] = 0.0
+    return rays
+
+
+@pytest.mark.parametrize("name", ["cube", "import", "bunny"])
+def test_closest_hit_exact(name, scenes, gpu_ctx):
+    scene, ctx = scenes(name), gpu_ctx(name)
+    rays = _random_rays(scene, 200_000 if name != "cube" else 50_000, seed=11)
+    got = ctx.trace_rays(rays)
+    want = _oracle().trace_rays(scene.desc, rays)
+    assert (got["found"] == want["found"]).all()
+    assert (got["triangle"] == want["triangle"]).all()          # exact index, ties included
+    assert (got["t"].view(np.uint32) == want["t"].view(np.uint32)).all()          # bit-exact t
+    assert (got["tclosest"].view(np.uint32) == want["tclosest"].view(np.uint32)).all()
+    assert want["found"].sum() > len(rays) // 20                 # the test really hits geometry
+
+
+@pytest.mark.parametrize("name,w,h,t", [("cube", 640, 480, 8), ("import", 1920, 1080, 32), ("bunny", 1920, 1080, 32),
+                                        ("bunny", 1920, 1080, 8)])
+def test_frame_single_sample(name, w, h, t, scenes, gpu_ctx):
+    scene, ctx = scenes(name), gpu_ctx(name)
+    frame = scene.frame(w, h, threads=t, supersampling=False)
+    gpu_fb, st = ctx.render(frame)
+    cpu_fb, cst = _oracle().render(scene.desc, frame, os_threads=8)
+    _compare(gpu_fb, cpu_fb, "%s %dx%d T=%d" % (name, w, h, t))
+    # untouched pixels stay untouched (row 0, rows beyond T*(H/T), columns outside the square)
+    assert ((gpu_fb == 0) == (cpu_fb == 0)).all()
+    # the GPU does not trace the y = -H/2 row, whose pixels the reference computes and drops
+    assert st.rays_primary == cst.rays_primary - 2 * (h // 2)
+    assert st.rays_shadow <= cst.rays_shadow and st.rays_reflect <= cst.rays_reflect
+
+
+@pytest.mark.parametrize("name,w,h,t", [("cube", 320, 240, 8), ("bunny", 640, 360, 32), ("import", 480, 270, 32)])
+def test_frame_supersampled_hash(name, w, h, t, scenes, gpu_ctx):
+    scene, ctx = scenes(name), gpu_ctx(name)
+    frame = scene.frame(w, h, threads=t, supersampling=True, rng_mode=ca.RNG_HASH, rng_seed=3)
+    gpu_fb, st = ctx.render(frame)
+    cpu_fb, _ = _oracle().render(scene.desc, frame, os_threads=8)
+    _compare(gpu_fb, cpu_fb, "%s ss hash" % name)
+    # another seed gives another image (the jitter is really applied)
+    frame2 = scene.frame(w, h, threads=t, supersampling=True, rng_mode=ca.RNG_HASH, rng_seed=4)
+    other, _ = ctx.render(frame2)
+    assert (other != gpu_fb).any()
+
+
+def test_frame_supersampled_libc_single_worker(scenes, gpu_ctx):
+    """CTGPU_RNG_LIBC reproduces what ONE reference worker draws from glibc rand()."""
+    scene, ctx = scenes("bunny"), gpu_ctx("bunny")
+    frame = scene.frame(200, 160, threads=1, supersampling=True, rng_mode=ca.RNG_LIBC, rng_seed=1)
+    gpu_fb, _ = ctx.render(frame)
+    cpu_fb, _ = _oracle().render(scene.desc, frame, os_threads=1)
+    _compare(gpu_fb, cpu_fb, "bunny ss libc T=1")
+    # second frame continues the stream
+    frame.rng_offset = 160 * 160 * 32
+    gpu2, _ = ctx.render(frame)
+    cpu2, _ = _oracle().render(scene.desc, frame, os_threads=1)
+    _compare(gpu2, cpu2, "bunny ss libc T=1 frame 2")
+    assert (gpu2 != gpu_fb).any()
+
+
+@pytest.mark.parametrize("t,h", [(8, 240), (7, 240), (1, 121), (4, 66)])
+def test_frame_subsampled(t, h, scenes, gpu_ctx):
+    """settings.subsampling (the parser's default): every other row traced, rows between averaged."""
+    scene, ctx = scenes("import"), gpu_ctx("import")
+    for ss in (False, True):
+        frame = scene.frame(320, h, threads=t, supersampling=ss, subsampling=True, rng_seed=5)
+        gpu_fb, _ = ctx.render(frame)
+        cpu_fb, _ = _oracle().render(scene.desc, frame, os_threads=4)
+        _compare(gpu_fb, cpu_fb, "import subsample T=%d H=%d ss=%d" % (t, h, ss))
+        assert ((gpu_fb == 0) == (cpu_fb == 0)).all()
+
+
+@pytest.mark.parametrize("w,h", [(64, 2), (3, 64), (65, 63), (1000, 64), (64, 1000)])
+def test_odd_bitmap_shapes(w, h, scenes, gpu_ctx):
+    scene, ctx = scenes("cube"), gpu_ctx("cube")
+    t = 1 if h < 8 else 8
+    frame = scene.frame(w, h, threads=t, supersampling=False)
+    gpu_fb, _ = ctx.render(frame)
+    cpu_fb, _ = _oracle().render(scene.desc, frame, os_threads=2)
+    _compare(gpu_fb, cpu_fb, "cube %dx%d" % (w, h))
+    assert ((gpu_fb == 0) == (cpu_fb == 0)).all()
+
+
+def test_rotated_camera(scenes, gpu_ctx):
+    scene, ctx = scenes("import"), gpu_ctx("import")
+    rot = _oracle().camera_rotation(np.float32(np.pi / 16), np.float32(np.pi / 8), np.float32(-np.pi / 16))
+    frame = scene.frame(400, 300, threads=4, supersampling=False, rotation=rot)
+    gpu_fb, _ = ctx.render(frame)
+    cpu_fb, _ = _oracle().render(scene.desc, frame, os_threads=4)
+    _compare(gpu_fb, cpu_fb, "import rotated")
+
+
+def test_work_counters_match_oracle(scenes, gpu_ctx):
+    """node-visit / triangle-test totals of the roofline model, against the oracle walking the
+    same order with the same shadow early exit."""
+    for name, w, h in (("bunny", 480, 270), ("cube", 160, 120)):
+        scene, ctx = scenes(name), gpu_ctx(name)
+        frame = scene.frame(w, h, threads=2, supersampling=False)
+        got = ctx.count_work(frame)
+        _, want = _oracle().render(scene.desc, frame, os_threads=4, shadow_early_exit=True, count_work=True)
+        # the GPU skips the off-bitmap row y = -H/2 the reference traces and drops
+        frame_rows_skipped = 1
+        assert got.rays_shadow == want.rays_shadow - _rays_in_dropped_row(scene, frame, "shadow")
+        assert got.node_visits == want.node_visits - _rays_in_dropped_row(scene, frame, "visits")
+        assert got.triangle_tests == want.triangle_tests - _rays_in_dropped_row(scene, frame, "tests")
+        assert frame_rows_skipped == 1
+
+
+def _rays_in_dropped_row(scene, frame, what):
+    """Work the oracle spends on the y = -H/2 row (band 0's first row), measured by rendering
+    that band alone at T = rendered rows so that the band is exactly one row."""
+    import copy
+    f = copy.copy(frame)
+    rows = (frame.height // frame.num_threads) * frame.num_threads
+    if rows != frame.height:
+        raise AssertionError("test assumes T divides H")
+    f.num_threads = frame.height          # one row per band
+    _, st = _oracle().render(scene.desc, f, os_threads=1, shadow_early_exit=True, count_work=True, band_first=0,
+                             band_count=1)
+    return {"shadow": st.rays_shadow, "visits": st.node_visits, "tests": st.triangle_tests}[what]
+
+
+def test_partitions_assemble_to_the_same_frame(scenes, gpu_ctx):
+    """Row tiles rendered as 1, 2, 3 and 8 partitions (all on this one GPU) and merged by
+    ctgpu_assemble give the bit-identical framebuffer -- the property the multi-GPU path rests on."""
+    torch = pytest.importorskip("torch")
+    scene, ctx = scenes("bunny"), gpu_ctx("bunny")
+    for ss, sub in ((False, False), (True, False), (False, True)):
+        frame = scene.frame(640, 360, threads=8, supersampling=ss, subsampling=sub, rng_seed=9)
+        whole, _ = ctx.render(frame)
+        for parts, tile_rows in ((1, 8), (2, 8), (3, 16), (8, 8), (5, 1)):
+            bufs = []
+            n = ctx.partition_pixels(frame, ca.Partition(tile_rows, 0, parts))
+            gathered = torch.zeros(parts * n, dtype=torch.int32, device="cuda")
+            for p in range(parts):
+                part = ca.Partition(tile_rows, p, parts)
+                ctx.render_partition(frame, part, gathered[p * n:].data_ptr(), torch.cuda.current_stream().cuda_stream)
+            fb = torch.zeros(frame.height * frame.width, dtype=torch.int32, device="cuda")
+            ctx.assemble(frame, ca.Partition(tile_rows, 0, parts), gathered.data_ptr(), fb.data_ptr(),
+                         torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            ctx.read_counters()
+            got = fb.cpu().numpy().view(np.uint32).reshape(frame.height, frame.width)
+            assert (got == whole).all(), "parts=%d tile_rows=%d ss=%d sub=%d" % (parts, tile_rows, ss, sub)
+            bufs.append(got)
+
+
+def test_dragon_full_size_properties(scenes, gpu_ctx):
+    """BASELINE.json's headline workload at full size (the oracle would take minutes here):
+    size-independent properties -- determinism, ray accounting, tile-split invariance against
+    a band of oracle rows."""
+    scene, ctx = scenes("dragon"), gpu_ctx("dragon")
+    frame = scene.frame(1920, 1080, supersampling=False)          # T = 32 from the scene file
+    a, sa = ctx.render(frame)
+    b, sb = ctx.render(frame)
+    assert (a == b).all() and sa.rays == sb.rays                  # idempotent
+    hits = int(((a != 0x333333) & (a != 0)).sum())
+    assert sa.rays_shadow == 2 * hits                             # two non-ambient lights per hit
+    assert sa.rays_primary == 1080 * 1056 - 1080                  # rendered rows x square, minus the dropped row
+    assert (a[1:25] == 0).all() and (a[0] == 0).all() and (a[:, :420] == 0).all() and (a[:, 1500:] == 0).all()
+    # four bands (of 32) against the oracle, bit for bit
+    cpu_fb, _ = _oracle().render(scene.desc, frame, os_threads=8, band_first=14, band_count=4)
+    rows = cpu_fb.any(axis=1)
+    assert rows.sum() == 4 * 33
+    _compare(a[rows], cpu_fb[rows], "dragon stand-in 1920x1080 bands 14-17")
