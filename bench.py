@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- Mrays/s of the CobbleTrace hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A step is ONE FRAME of BASELINE.json's headline workload: scene_import_dragon.json at
+1920x1080 with the scene file's own settings (32 row bands, supersampling on = 16 jittered
+samples per pixel, subsampling off), jitter from the counter-based generator (the mode in
+which GPU and CPU pixels are comparable).  The Stanford dragon itself is not
+distributed with the reference; the mesh is the repository's deterministic 871,200-triangle
+stand-in (tools/make_dragon_standin.py) -- "data" says so.
+
+For N > 1 (launched by torch.distributed.run, one rank per GPU) the frame's row tiles are
+dealt round-robin to the ranks and assembled with one RCCL gather; the total work per step
+is fixed, so scaling is "strong".  value = rays of all ranks / wall time (max over ranks),
+everything resident in HBM; the host-framebuffer copy is reported separately.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
+# algorithmic bytes, reference layout: node 64 B, triangle test 4 B index + 72 B
+# vertices, shaded hit 12 B material + 72 B vertices, pixel 4 B
+B_NODE, B_TRI, B_HIT, B_PIXEL = 64, 76, 84, 4
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--scene", default="dragon", choices=["dragon", "bunny", "import", "cube"])
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--supersampling", type=int, default=-1, help="-1: scene file's setting")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-bands", type=int, default=16, help="row bands (of T) the CPU baseline samples")
+    return ap.parse_args()
+
+
+SCENE_FILES = {"dragon": "scene_import_dragon.json", "bunny": "scene_import_bunny.json",
+               "import": "scene_import.json", "cube": "scene_file_cube.json"}
+
+
+def algorithmic_bytes(st, pixels):
+    hits = st.rays_shadow // 2 if st.rays_shadow else 0
+    return st.node_visits * B_NODE + st.triangle_tests * B_TRI + hits * B_HIT + pixels * B_PIXEL
+
+
+def cpu_baseline(scene, frame, n_bands):
+    """The oracle -- a plain-C port of the reference's Boss/Worker path, one worker thread per
+    row band like raythread.cpp:596-618 -- timed on this box's host cores on a bounded sample:
+    n_bands of the frame's T bands spread evenly over the image, all running concurrently."""
+    from oracle import oracle           # the checker, used here only as the timed CPU baseline
+    import numpy as np
+    cores = os.cpu_count() or 1
+    T = frame.num_threads
+    n_bands = max(1, min(n_bands, T))
+    stride = max(1, T // n_bands)
+    first = (T - ((n_bands - 1) * stride + 1)) // 2
+    threads = min(cores, n_bands)
+    fb = np.zeros((frame.height, frame.width), dtype=np.uint32)
+    t0 = time.perf_counter()
+    _, st = oracle.render(scene.desc, frame, os_threads=threads, band_first=first, band_count=n_bands,
+                          band_stride=stride, fb=fb)
+    seconds = time.perf_counter() - t0
+    picks = [first + i * stride for i in range(n_bands)]
+    return st.rays / seconds / 1e6, threads, picks, st.rays, seconds
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    import cobbletrace_amd as ca
+    from cobbletrace_amd.multi_gpu import ShardedRenderer
+    import __graft_entry__ as entry
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device is visible")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # every rank needs the assets and the native libraries; rank 0 prepares, the others wait
+    if rank == 0:
+        libs = [os.path.join(ROOT, "cobbletrace_amd", "csrc", "libctgpu.so"),
+                os.path.join(ROOT, "cobbletrace_amd", "host", "libcthost.so"),
+                os.path.join(ROOT, "oracle", "libctoracle.so")]
+        if not all(os.path.exists(p) for p in libs):
+            entry.build()
+        entry.prepare_assets(need_dragon=(args.scene == "dragon"))
+    if world > 1:
+        dist.barrier()
+
+    scene = ca.HostScene(os.path.join(ROOT, "assets", SCENE_FILES[args.scene]))
+    ss = None if args.supersampling < 0 else bool(args.supersampling)
+    frame = scene.frame(args.width, args.height, supersampling=ss, rng_mode=ca.RNG_HASH, rng_seed=0)
+    is_ss = bool(frame.flags & ca.F_SUPERSAMPLE)
+
+    renderer = ShardedRenderer(scene.desc, rank, world, local_rank)
+    stream = torch.cuda.current_stream()
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        renderer.frame(frame)
+    sync_all()
+    renderer.ctx.read_counters()          # reset the ray counters
+
+    # ---- timed region: exactly K frames
+    k_start = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    k_end = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    sync_all()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        k_start[i].record(stream)
+        tiles = renderer.trace(frame)
+        k_end[i].record(stream)
+        gathered = ca.multi_gpu.gather_to_root(tiles, world, rank) if world > 1 else tiles
+        if rank == 0:
+            _, fb = renderer._buffers_for(frame)
+            renderer.ctx.assemble(frame, renderer.part, gathered.data_ptr(), fb.data_ptr(), stream.cuda_stream)
+    sync_all()
+    elapsed = time.perf_counter() - t0
+
+    st = renderer.ctx.read_counters()
+    kernel_ms = sum(a.elapsed_time(b) for a, b in zip(k_start, k_end)) / args.steps
+    totals = torch.tensor([float(st.rays), elapsed], dtype=torch.float64, device="cuda")
+    if world > 1:
+        rays_all = totals[:1].clone()
+        dist.all_reduce(rays_all, op=dist.ReduceOp.SUM)
+        time_max = totals[1:].clone()
+        dist.all_reduce(time_max, op=dist.ReduceOp.MAX)
+        total_rays, elapsed = float(rays_all.item()), float(time_max.item())
+    else:
+        total_rays = float(st.rays)
+    rays_per_frame = total_rays / args.steps
+    ms_per_step = elapsed / args.steps * 1e3
+    value = total_rays / elapsed / 1e6
+
+    if rank == 0:
+        # ---- frame -> host framebuffer (the reference's hand-off buffer), PCIe included; not `value`
+        host_fb = torch.empty(frame.height * frame.width, dtype=torch.int32).pin_memory()
+        sync_all() if world == 1 else torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    fb = renderer.frame(frame)
+    if rank == 0:
+        host_fb.copy_(fb, non_blocking=True)
+    torch.cuda.synchronize()
+    to_host_ms = (time.perf_counter() - t0) * 1e3
+
+    out = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel (ct_trace_tiles): algorithmic bytes of ONE launch
+        work = renderer.ctx.count_work(frame)           # whole frame, instrumented variant
+        pixels = int(work.rays_primary // (16 if is_ss else 1))
+        frame_bytes = algorithmic_bytes(work, pixels)
+        launch_bytes = frame_bytes * (st.rays / args.steps) / max(work.rays, 1)   # rank 0's share of the frame
+        achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "kernel": "ct_trace_tiles", "kernel_ms": round(kernel_ms, 4),
+                    "bytes_per_launch": int(launch_bytes), "bytes_per_ray": round(frame_bytes / max(work.rays, 1), 1),
+                    "node_visits_per_ray": round(work.node_visits / max(work.rays, 1), 2),
+                    "triangle_tests_per_ray": round(work.triangle_tests / max(work.rays, 1), 2)}
+        out = {
+            "metric": "Mrays/sec + ms/frame, scene_import_dragon.json @1920x1080" if args.scene == "dragon"
+                      else "Mrays/sec + ms/frame, %s @%dx%d" % (SCENE_FILES[args.scene], args.width, args.height),
+            "value": round(value, 2), "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic (deterministic 871,200-triangle stand-in for the undistributed "
+                                    "Stanford dragon)" if args.scene == "dragon" else "reference asset",
+            "config": {"workload": "%s %dx%d T=%d %s, 3 lights with shadow rays" %
+                                   (SCENE_FILES[args.scene], args.width, args.height, frame.num_threads,
+                                    "supersampling 16 spp (hash jitter)" if is_ss else "1 spp"),
+                       "rays_per_frame": int(rays_per_frame), "row_tiles": "8 rows, round-robin over %d GPU(s)" % world,
+                       "collective": "RCCL gather to rank 0" if world > 1 else "none"},
+            "ms_per_frame_to_host": round(to_host_ms, 4),
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            mrays, threads, picks, rays, seconds = cpu_baseline(scene, frame, args.cpu_bands)
+            out["cpu_baseline"] = {"value": round(mrays, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
+                                   "sample": "row bands %s of %d of the same frame (%d rays, %.1f s wall), one worker "
+                                             "thread per band, oracle/ct_oracle.c" %
+                                             (picks, frame.num_threads, rays, seconds),
+                                   "host_cores": os.cpu_count()}
+        print(json.dumps(out), flush=True)
+    renderer.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -381,7 +381,7 @@ typedef struct {
     int32_t traced_rows;
     /* work queue */
     pthread_mutex_t lock;
-    int next_band, end_band;
+    int next_band, end_band, band_stride;
     /* totals */
     ctgpu_stats totals;
 } frame_job;
@@ -467,7 +467,8 @@ static void *worker_main(void *arg) {
     uint64_t written = 0;
     for (;;) {
         pthread_mutex_lock(&job->lock);
-        const int band = (job->next_band < job->end_band) ? job->next_band++ : -1;
+        int band = -1;
+        if (job->next_band < job->end_band) { band = job->next_band; job->next_band += job->band_stride; }
         pthread_mutex_unlock(&job->lock);
         if (band < 0) break;
         render_band(job, &tr, band, &written);
@@ -496,8 +497,9 @@ int cto_render(const ctgpu_scene_desc *scene, const ctgpu_frame_desc *frame, con
     job.scene = scene; job.frame = frame; job.opt = &opt; job.fb = fb;
     job.g = frame_geometry(frame);
     pthread_mutex_init(&job.lock, NULL);
+    job.band_stride = opt.band_stride > 1 ? opt.band_stride : 1;
     job.next_band = opt.band_count > 0 ? opt.band_first : 0;
-    job.end_band = opt.band_count > 0 ? opt.band_first + opt.band_count : job.g.bands;
+    job.end_band = opt.band_count > 0 ? opt.band_first + (opt.band_count - 1) * job.band_stride + 1 : job.g.bands;
     if (job.next_band < 0 || job.end_band > job.g.bands) return CTGPU_ERR_ARG;
 
     int32_t *table = NULL, *ordinal = NULL;
@@ -523,7 +525,8 @@ int cto_render(const ctgpu_scene_desc *scene, const ctgpu_frame_desc *frame, con
         job.row_ordinal = ordinal;
     }
 
-    int n_threads = opt.os_threads > 0 ? opt.os_threads : (job.end_band - job.next_band);
+    int n_threads = opt.os_threads > 0 ? opt.os_threads
+                                       : (job.end_band - job.next_band + job.band_stride - 1) / job.band_stride;
     if (n_threads < 1) n_threads = 1;
     pthread_t *threads = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
     for (int i = 0; i < n_threads; i++) pthread_create(&threads[i], NULL, worker_main, &job);

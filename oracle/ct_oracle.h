@@ -43,8 +43,9 @@ typedef struct cto_options {
                                      same image, fewer visits -- used to cross-check
                                      the GPU work counters)                            */
     int32_t count_work;        /* accumulate node_visits / triangle_tests             */
-    int32_t band_first, band_count; /* render only bands [first, first+count); count 0 = all
-                                       (bounded CPU-baseline sample)                   */
+    int32_t band_first, band_count; /* render only band_count bands starting at band_first;
+                                       count 0 = all (bounded CPU-baseline sample)     */
+    int32_t band_stride;            /* distance between the sampled bands (0 or 1: adjacent) */
 } cto_options;
 
 /* One frame, reference semantics, into fb (width*height uint32; only the pixels the

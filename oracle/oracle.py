@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 class Options(C.Structure):
     _fields_ = [("os_threads", C.c_int32), ("shadow_early_exit", C.c_int32), ("count_work", C.c_int32),
-                ("band_first", C.c_int32), ("band_count", C.c_int32)]
+                ("band_first", C.c_int32), ("band_count", C.c_int32), ("band_stride", C.c_int32)]
 
 
 _lib = None
@@ -67,12 +67,12 @@ def library():
 
 
 def render(scene_desc, frame, os_threads=0, shadow_early_exit=False, count_work=False, band_first=0, band_count=0,
-           fb=None):
+           band_stride=1, fb=None):
     """One frame with reference semantics -> (uint32 [H, W], Stats)."""
     lib = library()
     if fb is None:
         fb = np.zeros((frame.height, frame.width), dtype=np.uint32)
-    opt = Options(os_threads, int(shadow_early_exit), int(count_work), band_first, band_count)
+    opt = Options(os_threads, int(shadow_early_exit), int(count_work), band_first, band_count, band_stride)
     st = Stats()
     rc = lib.cto_render(C.byref(scene_desc), C.byref(frame), C.byref(opt), fb.ctypes.data, C.byref(st))
     if rc != 0:
