@@ -177,7 +177,9 @@ def main():
         achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                    "kernel": "ct_trace_tiles", "kernel_ms": round(kernel_ms, 4),
+                    "kernel": "frame trace = ct_sample_grid + ct_walk<primary> + ct_walk<shadow> per light + ct_shade "
+                              "(ct_walk is >95 % of it; rocprof per-kernel split in profiles/)",
+                    "kernel_ms": round(kernel_ms, 4),
                     "bytes_per_launch": int(launch_bytes), "bytes_per_ray": round(frame_bytes / max(work.rays, 1), 1),
                     "node_visits_per_ray": round(work.node_visits / max(work.rays, 1), 2),
                     "triangle_tests_per_ray": round(work.triangle_tests / max(work.rays, 1), 2)}

@@ -88,6 +88,103 @@ __device__ __forceinline__ void slab(const d3 &o, const d3 &d, const double *bmi
     tmax = lesser(tmax, greater(tz1, tz2));
 }
 
+// ---------------------------------------------------------------- slab test, division-free
+// The six quotients F((b - o) /D d) dominate the traversal (six f64 divides per box in the
+// reference, 54 % of its run time).  With inv = RN(1/d) computed once per ray,
+//     q = RN((b - o) * inv)       differs from       Q = RN((b - o) / d)
+// by at most 3 units in the last place of a double (three roundings of relative size 2^-53
+// each; zero / infinite / NaN results coincide exactly), so the approximate
+// float a = F(q) is either the reference's float e = F(Q) or one of its two neighbours in
+// the ordered set of floats (q and Q straddle at most one rounding boundary), with the same
+// sign.  min / max in the reference's macro form are monotone, so the approximate
+// tmin / tmax are likewise within ONE float step of the exact ones.
+//
+// Two flavours use this:
+//  * slab_fast() (megakernel): proves a == e per quotient -- q must not sit within 4 ulp_D of
+//    a binary32 rounding boundary; otherwise the caller recomputes with slab().
+//  * slab_approx() + the ordinal tests below (wavefront pipeline): takes the approximate
+//    floats as they are and proves each DECISION made from them -- `tmax >= tmin`,
+//    `tmin < ray.t`, `tmax > 0` -- by requiring a margin of more than the possible error in
+//    float-ordinal space; an uncertain decision is redone with slab().  Either way the
+//    traversal takes exactly the reference's branches.
+// Neither may be used for rays whose direction has a non-zero component outside
+// [2^-999, 2^1000) (inv would be inexact beyond one rounding): direction_allows_fast_slab().
+__device__ __forceinline__ bool fast_quotient(double x, double inv, float &f) {
+    const double q = x * inv;
+    f = (float)q;
+    const uint32_t lo = (uint32_t)__double2loint(q);
+    const bool near_midpoint = ((lo - 0x0FFFFFFCu) & 0x1FFFFFFFu) <= 8u;
+    // v_cmp_class_f32 mask: -inf | -denormal | -0 | +0 | +denormal | +inf
+    const bool odd_class = __builtin_amdgcn_classf(f, 0x2F4);
+    return near_midpoint | odd_class;
+}
+
+// Returns true when the result must be recomputed with slab().
+__device__ __forceinline__ bool slab_fast(const d3 &o, const d3 &inv, const double *bmin, const double *bmax,
+                                          float &tmin, float &tmax) {
+    float tx1, tx2, ty1, ty2, tz1, tz2;
+    bool redo = fast_quotient(bmin[0] - o.x, inv.x, tx1);
+    redo |= fast_quotient(bmax[0] - o.x, inv.x, tx2);
+    redo |= fast_quotient(bmin[1] - o.y, inv.y, ty1);
+    redo |= fast_quotient(bmax[1] - o.y, inv.y, ty2);
+    redo |= fast_quotient(bmin[2] - o.z, inv.z, tz1);
+    redo |= fast_quotient(bmax[2] - o.z, inv.z, tz2);
+    tmin = lesser(tx1, tx2);
+    tmax = greater(tx1, tx2);
+    tmin = greater(tmin, lesser(ty1, ty2));
+    tmax = lesser(tmax, greater(ty1, ty2));
+    tmin = greater(tmin, lesser(tz1, tz2));
+    tmax = lesser(tmax, greater(tz1, tz2));
+    return redo;
+}
+
+// approximate entry / exit parameters, each within one float step of the reference's
+__device__ __forceinline__ void slab_approx(const d3 &o, const d3 &inv, const double *bmin, const double *bmax,
+                                            float &tmin, float &tmax) {
+    const float tx1 = (float)((bmin[0] - o.x) * inv.x), tx2 = (float)((bmax[0] - o.x) * inv.x);
+    const float ty1 = (float)((bmin[1] - o.y) * inv.y), ty2 = (float)((bmax[1] - o.y) * inv.y);
+    const float tz1 = (float)((bmin[2] - o.z) * inv.z), tz2 = (float)((bmax[2] - o.z) * inv.z);
+    tmin = lesser(tx1, tx2);
+    tmax = greater(tx1, tx2);
+    tmin = greater(tmin, lesser(ty1, ty2));
+    tmax = lesser(tmax, greater(ty1, ty2));
+    tmin = greater(tmin, lesser(tz1, tz2));
+    tmax = lesser(tmax, greater(tz1, tz2));
+}
+
+// position of a float in the ordered set of floats (-0 and +0 are neighbours; NaNs lie
+// beyond the infinities, where no margin test is ever "close")
+__device__ __forceinline__ int32_t float_ordinal(float x) {
+    const int32_t b = __float_as_int(x);
+    return b ^ ((b >> 31) & 0x7fffffff);
+}
+// |a - b| <= steps in ordinal space (wrapping arithmetic; spurious "near" only costs a redo)
+__device__ __forceinline__ bool ordinals_near(int32_t a, int32_t b, uint32_t steps) {
+    return (uint32_t)(a - b) + steps <= 2u * steps;
+}
+
+// The three decisions of the box test from approximate tmin / tmax (each <= 1 step off):
+// returns true when all three are certain, with the reference's verdict in `pass`.
+//   tmax >= tmin : both sides may move one step           -> needs |tmax - tmin| > 2 steps
+//   tmin <  t    : t is exact                              -> needs |tmin - t|    > 1 step
+//   tmax >  0    : 0 is exact (either sign of zero)        -> needs tmax more than 2 steps from +-0
+__device__ __forceinline__ bool box_verdict(float tmin, float tmax, float ray_t, int32_t ray_t_ordinal, bool &pass) {
+    const int32_t kmin = float_ordinal(tmin), kmax = float_ordinal(tmax);
+    const bool uncertain = ordinals_near(kmax, kmin, 2u) | ordinals_near(kmin, ray_t_ordinal, 1u) |
+                           ordinals_near(kmax, 0, 3u);
+    pass = tmax >= tmin && tmin < ray_t && tmax > 0;
+    return !uncertain;
+}
+
+// true when every non-zero component of d is comfortably inside the binary64 normal range
+__device__ __forceinline__ bool direction_allows_fast_slab(const d3 &d) {
+    auto ok = [](double c) {
+        const uint32_t e = ((uint32_t)__double2hiint(c) >> 20) & 0x7FFu;
+        return c == 0.0 || (e > 23u && e < 2023u);     // |c| in [2^-999, 2^1000)
+    };
+    return ok(d.x) && ok(d.y) && ok(d.z);
+}
+
 // ---------------------------------------------------------------- triangle test (bvh.cpp:147-163)
 // Returns true exactly when the reference's IntersectTriangle returns true; ray_t is
 // lowered only when t > 0.0001f.

@@ -23,6 +23,7 @@
 // triangles in index order, strict '<' for the closest hit).
 #include "ct_device.h"
 #include "ct_params.h"
+#include "ct_raygen.h"
 
 using namespace ctd;
 
@@ -35,6 +36,8 @@ enum : uint32_t { PH_CLOSEST = 0, PH_SHADOW = 1, PH_IDLE = 2 };
 
 struct LaneRay {
     d3 o, d;
+    d3 inv;           // RN(1/d) per component, for the division-free slab test
+    bool fast;        // direction_allows_fast_slab(d)
     float t;          // ray.t
     float tclosest;   // *tclosest
     uint32_t slot;    // TriRecord slot of closestIndex (kNoNode = none recorded -> triangle 0)
@@ -46,11 +49,19 @@ struct LaneRay {
 // LDS stack: entry e of lane l at [e*64 + l]
 struct StackEntry { uint32_t ref; float tmin; };
 
+// both paths give the reference's floats; the fast one falls back when it cannot prove it
+__device__ __forceinline__ void box_test(const LaneRay &r, const double *bmin, const double *bmax, float &tmin,
+                                         float &tmax) {
+    if (!r.fast || slab_fast(r.o, r.inv, bmin, bmax, tmin, tmax)) slab(r.o, r.d, bmin, bmax, tmin, tmax);
+}
+
 __device__ __forceinline__ void start_traversal(LaneRay &r, const FrameParams &P) {
     // (COUNT: callers book the root's box test)
+    r.fast = direction_allows_fast_slab(r.d);
+    r.inv = make_d3(1.0 / r.d.x, 1.0 / r.d.y, 1.0 / r.d.z);
     // root box test (bvh.cpp:205 at nodeIdx = rootNodeIdx)
     float tmin, tmax;
-    slab(r.o, r.d, P.root_min, P.root_max, tmin, tmax);
+    box_test(r, P.root_min, P.root_max, tmin, tmax);
     const bool pass = tmax >= tmin && tmin < r.t && tmax > 0;
     r.cur = pass ? P.root_ref : kNoNode;
     r.sp = 0;
@@ -82,8 +93,15 @@ __device__ __forceinline__ void step_inner(LaneRay &r, const WideNode *__restric
     const double rmin[3] = {a1.z, a1.w, a2.x}, rmax[3] = {a2.y, a2.z, a2.w};
 
     float ltmin, ltmax, rtmin, rtmax;
-    slab(r.o, r.d, lmin, lmax, ltmin, ltmax);
-    slab(r.o, r.d, rmin, rmax, rtmin, rtmax);
+    bool redo = !r.fast;
+    if (!redo) {
+        redo = slab_fast(r.o, r.inv, lmin, lmax, ltmin, ltmax);
+        redo |= slab_fast(r.o, r.inv, rmin, rmax, rtmin, rtmax);
+    }
+    if (redo) {     // rare: a quotient too close to a binary32 rounding boundary (or an exotic direction)
+        slab(r.o, r.d, lmin, lmax, ltmin, ltmax);
+        slab(r.o, r.d, rmin, rmax, rtmin, rtmax);
+    }
     const bool lpass = ltmax >= ltmin && ltmin < r.t && ltmax > 0;
     // ray.t can only shrink while the left subtree is walked, so a right child failing
     // `tmin < ray.t` now fails it later as well; the survivors are re-checked when popped.
@@ -162,24 +180,6 @@ __device__ __forceinline__ void step_leaf(LaneRay &r, const TriRecord *__restric
     }
 }
 
-__device__ __forceinline__ d3 primary_direction(const FrameParams &P, float px, float py) {
-    // CanvasToViewport (raythread.cpp:186-194) then v * rotation (mymath.h:68-75)
-    const double vx = (double)px * (double)P.inv_height, vy = (double)py * (double)P.inv_height, vz = (double)1.0f;
-    return make_d3(vx * P.rot[0] + vy * P.rot[3] + vz * P.rot[6], vx * P.rot[1] + vy * P.rot[4] + vz * P.rot[7],
-                   vx * P.rot[2] + vy * P.rot[5] + vz * P.rot[8]);
-}
-
-__device__ __forceinline__ int32_t jitter_int(const FrameParams &P, uint32_t xi, uint32_t yi, uint32_t sample,
-                                              uint32_t axis) {
-    if (P.rng_mode == CTGPU_RNG_LIBC) {
-        const uint64_t row = (uint64_t)P.row_ordinal[yi];
-        const uint64_t k = ((uint64_t)xi * P.traced_rows + row) * 32u + sample * 2u + axis;
-        return P.rand_table[k];
-    }
-    const uint64_t k = ((uint64_t)xi * (uint64_t)P.height + yi) * 32u + sample * 2u + axis;
-    return hash_rand(P.rng_seed, k);
-}
-
 }  // namespace
 
 // ------------------------------------------------------------------------------------
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(kWave) void ct_trace_tiles(const FrameParams P) {
     Counters<COUNT> cnt;
     LaneRay r;
     r.cur = kNoNode; r.sp = 0; r.leaf_left = 0; r.t = kNoHit; r.tclosest = kFarAway; r.slot = kNoNode;
-    r.o = eye; r.d = make_d3(0, 0, 1);
+    r.o = eye; r.d = make_d3(0, 0, 1); r.inv = make_d3(0, 0, 1); r.fast = false;
 
     // sample iteration state (raythread.cpp:462-504)
     uint32_t sample = 0;
@@ -288,6 +288,12 @@ __global__ __launch_bounds__(kWave) void ct_trace_tiles(const FrameParams P) {
         else if (n_c >= P.thresh_c) pick = 2;
         else pick = (n_a >= n_b && n_a >= n_c) ? 0 : ((n_b >= n_c) ? 1 : 2);
 
+        if (COUNT && lane == 0) {
+            // divergence statistics: phase executions and the lanes each one served
+            const int served = pick == 0 ? n_a : (pick == 1 ? n_b : n_c);
+            atomicAdd(&P.counters[5 + pick * 2], 1ull);
+            atomicAdd(&P.counters[6 + pick * 2], (unsigned long long)served);
+        }
         // ---------------- (A) inner nodes
         if (pick == 0) {
             if (want_a) {
@@ -459,7 +465,7 @@ __global__ __launch_bounds__(kWave) void ct_trace_ray_list(const FrameParams P, 
     LaneRay r;
     bool busy = i < n;
     r.cur = kNoNode; r.sp = 0; r.leaf_left = 0; r.t = kNoHit; r.tclosest = kFarAway; r.slot = kNoNode;
-    r.o = make_d3(0, 0, 0); r.d = make_d3(0, 0, 1);
+    r.o = make_d3(0, 0, 0); r.d = make_d3(0, 0, 1); r.inv = make_d3(0, 0, 1); r.fast = false;
     if (busy) {
         r.o = load_d3(rays[i].origin);
         r.d = load_d3(rays[i].direction);

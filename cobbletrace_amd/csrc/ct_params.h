@@ -50,6 +50,26 @@ struct FrameParams {
     uint32_t *overflow;                    // set to 1 on traversal-stack overflow
 };
 
+// Buffers and knobs of the wavefront pipeline (ct_pipeline.hip); all pointers are device memory.
+struct PipelineParams {
+    float2   *coords;            // [n_samples] jittered canvas position (supersampled frames)
+    uint2    *hits;              // [n_samples] {ray.t bits, closest TriRecord slot | kNoNode | invalid}
+    uint8_t  *shadow;            // [n_shadow_lights][n_samples] 1 = that light is blocked
+    unsigned long long *queue;   // [1 + 32] next ray index of the primary walk / of each light's shadow walk
+    uint32_t light_slot;         // shadow walk: which non-ambient light this launch handles
+    void     *spill;             // [walk_blocks][spill_depth][64] stack entries beyond the LDS part
+    const uint32_t *shadow_lights;   // [n_shadow_lights] index into lights[]
+    uint64_t n_samples;
+    uint32_t n_shadow_lights;
+    uint32_t lds_depth, spill_depth, walk_blocks;
+    uint32_t chunk;              // ray ids a wave reserves per queue atomic (multiple of 64)
+    int32_t  thresh_r, thresh_a, thresh_b;
+};
+
+uint64_t pipeline_sample_count(const FrameParams &P, bool ss);
+int  pipeline_walk_occupancy(size_t lds_bytes);
+void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hipStream_t stream);
+
 void launch_trace_tiles(const FrameParams &P, uint32_t n_tiles, bool ss, bool reflect, bool count, hipStream_t stream);
 void launch_trace_ray_list(const FrameParams &P, const ctgpu_ray *rays, uint64_t n, ctgpu_hit *hits, hipStream_t stream);
 void launch_assemble(const FrameParams &P, const uint32_t *all_tiles, uint32_t *fb, hipStream_t stream);

@@ -1,0 +1,554 @@
+// ct_pipeline.hip -- wavefront pipeline of lean gfx950 kernels (the fast path).
+//
+// The megakernel in ct_kernels.hip keeps a whole pixel's life in one lane; its shading
+// code (pow, sqrt, HSV) drives the register count past 200 VGPRs, i.e. two waves per
+// SIMD, and the traversal -- which is issue-bound -- starves.  Here the frame is a short
+// chain of kernels over flat per-sample arrays in HBM (a few hundred MB at 1080p x 16 spp,
+// a rounding error against 288 GB and 8 TB/s):
+//
+//   ct_sample_grid   lane = pixel   jittered sample positions (the float residue of
+//                                   raythread.cpp:462-504 is sequential per pixel)
+//   ct_walk<PRIMARY> lane = ray     closest-hit traversal            -> hits[sample]
+//   ct_walk<SHADOW>  lane = ray     any-hit traversal per non-ambient light of every hit
+//                                   sample                           -> shadow bit mask
+//   ct_shade         lane = pixel   lighting + HSV + ordered supersample blend -> tile
+//
+// ct_walk is a PERSISTENT kernel: one wave per workgroup, as many workgroups as fit on the
+// chip, every lane pulls the next ray index from a global counter as soon as its ray is
+// done (wave-aggregated atomic), so lanes never wait for the slowest ray of "their" tile.
+// Only traversal state lives in registers (ray, inverse direction, t, closest slot, cursor),
+// which is what lets 6-8 waves share a SIMD.  The traversal stack is per lane: the first
+// P.lds_depth entries in LDS, deeper ones (rare) in a per-wave spill area in HBM.
+//
+// Scope: scenes without reflective materials, subsampling off, at most 32 non-ambient
+// lights.  Everything else takes the megakernel.  Semantics and citations: ct_device.h,
+// ct_kernels.hip header.
+#include "ct_params.h"
+#include "ct_raygen.h"
+
+using namespace ctd;
+
+namespace {
+
+constexpr int kWave = 64;
+#ifndef CT_WALK_WAVES
+#define CT_WALK_WAVES 5      // waves per SIMD the traversal kernel is register-budgeted for
+#endif
+constexpr uint32_t kInvalidSample = 0xfffffffeu;   // hits[].slot of a sample that is not part of the frame
+
+struct StackEntry { uint32_t ref; float tmin; };
+
+// ------------------------------------------------------------------ sample id <-> pixel
+// Supersampled frames: 16 consecutive ids are the 16 samples of a pixel, 4 consecutive
+// pixels are a 2x2 block (a wave = a 2x2-pixel footprint: rays as coherent as they get).
+// Single-sample frames: 64 consecutive ids are an 8x8 tile.
+struct PixelOfSample { uint32_t xi, local_row, sample; };
+
+template <bool SS>
+__device__ __forceinline__ PixelOfSample pixel_of(const FrameParams &P, uint64_t id) {
+    PixelOfSample r;
+    if (SS) {
+        r.sample = (uint32_t)(id & 15u);
+        const uint32_t p = (uint32_t)(id >> 4);
+        const uint32_t within = p & 3u, blk = p >> 2;
+        const uint32_t blocks_x = (P.square + 1u) >> 1;
+        r.xi = (blk % blocks_x) * 2u + (within & 1u);
+        r.local_row = (blk / blocks_x) * 2u + (within >> 1);
+    } else {
+        r.sample = 0;
+        const uint32_t within = (uint32_t)(id & 63u), tile = (uint32_t)(id >> 6);
+        const uint32_t tiles_x = (P.square + 7u) >> 3;
+        r.xi = (tile % tiles_x) * 8u + (within & 7u);
+        r.local_row = (tile / tiles_x) * 8u + (within >> 3);
+    }
+    return r;
+}
+
+// frame row of a partition-local row (interleaved row tiles), and whether the pixel exists
+__device__ __forceinline__ bool pixel_in_frame(const FrameParams &P, uint32_t xi, uint32_t local_row, uint32_t &yi) {
+    const uint32_t local_tile = local_row / P.tile_rows;
+    yi = (local_tile * P.part_count + P.part_index) * P.tile_rows + (local_row % P.tile_rows);
+    if (xi >= P.square || local_row >= P.local_rows || yi >= P.rendered_rows) return false;
+    // off-bitmap pixels are computed and dropped by the reference (draw2d.h:11-14): not traced here
+    const int row = P.height / 2 - ((int)yi - P.half), col = (int)xi - P.half + P.width / 2;
+    return row >= 0 && row < P.height && col >= 0 && col < P.width;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------
+// ct_sample_grid: jittered sample positions of every pixel (supersampled frames only).
+// One lane = one pixel, walking the 4x4 stratified grid exactly as raythread.cpp:462-504
+// does, including the float add/subtract residue that carries from sample to sample.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ct_sample_grid(const FrameParams P, const PipelineParams W) {
+    const uint64_t pixel_slot = (uint64_t)blockIdx.x * 256u + threadIdx.x;      // id >> 4
+    if (pixel_slot * 16u >= W.n_samples) return;
+    const PixelOfSample px = pixel_of<true>(P, pixel_slot * 16u);
+    uint32_t yi;
+    if (!pixel_in_frame(P, px.xi, px.local_row, yi)) return;
+    const float fx = (float)((int)px.xi - P.half), fy = (float)((int)yi - P.half);
+    const float jitter = 0.25f / 8.0f;
+    float run_x = fx;
+    for (uint32_t xs = 0; xs < 4; xs++) {
+        float run_y = fy;
+        for (uint32_t ys = 0; ys < 4; ys++) {
+            const uint32_t s = xs * 4u + ys;
+            float jx = (float)jitter_int(P, px.xi, yi, s, 0) / 2147483648.0f;
+            float jy = (float)jitter_int(P, px.xi, yi, s, 1) / 2147483648.0f;
+            jx = (jx * (2.0f * jitter)) - jitter;
+            jy = (jy * (2.0f * jitter)) - jitter;
+            run_x += jx;
+            run_y += jy;
+            W.coords[pixel_slot * 16u + s] = make_float2(run_x, run_y);
+            run_y -= jy;
+            run_y += 0.25f;
+            run_x -= jx;
+        }
+        run_x += 0.25f;
+    }
+}
+
+namespace {
+
+// position of a sample on the canvas: from the grid buffer (supersampled) or the pixel centre
+template <bool SS>
+__device__ __forceinline__ bool sample_position(const FrameParams &P, const PipelineParams &W, uint64_t id, float &px,
+                                                float &py) {
+    const PixelOfSample s = pixel_of<SS>(P, id);
+    uint32_t yi;
+    if (!pixel_in_frame(P, s.xi, s.local_row, yi)) return false;
+    if (SS) {
+        const float2 c = W.coords[id];
+        px = c.x; py = c.y;
+    } else {
+        px = (float)((int)s.xi - P.half);
+        py = (float)((int)yi - P.half);
+    }
+    return true;
+}
+
+// ------------------------------------------------------------------ traversal state of one lane
+struct Walker {
+    d3 o, d, inv;
+    float t;              // ray.t
+    uint32_t slot;        // closest record (kNoNode = none); *tclosest == t whenever slot is set
+    uint32_t cur;         // node / triangle slot to process next, kNoNode = traversal finished
+    uint32_t sp;          // stack entries in use
+    uint32_t leaf_left;   // triangles left in the current leaf (0 = cur is an inner node)
+    bool fast;            // division-free slab test allowed for this direction
+};
+
+// Per-lane stack of pending right children: {child reference, approximate tmin} plus the
+// WideNode that holds the child's box (needed only when the popped tmin is too close to
+// ray.t to be trusted, see pop_next).  Entry e of lane l: [e][l]; the first lds_depth
+// entries in LDS, deeper ones in this wave's spill area in HBM.
+struct WalkStack {
+    StackEntry *lds;          // [lds_depth][64]
+    uint32_t *lds_parent;     // [lds_depth][64]
+    StackEntry *spill;        // [spill_depth][64]
+    uint32_t *spill_parent;   // [spill_depth][64]
+    uint32_t lds_depth, spill_depth, lane;
+    uint32_t *overflow;
+
+    __device__ __forceinline__ void push(Walker &w, uint32_t ref, float tmin, uint32_t parent) const {
+        const StackEntry e{ref, tmin};
+        if (w.sp < lds_depth) {
+            lds[w.sp * kWave + lane] = e;
+            lds_parent[w.sp * kWave + lane] = parent;
+        } else if (w.sp - lds_depth < spill_depth) {
+            spill[(w.sp - lds_depth) * kWave + lane] = e;
+            spill_parent[(w.sp - lds_depth) * kWave + lane] = parent;
+        } else {
+            atomicOr(overflow, 1u);
+            return;
+        }
+        w.sp += 1;
+    }
+    __device__ __forceinline__ StackEntry top(const Walker &w) const {       // entry sp-1
+        const uint32_t i = w.sp - 1u;
+        return (i < lds_depth) ? lds[i * kWave + lane] : spill[(i - lds_depth) * kWave + lane];
+    }
+    __device__ __forceinline__ uint32_t top_parent(const Walker &w) const {
+        const uint32_t i = w.sp - 1u;
+        return (i < lds_depth) ? lds_parent[i * kWave + lane] : spill_parent[(i - lds_depth) * kWave + lane];
+    }
+};
+
+__device__ __forceinline__ void enter(Walker &w, uint32_t ref) {
+    w.cur = ref;
+    w.leaf_left = 0;
+    if (ref != kNoNode && (ref & kLeafBit)) {
+        w.cur = ref & ~kLeafBit;
+        w.leaf_left = 0xffffffffu;      // taken from the first record
+    }
+}
+
+constexpr uint32_t kExactPending = 0xfffffffeu;      // leaf_left: redo this inner node with real divisions
+constexpr uint32_t kExactPopPending = 0xfffffffdu;   // leaf_left: cur = parent whose RIGHT child must be re-tested
+
+// Pop until an entry survives `tmin < ray.t`, the deferred half of the right child's box test
+// (bvh.cpp:205 when the reference enters node left+1).  The stored tmin is approximate (one
+// float step); if it is within one step of ray.t the verdict is not certain and the child
+// is parked for an exact re-test (phase E).
+__device__ __forceinline__ void pop_next(Walker &w, const WalkStack &st) {
+    const int32_t kt = float_ordinal(w.t);
+    while (w.sp > 0) {
+        const StackEntry e = st.top(w);
+        if (ordinals_near(float_ordinal(e.tmin), kt, 1u)) {
+            w.cur = st.top_parent(w);
+            w.leaf_left = kExactPopPending;
+            w.sp -= 1;
+            return;
+        }
+        w.sp -= 1;
+        if (e.tmin < w.t) { enter(w, e.ref); return; }
+    }
+    w.cur = kNoNode;
+    w.leaf_left = 0;
+}
+
+// (A) open an inner node: both children's boxes from one 128-byte line, division-free.
+// A lane that cannot prove all six verdicts parks the node for phase (E) instead of dividing
+// here: keeping the rare path out of this block keeps its registers out, too.
+__device__ __forceinline__ void step_inner(Walker &w, const WideNode *__restrict__ nodes, const WalkStack &st) {
+    const WideNode *n = nodes + w.cur;
+    const double4 a0 = *reinterpret_cast<const double4 *>(&n->lmin[0]);   // lmin xyz, lmax x
+    const double4 a1 = *reinterpret_cast<const double4 *>(&n->lmax[1]);   // lmax yz, rmin xy
+    const double4 a2 = *reinterpret_cast<const double4 *>(&n->rmin[2]);   // rmin z, rmax xyz
+    const uint2 refs = *reinterpret_cast<const uint2 *>(&n->lref);
+    const double lmin[3] = {a0.x, a0.y, a0.z}, lmax[3] = {a0.w, a1.x, a1.y};
+    const double rmin[3] = {a1.z, a1.w, a2.x}, rmax[3] = {a2.y, a2.z, a2.w};
+    float ltmin, ltmax, rtmin, rtmax;
+    slab_approx(w.o, w.inv, lmin, lmax, ltmin, ltmax);
+    slab_approx(w.o, w.inv, rmin, rmax, rtmin, rtmax);
+    const int32_t kt = float_ordinal(w.t);
+    bool lpass, rpass;
+    const bool sure = box_verdict(ltmin, ltmax, w.t, kt, lpass) & box_verdict(rtmin, rtmax, w.t, kt, rpass);
+    if (!(sure & w.fast)) { w.leaf_left = kExactPending; return; }
+    const uint32_t parent = w.cur;
+    if (lpass) {
+        // ray.t only shrinks while the left subtree is walked: a right child failing now fails
+        // later too; survivors are re-checked against the then-current ray.t when popped
+        if (rpass) st.push(w, refs.y, rtmin, parent);
+        enter(w, refs.x);
+    } else if (rpass) {
+        enter(w, refs.y);
+    } else {
+        pop_next(w, st);
+    }
+}
+
+// (E) the rare exact paths, with the reference's divisions (bvh.cpp:165-179)
+__device__ __forceinline__ void step_exact(Walker &w, const WideNode *__restrict__ nodes, const WalkStack &st) {
+    const WideNode *n = nodes + w.cur;
+    const uint2 refs = *reinterpret_cast<const uint2 *>(&n->lref);
+    float rtmin, rtmax;
+    slab(w.o, w.d, n->rmin, n->rmax, rtmin, rtmax);
+    const bool rpass = rtmax >= rtmin && rtmin < w.t && rtmax > 0;
+    if (w.leaf_left == kExactPopPending) {
+        // a popped right child: the whole test with the current ray.t, as the reference does it
+        if (rpass) enter(w, refs.y);
+        else pop_next(w, st);
+        return;
+    }
+    float ltmin, ltmax;
+    slab(w.o, w.d, n->lmin, n->lmax, ltmin, ltmax);
+    const bool lpass = ltmax >= ltmin && ltmin < w.t && ltmax > 0;
+    const uint32_t parent = w.cur;
+    if (lpass) {
+        if (rpass) st.push(w, refs.y, rtmin, parent);     // exact tmin is fine as an "approximate" one
+        enter(w, refs.x);
+    } else if (rpass) {
+        enter(w, refs.y);
+    } else {
+        pop_next(w, st);
+    }
+}
+
+__device__ __forceinline__ void begin_ray(Walker &w, const FrameParams &P) {
+    w.fast = direction_allows_fast_slab(w.d);
+    w.inv = make_d3(1.0 / w.d.x, 1.0 / w.d.y, 1.0 / w.d.z);
+    // root box (bvh.cpp:205 at rootNodeIdx)
+    float tmin, tmax;
+    bool pass;
+    slab_approx(w.o, w.inv, P.root_min, P.root_max, tmin, tmax);
+    if (!(box_verdict(tmin, tmax, w.t, float_ordinal(w.t), pass) & w.fast)) {
+        slab(w.o, w.d, P.root_min, P.root_max, tmin, tmax);
+        pass = tmax >= tmin && tmin < w.t && tmax > 0;
+    }
+    w.sp = 0;
+    w.slot = kNoNode;
+    enter(w, pass ? P.root_ref : kNoNode);
+}
+
+// (B) one triangle of the current leaf
+template <bool ANY_HIT>
+__device__ __forceinline__ void step_leaf(Walker &w, const TriRecord *__restrict__ tris, const WalkStack &st) {
+    const TriRecord *rec = tris + w.cur;
+    const double2 b0 = *reinterpret_cast<const double2 *>(&rec->p1[0]);
+    const double2 b1 = *reinterpret_cast<const double2 *>(&rec->p1[2]);
+    const double2 b2 = *reinterpret_cast<const double2 *>(&rec->e1[1]);
+    const double2 b3 = *reinterpret_cast<const double2 *>(&rec->e2[0]);
+    const double2 b4 = *reinterpret_cast<const double2 *>(&rec->e2[2]);
+    const d3 p1 = make_d3(b0.x, b0.y, b1.x), e1 = make_d3(b1.y, b2.x, b2.y), e2 = make_d3(b3.x, b3.y, b4.x);
+    if (w.leaf_left == 0xffffffffu) w.leaf_left = (uint32_t)(__double_as_longlong(b4.y) >> 32);
+
+    const float before = w.t;
+    const bool hit = triangle_test(w.o, w.d, w.t, p1, e1, e2);
+    // bvh.cpp:212-215 with *tclosest == (slot set ? ray.t before this test : 2^32)
+    const float tclosest = (w.slot != kNoNode) ? before : kFarAway;
+    if (hit && w.t != kNoHit && w.t < tclosest) w.slot = w.cur;
+    w.leaf_left -= 1;
+    w.cur += 1;
+    if (ANY_HIT && w.t != kNoHit) {          // shadow ray decided (raythread.cpp:303-307)
+        w.cur = kNoNode; w.leaf_left = 0; w.sp = 0;
+        return;
+    }
+    if (w.leaf_left == 0) pop_next(w, st);
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------
+// ct_walk: persistent traversal kernel.
+//   KIND 0  primary rays: ray index = sample id; result hits[id] = {ray.t, slot}
+//   KIND 1  shadow rays of ONE light (W.light_slot): ray index = sample id as well, but only
+//           samples whose primary ray found something get a ray; result: shadow byte of
+//           (light, sample) set when the light is blocked
+// Ray indices are handed out in chunks of W.chunk consecutive ids: one global atomic per chunk
+// and wave (a single head word saturates near 90 dequeues/us on this chip, so per-ray or
+// per-refill atomics would serialise the whole kernel), then the wave serves its lanes from
+// the chunk with ballots only.
+// ------------------------------------------------------------------------------------
+
+template <int KIND, bool SS>
+__global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk(const FrameParams P, const PipelineParams W) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    WalkStack st;
+    st.lds = reinterpret_cast<StackEntry *>(lds_raw);
+    st.lds_parent = reinterpret_cast<uint32_t *>(lds_raw + (size_t)W.lds_depth * kWave * sizeof(StackEntry));
+    st.lane = threadIdx.x;
+    st.lds_depth = W.lds_depth;
+    st.spill_depth = W.spill_depth;
+    // this wave's spill area: spill_depth x 64 entries of 8 bytes, then as many parent words
+    unsigned char *spill_base = reinterpret_cast<unsigned char *>(W.spill) + (size_t)blockIdx.x * W.spill_depth * kWave * 12u;
+    st.spill = reinterpret_cast<StackEntry *>(spill_base);
+    st.spill_parent = reinterpret_cast<uint32_t *>(spill_base + (size_t)W.spill_depth * kWave * sizeof(StackEntry));
+    st.overflow = P.overflow;
+    const uint32_t lane = threadIdx.x;
+    const unsigned long long lanes_below = (1ull << lane) - 1ull;
+    const uint64_t n_rays = W.n_samples;
+    unsigned long long *queue = W.queue + (KIND == 0 ? 0u : 1u + W.light_slot);
+    const Light shadow_light = (KIND == 1) ? P.lights[W.shadow_lights[W.light_slot]] : Light{};
+    uint8_t *blocked = (KIND == 1) ? W.shadow + (size_t)W.light_slot * W.n_samples : nullptr;
+    const d3 eye = make_d3(P.cam[0], P.cam[1], P.cam[2]);
+
+    Walker w;
+    w.o = eye; w.d = make_d3(0, 0, 1); w.inv = make_d3(0, 0, 1);
+    w.t = kNoHit; w.slot = kNoNode; w.cur = kNoNode; w.sp = 0; w.leaf_left = 0; w.fast = false;
+    uint64_t ray_id = 0;
+    bool has_ray = false;
+    // wave-uniform chunk cursor
+    uint64_t chunk_next = 0, chunk_end = 0;
+    bool wave_drained = false;
+    uint32_t n_traced = 0;
+
+    for (;;) {
+        const bool walking = has_ray && w.cur != kNoNode;
+        const bool finished = has_ray && w.cur == kNoNode;
+        const bool want_e = walking && w.leaf_left >= kExactPopPending && w.leaf_left <= kExactPending;
+        const bool want_b = walking && w.leaf_left != 0 && !want_e;
+        const bool want_a = walking && w.leaf_left == 0;
+        const unsigned long long m_a = __ballot(want_a), m_b = __ballot(want_b);
+        const int n_a = __popcll(m_a), n_b = __popcll(m_b);
+        const int n_r = wave_drained ? __popcll(__ballot(finished)) : __popcll(__ballot(!walking));
+        if (__ballot(want_e) != 0ull) {       // rare (about 1e-7 per node): settle it at once
+            if (want_e) step_exact(w, P.nodes, st);
+            continue;
+        }
+        if (n_r == 0 && n_a == 0 && n_b == 0) break;
+
+        // ---------------- (R) retire finished rays, hand out new ones
+        if (n_r >= W.thresh_r || (n_a == 0 && n_b == 0)) {
+            if (finished) {
+                if (KIND == 0) W.hits[ray_id] = make_uint2(__float_as_uint(w.t), w.slot);
+                else if (w.t != kNoHit) blocked[ray_id] = 1;
+                has_ray = false;
+            }
+            for (;;) {
+                const unsigned long long m_i = __ballot(!has_ray);
+                if (m_i == 0ull || wave_drained) break;
+                if (chunk_next >= chunk_end) {
+                    unsigned long long base = 0;
+                    if (lane == 0) base = atomicAdd(queue, (unsigned long long)W.chunk);
+                    base = __shfl(base, 0);
+                    if (base >= n_rays) { wave_drained = true; break; }
+                    chunk_next = base;
+                    chunk_end = (base + W.chunk < n_rays) ? base + W.chunk : n_rays;
+                }
+                const uint64_t avail = chunk_end - chunk_next;
+                const uint32_t rank = (uint32_t)__popcll(m_i & lanes_below);
+                const bool take = !has_ray && rank < avail;
+                const uint64_t id = chunk_next + rank;
+                const uint64_t wanted = (uint64_t)__popcll(m_i);
+                chunk_next += (wanted < avail) ? wanted : avail;
+                if (take) {
+                    float px, py;
+                    bool live = sample_position<SS>(P, W, id, px, py);
+                    if (KIND == 0) {
+                        if (live) {
+                            w.o = eye;
+                            w.d = primary_direction(P, px, py);
+                        } else {
+                            W.hits[id] = make_uint2(__float_as_uint(kNoHit), kInvalidSample);
+                        }
+                    } else if (live) {
+                        const uint2 h = W.hits[id];
+                        live = __uint_as_float(h.x) != kNoHit;           // ClosestIntersection found something
+                        if (live) {
+                            // P = origin + tclosest * dir (raythread.cpp:360); tclosest = ray.t when a
+                            // triangle was recorded, else 2^32
+                            const float tclosest = (h.y != kNoNode) ? __uint_as_float(h.x) : kFarAway;
+                            w.o = eye + scale((double)tclosest, primary_direction(P, px, py));
+                            w.d = (shadow_light.type == CTGPU_LIGHT_POINT) ? load_d3(shadow_light.position) - w.o
+                                                                           : load_d3(shadow_light.direction);
+                        }
+                    }
+                    if (live) {
+                        w.t = kNoHit;
+                        begin_ray(w, P);
+                        ray_id = id;
+                        has_ray = true;
+                        n_traced += 1;
+                    }
+                }
+            }
+            continue;
+        }
+        // ---------------- (A) / (B): the fuller queue goes first unless the other reached its threshold
+        const bool do_a = (n_a >= W.thresh_a) || (n_b < W.thresh_b && n_a >= n_b) || n_b == 0;
+        if (do_a && n_a > 0) {
+            if (want_a) step_inner(w, P.nodes, st);
+        } else {
+            if (want_b) step_leaf<KIND == 1>(w, P.tris, st);
+        }
+    }
+
+    // ray counters: one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) n_traced += __shfl_down(n_traced, off);
+    if (lane == 0) atomicAdd(&P.counters[KIND == 0 ? 0 : 1], (unsigned long long)n_traced);
+}
+
+// ------------------------------------------------------------------------------------
+// ct_shade: lighting of every sample of a pixel in order, running blend, pixel store.
+// raythread.cpp:353-366 (TraceRay without reflection), 275-327 (ComputeLighting with the
+// shadow decisions read from the mask), 482-498 (blend), color.h.
+// ------------------------------------------------------------------------------------
+template <bool SS>
+__global__ __launch_bounds__(256) void ct_shade(const FrameParams P, const PipelineParams W) {
+    const uint64_t slot = (uint64_t)blockIdx.x * 256u + threadIdx.x;     // pixel slot: id >> 4 (SS) or id
+    const uint64_t first = SS ? slot * 16u : slot;
+    if (first >= W.n_samples) return;
+    const PixelOfSample px = pixel_of<SS>(P, first);
+    uint32_t yi;
+    if (!pixel_in_frame(P, px.xi, px.local_row, yi)) return;
+    const d3 eye = make_d3(P.cam[0], P.cam[1], P.cam[2]);
+
+    uint32_t pixel_color = 0;
+    for (uint32_t s = 0; s < (SS ? 16u : 1u); s++) {
+        const uint64_t id = first + s;
+        const uint2 h = W.hits[id];
+        uint32_t color = kBackground;
+        if (__uint_as_float(h.x) != kNoHit) {
+            float cx, cy;
+            if (SS) { const float2 c = W.coords[id]; cx = c.x; cy = c.y; }
+            else { cx = (float)((int)px.xi - P.half); cy = (float)((int)yi - P.half); }
+            const d3 dir = primary_direction(P, cx, cy);
+            const uint32_t rec_slot = (h.y != kNoNode) ? h.y : P.slot_of_triangle0;
+            const float tclosest = (h.y != kNoNode) ? __uint_as_float(h.x) : kFarAway;
+            const TriRecord *rec = P.tris + rec_slot;
+            const Material m = P.materials[rec->triangle];
+            const d3 position = eye + scale((double)tclosest, dir);
+            d3 normal = cross(load_d3(rec->e1), load_d3(rec->e2));
+            if (!(dotf(normal, dir) < 0)) normal = -normal;
+            const d3 view = -dir;
+
+            float intensity = 0.0f;
+            uint32_t shadow_slot = 0;
+            for (uint32_t li = 0; li < P.n_lights; li++) {
+                const Light L = P.lights[li];
+                d3 to_light;
+                if (L.type == CTGPU_LIGHT_AMBIENT) { intensity += L.intensity; continue; }
+                else if (L.type == CTGPU_LIGHT_POINT) to_light = load_d3(L.position) - position;
+                else if (L.type == CTGPU_LIGHT_DIRECTIONAL) to_light = load_d3(L.direction);
+                else continue;
+                const bool in_shadow = W.shadow[(size_t)shadow_slot * W.n_samples + id] != 0;
+                shadow_slot += 1;
+                if (in_shadow) continue;
+                const float n_dot_l = dotf(normal, to_light);
+                if (n_dot_l > 0) intensity += L.intensity * n_dot_l / (lengthf(normal) * lengthf(to_light));
+                if (m.specular != -1) {
+                    const double nl = (double)dotf(normal, to_light);
+                    const d3 reflected = scale(nl, scale(2.0, normal)) - to_light;
+                    const float r_dot_v = dotf(reflected, view);
+                    if (r_dot_v > 0) {
+                        const float base = r_dot_v / (lengthf(reflected) * lengthf(view));
+                        intensity = (float)((double)intensity + (double)L.intensity * pow((double)base, (double)m.specular));
+                    }
+                }
+            }
+            color = shade_value(m.color, intensity);
+        }
+        pixel_color = (s == 0) ? color : blend_sample(pixel_color, color);
+    }
+    P.out[(size_t)px.local_row * P.square + px.xi] = pixel_color;
+}
+
+// ------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------
+namespace ctd {
+
+uint64_t pipeline_sample_count(const FrameParams &P, bool ss) {
+    if (ss) {
+        const uint64_t blocks = (uint64_t)((P.square + 1u) / 2u) * ((P.local_rows + 1u) / 2u);
+        return blocks * 4u * 16u;
+    }
+    const uint64_t tiles = (uint64_t)((P.square + 7u) / 8u) * ((P.local_rows + 7u) / 8u);
+    return tiles * 64u;
+}
+
+int pipeline_walk_occupancy(size_t lds_bytes) {
+    int a = 0, b = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, ct_walk<0, true>, kWave, lds_bytes);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, ct_walk<1, true>, kWave, lds_bytes);
+    return a < b ? a : b;
+}
+
+void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hipStream_t stream) {
+    const size_t lds = (size_t)W.lds_depth * kWave * 12u;      // entries + parent words
+    const uint32_t pixel_slots = (uint32_t)(ss ? W.n_samples / 16u : W.n_samples);
+    const uint32_t pixel_blocks = (pixel_slots + 255u) / 256u;
+    if (W.n_samples == 0) return;
+    if (ss) {
+        hipLaunchKernelGGL(ct_sample_grid, dim3(pixel_blocks), dim3(256), 0, stream, P, W);
+        hipLaunchKernelGGL((ct_walk<0, true>), dim3(W.walk_blocks), dim3(kWave), lds, stream, P, W);
+        for (uint32_t j = 0; j < W.n_shadow_lights; j++) {
+            PipelineParams Wj = W;
+            Wj.light_slot = j;
+            hipLaunchKernelGGL((ct_walk<1, true>), dim3(W.walk_blocks), dim3(kWave), lds, stream, P, Wj);
+        }
+        hipLaunchKernelGGL((ct_shade<true>), dim3(pixel_blocks), dim3(256), 0, stream, P, W);
+    } else {
+        hipLaunchKernelGGL((ct_walk<0, false>), dim3(W.walk_blocks), dim3(kWave), lds, stream, P, W);
+        for (uint32_t j = 0; j < W.n_shadow_lights; j++) {
+            PipelineParams Wj = W;
+            Wj.light_slot = j;
+            hipLaunchKernelGGL((ct_walk<1, false>), dim3(W.walk_blocks), dim3(kWave), lds, stream, P, Wj);
+        }
+        hipLaunchKernelGGL((ct_shade<false>), dim3(pixel_blocks), dim3(256), 0, stream, P, W);
+    }
+}
+
+}  // namespace ctd

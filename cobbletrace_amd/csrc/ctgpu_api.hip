@@ -67,11 +67,26 @@ struct ctgpu_ctx {
 
     DeviceArray<uint32_t> tiles;       // compact tile buffer of a whole-frame render
     DeviceArray<uint32_t> fb;          // device framebuffer of ctgpu_render
-    DeviceArray<unsigned long long> counters;   // 8 words
+    DeviceArray<unsigned long long> counters;   // 16 words
     DeviceArray<uint32_t> overflow;    // 1 word
     DeviceArray<int32_t> rand_table;   // LIBC jitter stream
     DeviceArray<int32_t> row_ordinal;
     uint64_t rand_key[4] = {~0ull, ~0ull, ~0ull, ~0ull};   // (seed, offset, count, rows) of the cached table
+
+    // wavefront pipeline (ct_pipeline.hip)
+    DeviceArray<float2> coords;
+    DeviceArray<uint2> hits;
+    DeviceArray<uint8_t> shadow;
+    DeviceArray<unsigned long long> queue;      // 1 + 32 ray counters, then the hit count
+    DeviceArray<unsigned long long> spill;      // stack entries beyond the LDS part
+    DeviceArray<uint32_t> shadow_lights;
+    uint32_t n_shadow_lights = 0;
+    int cu_count = 256;
+    int walk_thresh[3] = {64, 40, 24};          // retire/fetch, inner, leaf (measured best on MI355X)
+    int lds_depth = 12;
+    int blocks_per_cu = 0;                      // 0 = occupancy query
+    int chunk = 0;                              // 0 = sized from the frame
+    bool force_megakernel = false;
 
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -137,14 +152,26 @@ extern "C" int ctgpu_create(int device, ctgpu_ctx **out) {
     HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&ctx->ev0));
     HIP_TRY(hipEventCreate(&ctx->ev1));
-    HIP_TRY(ctx->counters.resize(8));
+    HIP_TRY(ctx->counters.resize(16));
     HIP_TRY(ctx->overflow.resize(1));
-    HIP_TRY(hipMemset(ctx->counters.ptr, 0, 8 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(ctx->counters.ptr, 0, 16 * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(ctx->overflow.ptr, 0, sizeof(uint32_t)));
     if (const char *t = std::getenv("CTGPU_THRESH")) {   // tuning knob: "a,b,c"
         int a, b, c;
         if (std::sscanf(t, "%d,%d,%d", &a, &b, &c) == 3) { ctx->thresh[0] = a; ctx->thresh[1] = b; ctx->thresh[2] = c; }
     }
+    // tuning / A-B knobs of the wavefront pipeline
+    if (const char *t = std::getenv("CTGPU_WALK_THRESH")) {
+        int a, b, c;
+        if (std::sscanf(t, "%d,%d,%d", &a, &b, &c) == 3) { ctx->walk_thresh[0] = a; ctx->walk_thresh[1] = b; ctx->walk_thresh[2] = c; }
+    }
+    if (const char *t = std::getenv("CTGPU_LDS_DEPTH")) ctx->lds_depth = std::max(1, std::atoi(t));
+    if (const char *t = std::getenv("CTGPU_BLOCKS_PER_CU")) ctx->blocks_per_cu = std::max(0, std::atoi(t));
+    if (const char *t = std::getenv("CTGPU_CHUNK")) ctx->chunk = std::max(0, std::atoi(t));
+    if (const char *t = std::getenv("CTGPU_FORCE_MEGAKERNEL")) ctx->force_megakernel = std::atoi(t) != 0;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->cu_count = prop.multiProcessorCount;
+    HIP_TRY(ctx->queue.resize(40));
     *out = ctx;
     return CTGPU_OK;
 }
@@ -156,6 +183,8 @@ extern "C" void ctgpu_destroy(ctgpu_ctx *ctx) {
     ctx->nodes.release(); ctx->tris.release(); ctx->materials.release(); ctx->lights.release();
     ctx->tiles.release(); ctx->fb.release(); ctx->counters.release(); ctx->overflow.release();
     ctx->rand_table.release(); ctx->row_ordinal.release();
+    ctx->coords.release(); ctx->hits.release(); ctx->shadow.release(); ctx->queue.release(); ctx->spill.release();
+    ctx->shadow_lights.release();
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -261,6 +290,15 @@ extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
     HIP_TRY(hipMemcpy(ctx->materials.ptr, s->materials, (size_t)N * sizeof(Material), hipMemcpyHostToDevice));
     if (s->n_lights)
         HIP_TRY(hipMemcpy(ctx->lights.ptr, s->lights, (size_t)s->n_lights * sizeof(Light), hipMemcpyHostToDevice));
+
+    // non-ambient lights, in file order: each gets one shadow ray per hit (raythread.cpp:289-307)
+    std::vector<uint32_t> shadow_lights;
+    for (uint32_t i = 0; i < s->n_lights; i++)
+        if (s->lights[i].type == CTGPU_LIGHT_POINT || s->lights[i].type == CTGPU_LIGHT_DIRECTIONAL) shadow_lights.push_back(i);
+    HIP_TRY(ctx->shadow_lights.resize(std::max<size_t>(shadow_lights.size(), 1)));
+    if (!shadow_lights.empty())
+        HIP_TRY(hipMemcpy(ctx->shadow_lights.ptr, shadow_lights.data(), shadow_lights.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    ctx->n_shadow_lights = (uint32_t)shadow_lights.size();
 
     ctx->n_triangles = N;
     ctx->n_lights = s->n_lights;
@@ -391,13 +429,70 @@ int check_overflow(ctgpu_ctx *ctx) {
 }
 
 int read_counters(ctgpu_ctx *ctx, ctgpu_stats *st) {
-    unsigned long long c[8];
+    unsigned long long c[16];
     HIP_TRY(hipMemcpy(c, ctx->counters.ptr, sizeof c, hipMemcpyDeviceToHost));
+    if (std::getenv("CTGPU_DEBUG_PHASES") && c[5])
+        std::fprintf(stderr, "phases: A %llu x %.1f lanes, B %llu x %.1f lanes, C %llu x %.1f lanes\n", c[5],
+                     (double)c[6] / c[5], c[7], c[7] ? (double)c[8] / c[7] : 0.0, c[9], c[9] ? (double)c[10] / c[9] : 0.0);
     HIP_TRY(hipMemset(ctx->counters.ptr, 0, sizeof c));
     if (st) {
         st->rays_primary = c[0]; st->rays_shadow = c[1]; st->rays_reflect = c[2];
         st->node_visits = c[3]; st->triangle_tests = c[4];
     }
+    return CTGPU_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ one partition's trace
+namespace {
+
+// The wavefront pipeline covers what the shipped import scenes need; reflective materials,
+// subsampling and more than 32 shadow-casting lights take the megakernel.
+bool pipeline_eligible(const ctgpu_ctx *ctx, const ctgpu_frame_desc *f) {
+    if (ctx->force_megakernel) return false;
+    if (ctx->has_reflection && f->max_depth > 0) return false;
+    if (f->flags & CTGPU_F_SUBSAMPLE) return false;
+    return ctx->n_shadow_lights <= 32;
+}
+
+int launch_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, FrameParams &P, hipStream_t stream) {
+    const bool ss = (f->flags & CTGPU_F_SUPERSAMPLE) != 0;
+    if (!pipeline_eligible(ctx, f)) {
+        launch_trace_tiles(P, tile_count(P), ss, ctx->has_reflection && f->max_depth > 0, false, stream);
+        HIP_TRY(hipGetLastError());
+        return CTGPU_OK;
+    }
+    PipelineParams W;
+    std::memset(&W, 0, sizeof W);
+    W.n_samples = pipeline_sample_count(P, ss);
+    W.n_shadow_lights = ctx->n_shadow_lights;
+    W.lds_depth = std::min<uint32_t>((uint32_t)ctx->lds_depth, std::max<uint32_t>(ctx->tree_depth, 1));
+    W.spill_depth = std::max<uint32_t>(ctx->tree_depth, 1) - W.lds_depth;
+    const size_t lds_bytes = (size_t)W.lds_depth * 64 * 12;
+    int per_cu = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : pipeline_walk_occupancy(lds_bytes);
+    if (per_cu < 1) per_cu = 1;
+    const uint64_t waves_needed = (W.n_samples + 63) / 64;
+    W.walk_blocks = (uint32_t)std::min<uint64_t>((uint64_t)per_cu * ctx->cu_count, std::max<uint64_t>(waves_needed, 1));
+    // chunk: small enough that every wave gets many (dynamic balance), large enough that the
+    // queue's head word sees few atomics
+    // (measured on MI355X, dragon stand-in: 128 for 18M-sample frames, 64 for 1M-sample frames)
+    uint64_t chunk = ctx->chunk > 0 ? (uint64_t)ctx->chunk : (W.n_samples >= (4u << 20) ? 128u : 64u);
+    chunk = std::min<uint64_t>(std::max<uint64_t>((chunk + 63) / 64 * 64, 64), 4096);
+    W.chunk = (uint32_t)chunk;
+    W.thresh_r = ctx->walk_thresh[0]; W.thresh_a = ctx->walk_thresh[1]; W.thresh_b = ctx->walk_thresh[2];
+
+    if (ss) HIP_TRY(ctx->coords.resize(W.n_samples));
+    HIP_TRY(ctx->hits.resize(W.n_samples));
+    HIP_TRY(ctx->shadow.resize(W.n_samples * std::max<uint32_t>(W.n_shadow_lights, 1)));
+    if (W.n_samples >= 0xfffffff0ull) return fail(CTGPU_ERR_ARG, "frame too large: %llu samples", (unsigned long long)W.n_samples);
+    HIP_TRY(ctx->spill.resize((size_t)W.walk_blocks * std::max<uint32_t>(W.spill_depth, 1) * 64 * 12 / 8 + 64));
+    W.coords = ctx->coords.ptr; W.hits = ctx->hits.ptr; W.shadow = ctx->shadow.ptr;
+    W.queue = ctx->queue.ptr; W.spill = ctx->spill.ptr; W.shadow_lights = ctx->shadow_lights.ptr;
+    HIP_TRY(hipMemsetAsync(ctx->queue.ptr, 0, 40 * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(ctx->shadow.ptr, 0, W.n_samples * std::max<uint32_t>(W.n_shadow_lights, 1), stream));
+    launch_pipeline(P, W, ss, stream);
+    HIP_TRY(hipGetLastError());
     return CTGPU_OK;
 }
 
@@ -423,10 +518,7 @@ extern "C" int ctgpu_render_partition(ctgpu_ctx *ctx, const ctgpu_frame_desc *fr
     FrameParams P;
     rc = fill_params(ctx, frame, part, false, P); if (rc) return rc;
     P.out = (uint32_t *)d_tiles;
-    const bool ss = (frame->flags & CTGPU_F_SUPERSAMPLE) != 0;
-    launch_trace_tiles(P, tile_count(P), ss, ctx->has_reflection && frame->max_depth > 0, false, (hipStream_t)stream);
-    HIP_TRY(hipGetLastError());
-    return CTGPU_OK;
+    return launch_frame(ctx, frame, P, (hipStream_t)stream);
 }
 
 extern "C" int ctgpu_assemble(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, const ctgpu_partition *part,
@@ -469,10 +561,8 @@ extern "C" int ctgpu_render(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, uint3
     HIP_TRY(ctx->fb.resize((size_t)frame->width * frame->height));
     P.out = ctx->tiles.ptr;
 
-    const bool ss = (frame->flags & CTGPU_F_SUPERSAMPLE) != 0;
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
-    launch_trace_tiles(P, tile_count(P), ss, ctx->has_reflection && frame->max_depth > 0, false, ctx->stream);
-    HIP_TRY(hipGetLastError());
+    rc = launch_frame(ctx, frame, P, ctx->stream); if (rc) return rc;
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
     launch_assemble(P, ctx->tiles.ptr, ctx->fb.ptr, ctx->stream);
     HIP_TRY(hipGetLastError());
@@ -514,7 +604,7 @@ extern "C" int ctgpu_count_work(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, c
     rc = fill_params(ctx, frame, &whole, true, P); if (rc) return rc;
     HIP_TRY(ctx->tiles.resize((size_t)P.local_rows * P.square));
     P.out = ctx->tiles.ptr;
-    HIP_TRY(hipMemsetAsync(ctx->counters.ptr, 0, 8 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->counters.ptr, 0, 16 * sizeof(unsigned long long), ctx->stream));
     const bool ss = (frame->flags & CTGPU_F_SUPERSAMPLE) != 0;
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
     launch_trace_tiles(P, tile_count(P), ss, ctx->has_reflection && frame->max_depth > 0, true, ctx->stream);
