@@ -17,6 +17,11 @@
 
 using namespace ctd;
 
+// sizes the bindings (cobbletrace_amd/bindings.py) rely on
+static_assert(sizeof(ctgpu_node) == 64 && sizeof(ctgpu_light) == 56 && sizeof(ctgpu_material) == 12, "scene records");
+static_assert(sizeof(ctgpu_scene_desc) == 56 && sizeof(ctgpu_frame_desc) == 136 && sizeof(ctgpu_stats) == 64, "descriptors");
+static_assert(sizeof(ctgpu_ray) == 56 && sizeof(ctgpu_hit) == 16 && sizeof(ctgpu_partition) == 12, "test-hook records");
+
 // ------------------------------------------------------------------ error plumbing
 static thread_local std::string g_last_error;
 

@@ -1,0 +1,74 @@
+"""RayThread(env, scene) -- the drop-in boundary (raythread.h:5) -- on the GPU: first call
+renders, an idle call keeps the image, key events move the camera like HandleKeyboard
+(raythread.cpp:388-434), and the pixels equal the oracle's for the same camera."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import cobbletrace_amd as ca
+from conftest import channel_diff
+
+pytestmark = pytest.mark.gpu
+
+
+def _frames(scene, w, h, keys=b""):
+    fb = np.zeros((h, w), dtype=np.uint32)
+    calls = scene.lib.cth_raythread_frames(scene.handle, w, h, fb.ctypes.data, keys)
+    return fb, calls
+
+
+def test_raythread_renders_and_tracks_the_camera(assets):
+    from oracle import oracle
+    host = ca.host_library()
+    host.cth_raythread_reset()
+    host.cth_raythread_options(ca.RNG_HASH, 11, 0)
+    scene = ca.HostScene(os.path.join(assets, "scene_import.json"))
+    scene.set_settings(threads=8, supersampling=0)
+    w, h = 320, 240
+
+    fb, calls = _frames(scene, w, h)
+    assert calls == 1
+    frame = scene.frame(w, h, threads=8, supersampling=False)
+    want, _ = oracle.render(scene.desc, frame, os_threads=4)
+    assert channel_diff(fb, want).max() <= 1 and ((fb == 0) == (want == 0)).all()
+    rot = (C.c_double * 9)()
+    scene.lib.cth_get_rotation(scene.handle, rot)
+    assert list(rot) == [1, 0, 0, 0, 1, 0, -0.0, 0, 1] and np.signbit(rot[6])     # RayThread wrote camera.rotation
+
+    # nothing changed -> the previous image is kept: the caller's buffer is not touched
+    sentinel = np.full((h, w), 0xdeadbeef, dtype=np.uint32)
+    env_calls = scene.lib.cth_raythread_frames(scene.handle, w, h, sentinel.ctypes.data, b"")
+    assert env_calls == 1 and (sentinel == 0xdeadbeef).all()
+
+    # 'w' twice, 'd' once, then yaw: position += 0.1 in double, angles += pi/16 in float
+    fb2, calls = _frames(scene, w, h, b"wwdy")
+    assert calls == 5
+    cam = scene.camera
+    base = frame.cam_pos
+    assert cam[1] == (base[1] + 0.1) + 0.1 and cam[0] == base[0] + 0.1
+    rot2 = oracle.camera_rotation(np.float32(np.float32(0) + np.pi / 16), np.float32(0), np.float32(0))
+    moved = scene.frame(w, h, threads=8, supersampling=False, rotation=rot2)
+    want2, _ = oracle.render(scene.desc, moved, os_threads=4)
+    assert channel_diff(fb2, want2).max() <= 1
+    assert (fb2 != fb).any()
+
+    # 'c' resets the camera to the origin with no rotation (raythread.cpp:420-423)
+    fb3, _ = _frames(scene, w, h, b"c")
+    assert scene.camera == (0.0, 0.0, 0.0)
+    host.cth_raythread_reset()
+
+
+def test_raythread_supersampled_scene_defaults(assets):
+    from oracle import oracle
+    host = ca.host_library()
+    host.cth_raythread_reset()
+    host.cth_raythread_options(ca.RNG_HASH, 0, 0)
+    scene = ca.HostScene(os.path.join(assets, "scene_import_bunny.json"))       # T=32, supersampling on
+    w, h = 480, 256
+    fb, _ = _frames(scene, w, h)
+    frame = scene.frame(w, h, rng_mode=ca.RNG_HASH, rng_seed=0)
+    want, _ = oracle.render(scene.desc, frame, os_threads=8)
+    assert channel_diff(fb, want).max() <= 1
+    host.cth_raythread_reset()

@@ -1,0 +1,201 @@
+"""Host input layer (cobbletrace_amd/host): number parsing arithmetic, OBJ / PLY import,
+placement transform, settings defaults and error behaviour of the reference's input API
+(fileBuffer.cpp:160-234, objectLoader.cpp:27-279, scenefile.cpp:11-299)."""
+import json
+import os
+import subprocess
+import sys
+import textwrap
+
+import numpy as np
+import pytest
+
+import cobbletrace_amd as ca
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def write_scene(tmp_path, objects, settings=None, camera=(0, 0, -3)):
+    scene = {"objects": objects,
+             "lights": [{"type": "ambient", "intensity": 0.2}, {"type": "point", "intensity": 0.6, "position": [2, 1, 0]}],
+             "camera": {"position": list(camera)}}
+    if settings is not None:
+        scene["settings"] = settings
+    path = tmp_path / "scene.json"
+    path.write_text(json.dumps(scene, indent=2))
+    return str(path)
+
+
+def tri(p1, p2, p3, color=(255, 0, 0), specular=100, reflection=0):
+    return {"type": "triangle", "p1": list(p1), "p2": list(p2), "p3": list(p3), "color": list(color),
+            "specular": specular, "reflection": reflection}
+
+
+def reference_number(text):
+    """fileBuffer.cpp:160-207 in numpy float32 arithmetic (independent restatement for the test)."""
+    f32 = np.float32
+    i, sign = 0, f32(1)
+    if text[0] == "-":
+        sign, i = f32(-1), 1
+    acc, place, frac, sci, exp, esign = f32(0), f32(10), False, False, 0, 1
+    while i < len(text):
+        c = text[i]
+        if c.isdigit():
+            d = int(c)
+            if sci:
+                exp = exp * 10 + d
+            elif frac:
+                acc = f32(acc + f32(f32(d) / place))
+                place = f32(place * f32(10))
+            else:
+                acc = f32(f32(acc * f32(10)) + f32(d))
+        elif c == ".":
+            frac = True
+        elif c == "e":
+            sci = True
+        elif c == "-" and sci:
+            esign = -1
+        else:
+            break
+        i += 1
+    return float(f32(np.float64(sign * acc) * np.float64(10.0) ** (esign * exp)))
+
+
+@pytest.mark.parametrize("text", ["0.2", "0.6", "1.4", "-5.2", "0.7071", "17.0", "0.392", "3.14", "-0.0378297",
+                                  "0.00447467", "8.84e-05", "1.5e3", "-2.5e-3", "123456789", "0.1", "1000000.5",
+                                  "0.3333333333333", "255", "16777217"])
+def test_number_parser_is_binary32_accumulation(text, tmp_path):
+    path = write_scene(tmp_path, [tri((0, 0, 0), (1, 0, 0), (0, 1, 0))], camera=(text, 0, 0))
+    # json.dumps quotes strings: write the literal by hand
+    raw = open(path).read().replace('"%s"' % text, text)
+    open(path, "w").write(raw)
+    scene = ca.HostScene(path)
+    assert scene.camera[0] == reference_number(text)
+    if text == "0.2":
+        assert scene.camera[0] != 0.2 and abs(scene.camera[0] - 0.200000003) < 1e-9     # not the correctly rounded double
+
+
+def test_defaults_and_settings(tmp_path):
+    scene = ca.HostScene(write_scene(tmp_path, [tri((0, 0, 0), (1, 0, 0), (0, 1, 0))]))
+    assert scene.settings == dict(numberOfThreads=8, subsampling=True, wireframe=False, supersampling=False)   # scenefile.cpp:23-26
+    s2 = ca.HostScene(write_scene(tmp_path, [tri((0, 0, 0), (1, 0, 0), (0, 1, 0))],
+                                  settings={"numberOfThreads": 32, "subsampling": False, "wireframe": False,
+                                            "supersampling": True}))
+    assert s2.settings == dict(numberOfThreads=32, subsampling=False, wireframe=False, supersampling=True)
+
+
+def test_inline_triangles_spheres_and_material_packing(tmp_path):
+    objs = [{"type": "sphere", "center": [0, 0, 6], "radius": 1.0, "color": [100, 200, 0], "specular": 100, "reflection": 0.5},
+            tri((0, 0, 2), (0, 1, 2), (0.7071, 1, 2.7071), color=(1, 2, 3), specular=-1, reflection=0.25),
+            tri((1, 0, 2), (1, 1, 2), (2, 1, 2), color=(255, 155, 255), specular=500, reflection=0)]
+    scene = ca.HostScene(write_scene(tmp_path, objs))
+    d = scene.desc
+    assert d.n_triangles == 2 and scene.lib.cth_object_count(scene.handle) == 3      # spheres stay on the stack, untraced
+    assert d.materials[0].color == (3 << 16) | (2 << 8) | 1 and d.materials[0].specular == -1
+    assert d.materials[0].reflection == np.float32(0.25)
+    assert d.materials[1].color == 0x00ff9bff and d.materials[1].specular == 500
+    assert scene.vertices()[0, 6] == reference_number("0.7071")
+
+
+OBJ = """# a comment
+o Quad
+v -1.0 -1.0 0.5
+v 1.0 -1.0 0.5
+v 1.0 1.0 0.5
+v -1.0 1.0 0.5
+s off
+f 1 2 3
+f 1 3 4
+"""
+
+PLY = """ply
+format ascii 1.0
+comment made by hand
+element vertex 4
+property float32 x
+property float32 y
+property float32 z
+property float32 confidence
+element face 2
+property list uint8 int32 vertex_indices
+end_header
+-1 -1 0.5 0.9
+1 -1 0.5 0.8
+1 1 0.5 0.7
+-1 1 0.5 0.6
+3 0 1 2
+3 0 2 3
+"""
+
+
+def placement(p, pos, rot, scale):
+    """objectLoader.cpp:27-140 in float64: RotY, RotX, RotZ, scale, translate (row vector x matrix)."""
+    import math
+    x, y, z = p
+    cy, sy = math.cos(rot[1]), math.sin(rot[1])
+    x, y, z = x * cy + y * 0.0 + z * -sy + 1.0 * 0.0, x * 0.0 + y * 1.0 + z * 0.0 + 0.0, x * sy + y * 0.0 + z * cy + 0.0
+    cx, sx = math.cos(rot[0]), math.sin(rot[0])
+    x, y, z = x * 1.0 + y * 0.0 + z * 0.0 + 0.0, x * 0.0 + y * cx + z * sx + 0.0, x * 0.0 + y * -sx + z * cx + 0.0
+    cz, sz = math.cos(rot[2]), math.sin(rot[2])
+    x, y, z = x * cz + y * sz + z * 0.0 + 0.0, x * -sz + y * cz + z * 0.0 + 0.0, x * 0.0 + y * 0.0 + z * 1.0 + 0.0
+    x, y, z = x * scale[0] + 0.0, y * scale[1] + 0.0, z * scale[2] + 0.0
+    return [x + pos[0], y + pos[1], z + pos[2]]
+
+
+@pytest.mark.parametrize("fmt", ["blender", "ply", None])
+def test_mesh_import_and_placement(fmt, tmp_path):
+    (tmp_path / "models").mkdir()
+    name = "models/quad.ply" if fmt == "ply" else "models/quad.obj"
+    (tmp_path / name).write_text(PLY if fmt == "ply" else OBJ)
+    pos, rot, scale = [0.5, 2.5, -1.0], [0.392, 3.14, 0.3927], [2.0, 0.75, 1.5]
+    obj = {"type": "import", "filename": name, "position": pos, "rotation": rot, "scale": scale,
+           "color": [255, 230, 102], "specular": 100, "reflection": 0}
+    if fmt is not None:
+        obj["format"] = fmt                     # omitted = OBJ, like scene_import.json relies on
+    scene = ca.HostScene(write_scene(tmp_path, [obj]))
+    assert scene.desc.n_triangles == 2
+    f32 = lambda v: [reference_number(json.dumps(c)) for c in v]      # as the scene parser reads them
+    corners = [(-1, -1, 0.5), (1, -1, 0.5), (1, 1, 0.5), (-1, 1, 0.5)]
+    want = []
+    for face in ((0, 1, 2), (0, 2, 3)):
+        row = []
+        for k in face:
+            row += placement(corners[k], f32(pos), f32(rot), f32(scale))
+        want.append(row)
+    got = scene.vertices()
+    assert got.tolist() == want                                     # bit-exact placement arithmetic
+    assert scene.desc.materials[1].color == (102 << 16) | (230 << 8) | 255
+
+
+def test_obj_without_faces_and_mixed_scene(tmp_path):
+    (tmp_path / "models").mkdir()
+    (tmp_path / "models" / "empty.obj").write_text("# nothing\nv 0 0 0\n")
+    objs = [{"type": "import", "filename": "models/empty.obj", "position": [0, 0, 0], "rotation": [0, 0, 0],
+             "scale": [1, 1, 1], "color": [1, 1, 1], "specular": 1, "reflection": 0},
+            tri((0, 0, 1), (1, 0, 1), (0, 1, 1))]
+    scene = ca.HostScene(write_scene(tmp_path, objs))
+    assert scene.desc.n_triangles == 1
+
+
+def _run_child(code):
+    return subprocess.run([sys.executable, "-c", textwrap.dedent(code)], cwd=ROOT, capture_output=True, text=True)
+
+
+def test_malformed_input_aborts_like_the_reference_asserts(tmp_path):
+    """The reference asserts on malformed input; an assert failure is an abort, and so is ours."""
+    bad = tmp_path / "bad.json"
+    bad.write_text('{"objects":[{"type": "cylinder"}]}')
+    proc = _run_child("import cobbletrace_amd as ca; ca.HostScene(%r)" % str(bad))
+    assert proc.returncode < 0 and "unknown object type" in proc.stderr          # killed by SIGABRT
+    bad.write_text('{"settings":{"numberOfThreads": 4, "turbo": true}}')
+    proc = _run_child("import cobbletrace_amd as ca; ca.HostScene(%r)" % str(bad))
+    assert proc.returncode < 0 and "unknown settings key" in proc.stderr
+    with pytest.raises(FileNotFoundError):
+        ca.HostScene(str(tmp_path / "missing.json"))
+
+
+def test_shipped_scenes_load(scenes):
+    for name, tris in (("cube", 37), ("import", 1712), ("bunny", 69451)):
+        s = scenes(name)
+        assert s.desc.n_triangles == tris and s.desc.n_lights == 3
+        assert s.settings["supersampling"] is True and s.settings["subsampling"] is False

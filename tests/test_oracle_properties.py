@@ -1,0 +1,131 @@
+"""Oracle self-consistency: thread-count independence, band sampling, jitter sources, the
+subsampling rule, frozen regression hashes, and the building blocks against hand-computed cases."""
+import ctypes as C
+import json
+import os
+
+import numpy as np
+import pytest
+
+import cobbletrace_amd as ca
+from oracle import oracle
+
+GOLDEN = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "oracle_regression.json")))
+
+
+@pytest.mark.parametrize("case", GOLDEN, ids=lambda c: "%s-%dx%d-T%d-ss%d-sub%d-rng%d" % (
+    c["scene"], c["width"], c["height"], c["threads"], c["supersampling"], c["subsampling"], c["rng_mode"]))
+def test_regression_hashes(case, scenes):
+    scene = scenes(case["scene"])
+    frame = scene.frame(case["width"], case["height"], threads=case["threads"], supersampling=case["supersampling"],
+                        subsampling=case["subsampling"], rng_mode=case["rng_mode"], rng_seed=case["rng_seed"])
+    fb, st = oracle.render(scene.desc, frame, os_threads=3)
+    assert "%016x" % oracle.fnv1a64(fb) == case["fnv1a64"]
+    assert st.rays == case["rays"]
+
+
+def test_image_does_not_depend_on_os_threads(scenes):
+    scene = scenes("import")
+    frame = scene.frame(320, 200, threads=8, supersampling=True, rng_seed=1)
+    a, _ = oracle.render(scene.desc, frame, os_threads=1)
+    b, _ = oracle.render(scene.desc, frame, os_threads=0)        # one thread per band, like the reference
+    c, _ = oracle.render(scene.desc, frame, os_threads=5)
+    assert (a == b).all() and (a == c).all()
+
+
+def test_hash_jitter_does_not_depend_on_band_count_but_libc_order_does(scenes):
+    scene = scenes("cube")
+    f8 = scene.frame(128, 128, threads=8, supersampling=True, rng_mode=ca.RNG_HASH, rng_seed=2)
+    f4 = scene.frame(128, 128, threads=4, supersampling=True, rng_mode=ca.RNG_HASH, rng_seed=2)
+    a, _ = oracle.render(scene.desc, f8, os_threads=4)
+    b, _ = oracle.render(scene.desc, f4, os_threads=4)
+    assert (a == b).all()                                         # T divides H in both: same rows, same jitter
+
+
+def test_libc_mode_is_the_single_worker_rand_sequence(scenes):
+    """At T=1 the table-driven LIBC mode must equal calling rand() in loop order; checked by
+    re-deriving two pixels' jitter from libc directly."""
+    libc = C.CDLL(None)
+    libc.rand.restype = C.c_int
+    libc.srand(1)
+    stream = [libc.rand() for _ in range(4 * 4 * 32 + 64)]
+    # ctgpu_rand_stream (product, own TYPE_3 implementation) equals libc
+    g = ca.gpu_library()
+    out = (C.c_int32 * len(stream))()
+    assert g.ctgpu_rand_stream(1, 0, len(stream), out) == 0
+    assert list(out) == stream
+    out2 = (C.c_int32 * 10)()
+    assert g.ctgpu_rand_stream(1, 100, 10, out2) == 0 and list(out2) == stream[100:110]
+    libc.srand(12345)
+    other = [libc.rand() for _ in range(50)]
+    out3 = (C.c_int32 * 50)()
+    assert g.ctgpu_rand_stream(12345, 0, 50, out3) == 0 and list(out3) == other
+
+
+def test_band_sampling_matches_full_frame(scenes):
+    scene = scenes("bunny")
+    frame = scene.frame(320, 256, threads=16, supersampling=False)
+    full, sf = oracle.render(scene.desc, frame, os_threads=8)
+    part, sp = oracle.render(scene.desc, frame, os_threads=4, band_first=2, band_count=4, band_stride=3)
+    rows = part.any(axis=1)
+    assert rows.sum() == 4 * 16 and (part[rows] == full[rows]).all()
+    assert sp.rays < sf.rays
+
+
+def test_subsampling_rule(scenes):
+    """Traced rows: even offsets of a band plus its last row; rows between are channel averages;
+    with an even band height the second-to-last row ends up averaged with the last (raythread.cpp:512-535)."""
+    scene = scenes("import")
+    full = scene.frame(200, 120, threads=4, supersampling=False, subsampling=False)
+    sub = scene.frame(200, 120, threads=4, supersampling=False, subsampling=True)
+    a, sa = oracle.render(scene.desc, full, os_threads=4)
+    b, sb = oracle.render(scene.desc, sub, os_threads=4)
+    q = 120 // 4
+    lib = oracle.library()
+    for yi in range(2, 120):                      # yi = y + H/2; raster row = H - yi (yi = 1 averages with the dropped row)
+        off, row = yi % q, 120 - yi
+        if (off % 2 == 1 and off != q - 1):
+            lo, hi = a[120 - (yi - 1)], a[120 - (yi + 1)]
+            want = np.array([lib.cto_average_pair(int(x), int(y)) for x, y in zip(lo[40:160], hi[40:160])])
+            assert (b[row, 40:160] == want).all()
+        elif q % 2 == 0 and off == q - 2:
+            lo, hi = a[row], a[120 - (yi + 1)]
+            want = np.array([lib.cto_average_pair(int(x), int(y)) for x, y in zip(lo[40:160], hi[40:160])])
+            assert (b[row, 40:160] == want).all()
+        else:
+            assert (b[row] == a[row]).all()
+    assert sb.rays_primary < sa.rays_primary
+
+
+def test_slab_and_triangle_building_blocks():
+    lib = oracle.library()
+    d3 = lambda *v: (C.c_double * 3)(*v)
+    # box straight ahead
+    assert lib.cto_intersect_aabb(d3(0, 0, -5), d3(0, 0, 1), 1e30, d3(-1, -1, -1), d3(1, 1, 1)) == 1
+    # zero direction components: inf / NaN slabs flow through the min/max macros
+    assert lib.cto_intersect_aabb(d3(0.5, 0.5, -5), d3(0, 0, 1), 1e30, d3(-1, -1, -1), d3(1, 1, 1)) == 1
+    assert lib.cto_intersect_aabb(d3(2.0, 0.5, -5), d3(0, 0, 1), 1e30, d3(-1, -1, -1), d3(1, 1, 1)) == 0
+    # origin exactly on a face plane with zero direction: 0/0 = NaN in that slab
+    assert lib.cto_intersect_aabb(d3(1.0, 0, -5), d3(0, 0, 1), 1e30, d3(-1, -1, -1), d3(1, 1, 1)) in (0, 1)
+    # behind the origin, and beyond ray.t
+    assert lib.cto_intersect_aabb(d3(0, 0, 5), d3(0, 0, 1), 1e30, d3(-1, -1, -1), d3(1, 1, 1)) == 0
+    assert lib.cto_intersect_aabb(d3(0, 0, -5), d3(0, 0, 1), 3.0, d3(-1, -1, -1), d3(1, 1, 1)) == 0
+    tri = (C.c_double * 9)(-1, -1, 0, 1, -1, 0, 0, 1, 0)
+    t = C.c_float(1e30)
+    assert lib.cto_intersect_triangle(d3(0, 0, -2), d3(0, 0, 1), C.byref(t), tri) == 1 and t.value == 2.0
+    t = C.c_float(1e30)     # behind: returns true (!) but leaves ray.t alone (bvh.cpp:161-162)
+    assert lib.cto_intersect_triangle(d3(0, 0, 2), d3(0, 0, 1), C.byref(t), tri) == 1 and t.value == np.float32(1e30)
+    t = C.c_float(1e30)     # parallel
+    assert lib.cto_intersect_triangle(d3(0, 0, -2), d3(1, 0, 0), C.byref(t), tri) == 0
+    t = C.c_float(1e30)     # outside the edges
+    assert lib.cto_intersect_triangle(d3(3, 0, -2), d3(0, 0, 1), C.byref(t), tri) == 0
+
+
+def test_frame_geometry_quirks(scenes):
+    scene = scenes("cube")
+    f = scene.frame(100, 64, threads=5, supersampling=False)     # 64/5 = 12 -> 60 rows, 4 rows never rendered
+    fb, st = oracle.render(scene.desc, f, os_threads=2)
+    assert (fb[0] == 0).all()                                    # row 0 is never addressed
+    assert (fb[1:4] == 0).all() and (fb[5] != 0).any()           # rows beyond T*(H/T) stay untouched
+    assert (fb[:, :18] == 0).all() and (fb[:, 82:] == 0).all()   # only the centred H x H square
+    assert st.rays_primary == 64 * 60
