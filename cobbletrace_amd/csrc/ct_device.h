@@ -138,18 +138,18 @@ __device__ __forceinline__ bool slab_fast(const d3 &o, const d3 &inv, const doub
     return redo;
 }
 
-// approximate entry / exit parameters, each within one float step of the reference's
+// approximate entry / exit parameters, each within one float step of the reference's.
+// PRECONDITION: every direction component is finite and NON-ZERO (so is inv), hence no
+// quotient is NaN and the hardware min / max (one instruction each) return the same VALUE as
+// the reference's `a<b?a:b` macros; they may pick the other sign of a zero, which no
+// comparison downstream can see and which the verdict margins below allow for.
 __device__ __forceinline__ void slab_approx(const d3 &o, const d3 &inv, const double *bmin, const double *bmax,
                                             float &tmin, float &tmax) {
     const float tx1 = (float)((bmin[0] - o.x) * inv.x), tx2 = (float)((bmax[0] - o.x) * inv.x);
     const float ty1 = (float)((bmin[1] - o.y) * inv.y), ty2 = (float)((bmax[1] - o.y) * inv.y);
     const float tz1 = (float)((bmin[2] - o.z) * inv.z), tz2 = (float)((bmax[2] - o.z) * inv.z);
-    tmin = lesser(tx1, tx2);
-    tmax = greater(tx1, tx2);
-    tmin = greater(tmin, lesser(ty1, ty2));
-    tmax = lesser(tmax, greater(ty1, ty2));
-    tmin = greater(tmin, lesser(tz1, tz2));
-    tmax = lesser(tmax, greater(tz1, tz2));
+    tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx1, tx2), __builtin_fminf(ty1, ty2)), __builtin_fminf(tz1, tz2));
+    tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx1, tx2), __builtin_fmaxf(ty1, ty2)), __builtin_fmaxf(tz1, tz2));
 }
 
 // position of a float in the ordered set of floats (-0 and +0 are neighbours; NaNs lie
@@ -165,22 +165,24 @@ __device__ __forceinline__ bool ordinals_near(int32_t a, int32_t b, uint32_t ste
 
 // The three decisions of the box test from approximate tmin / tmax (each <= 1 step off):
 // returns true when all three are certain, with the reference's verdict in `pass`.
-//   tmax >= tmin : both sides may move one step           -> needs |tmax - tmin| > 2 steps
-//   tmin <  t    : t is exact                              -> needs |tmin - t|    > 1 step
-//   tmax >  0    : 0 is exact (either sign of zero)        -> needs tmax more than 2 steps from +-0
+// (one more step of margin than the rounding argument needs, for the -0 / +0 ordinal pair)
+//   tmax >= tmin : both sides may move one step           -> needs |tmax - tmin| > 3 steps
+//   tmin <  t    : t is exact                              -> needs |tmin - t|    > 2 steps
+//   tmax >  0    : 0 is exact (either sign of zero)        -> needs tmax more than 3 steps from +-0
 __device__ __forceinline__ bool box_verdict(float tmin, float tmax, float ray_t, int32_t ray_t_ordinal, bool &pass) {
     const int32_t kmin = float_ordinal(tmin), kmax = float_ordinal(tmax);
-    const bool uncertain = ordinals_near(kmax, kmin, 2u) | ordinals_near(kmin, ray_t_ordinal, 1u) |
+    const bool uncertain = ordinals_near(kmax, kmin, 3u) | ordinals_near(kmin, ray_t_ordinal, 2u) |
                            ordinals_near(kmax, 0, 3u);
     pass = tmax >= tmin && tmin < ray_t && tmax > 0;
     return !uncertain;
 }
 
-// true when every non-zero component of d is comfortably inside the binary64 normal range
+// true when every component of d is non-zero and comfortably inside the binary64 normal range
+// (a zero component makes inf / NaN slabs: those rays take the reference's divisions)
 __device__ __forceinline__ bool direction_allows_fast_slab(const d3 &d) {
     auto ok = [](double c) {
         const uint32_t e = ((uint32_t)__double2hiint(c) >> 20) & 0x7FFu;
-        return c == 0.0 || (e > 23u && e < 2023u);     // |c| in [2^-999, 2^1000)
+        return e > 23u && e < 2023u;                    // |c| in [2^-999, 2^1000): finite, normal, non-zero
     };
     return ok(d.x) && ok(d.y) && ok(d.z);
 }

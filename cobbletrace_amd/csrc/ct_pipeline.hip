@@ -195,7 +195,7 @@ __device__ __forceinline__ void pop_next(Walker &w, const WalkStack &st) {
     const int32_t kt = float_ordinal(w.t);
     while (w.sp > 0) {
         const StackEntry e = st.top(w);
-        if (ordinals_near(float_ordinal(e.tmin), kt, 1u)) {
+        if (ordinals_near(float_ordinal(e.tmin), kt, 2u)) {
             w.cur = st.top_parent(w);
             w.leaf_left = kExactPopPending;
             w.sp -= 1;
@@ -353,6 +353,10 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk(const FrameParam
     uint64_t chunk_next = 0, chunk_end = 0;
     bool wave_drained = false;
     uint32_t n_traced = 0;
+#ifdef CT_WALK_STATS
+    unsigned long long stat_cycles[3] = {0, 0, 0}, stat_exec[3] = {0, 0, 0}, stat_lanes[3] = {0, 0, 0};
+    const unsigned long long stat_begin = __builtin_amdgcn_s_memtime();
+#endif
 
     for (;;) {
         const bool walking = has_ray && w.cur != kNoNode;
@@ -363,11 +367,26 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk(const FrameParam
         const unsigned long long m_a = __ballot(want_a), m_b = __ballot(want_b);
         const int n_a = __popcll(m_a), n_b = __popcll(m_b);
         const int n_r = wave_drained ? __popcll(__ballot(finished)) : __popcll(__ballot(!walking));
+#ifdef CT_WALK_STATS
+        const unsigned long long stamp0 = __builtin_amdgcn_s_memtime();
+#define CT_STAMP(slot) do { stat_cycles[slot - 11] += __builtin_amdgcn_s_memtime() - stamp0; } while (0)
+#else
+#define CT_STAMP(slot) do {} while (0)
+#endif
         if (__ballot(want_e) != 0ull) {       // rare (about 1e-7 per node): settle it at once
             if (want_e) step_exact(w, P.nodes, st);
             continue;
         }
         if (n_r == 0 && n_a == 0 && n_b == 0) break;
+#ifdef CT_WALK_STATS
+        {   // divergence statistics (diagnostic build only): executions and lanes served per phase
+            const bool do_r_ = n_r >= W.thresh_r || (n_a == 0 && n_b == 0);
+            const bool do_a_ = !do_r_ && (((n_a >= W.thresh_a) || (n_b < W.thresh_b && n_a >= n_b) || n_b == 0) && n_a > 0);
+            const int which = do_r_ ? 2 : (do_a_ ? 0 : 1);
+            stat_exec[which] += 1;
+            stat_lanes[which] += (unsigned long long)(which == 2 ? n_r : (which == 0 ? n_a : n_b));
+        }
+#endif
 
         // ---------------- (R) retire finished rays, hand out new ones
         if (n_r >= W.thresh_r || (n_a == 0 && n_b == 0)) {
@@ -424,17 +443,30 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk(const FrameParam
                     }
                 }
             }
+            CT_STAMP(13);
             continue;
         }
         // ---------------- (A) / (B): the fuller queue goes first unless the other reached its threshold
         const bool do_a = (n_a >= W.thresh_a) || (n_b < W.thresh_b && n_a >= n_b) || n_b == 0;
         if (do_a && n_a > 0) {
             if (want_a) step_inner(w, P.nodes, st);
+            CT_STAMP(11);
         } else {
             if (want_b) step_leaf<KIND == 1>(w, P.tris, st);
+            CT_STAMP(12);
         }
     }
 
+#ifdef CT_WALK_STATS
+    if (lane == 0) {
+        for (int k = 0; k < 3; k++) {
+            atomicAdd(&P.counters[5 + k * 2], stat_exec[k]);
+            atomicAdd(&P.counters[6 + k * 2], stat_lanes[k]);
+            atomicAdd(&P.counters[11 + k], stat_cycles[k]);
+        }
+        atomicAdd(&P.counters[14], __builtin_amdgcn_s_memtime() - stat_begin);
+    }
+#endif
     // ray counters: one atomic per wave
     for (int off = 32; off > 0; off >>= 1) n_traced += __shfl_down(n_traced, off);
     if (lane == 0) atomicAdd(&P.counters[KIND == 0 ? 0 : 1], (unsigned long long)n_traced);

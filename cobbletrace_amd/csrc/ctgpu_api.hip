@@ -88,7 +88,7 @@ struct ctgpu_ctx {
     uint32_t n_shadow_lights = 0;
     int cu_count = 256;
     int walk_thresh[3] = {64, 40, 24};          // retire/fetch, inner, leaf (measured best on MI355X)
-    int lds_depth = 12;
+    int lds_depth = 8;                          // 6 KB of LDS per wave; deeper entries spill to HBM
     int blocks_per_cu = 0;                      // 0 = occupancy query
     int chunk = 0;                              // 0 = sized from the frame
     bool force_megakernel = false;
@@ -437,8 +437,13 @@ int read_counters(ctgpu_ctx *ctx, ctgpu_stats *st) {
     unsigned long long c[16];
     HIP_TRY(hipMemcpy(c, ctx->counters.ptr, sizeof c, hipMemcpyDeviceToHost));
     if (std::getenv("CTGPU_DEBUG_PHASES") && c[5])
-        std::fprintf(stderr, "phases: A %llu x %.1f lanes, B %llu x %.1f lanes, C %llu x %.1f lanes\n", c[5],
-                     (double)c[6] / c[5], c[7], c[7] ? (double)c[8] / c[7] : 0.0, c[9], c[9] ? (double)c[10] / c[9] : 0.0);
+        std::fprintf(stderr, "phases: A %llu x %.1f lanes (%.0f cyc each), B %llu x %.1f lanes (%.0f cyc), C %llu x %.1f lanes (%.0f cyc)\n", c[5],
+                     (double)c[6] / c[5], (double)c[11] / c[5], c[7], c[7] ? (double)c[8] / c[7] : 0.0, c[7] ? (double)c[12] / c[7] : 0.0,
+                     c[9], c[9] ? (double)c[10] / c[9] : 0.0, c[9] ? (double)c[13] / c[9] : 0.0);
+    if (std::getenv("CTGPU_DEBUG_PHASES") && c[14])
+        std::fprintf(stderr, "wave lifetime cycles total %llu: A %.1f%% B %.1f%% R %.1f%% other %.1f%%\n", c[14],
+                     100.0 * c[11] / c[14], 100.0 * c[12] / c[14], 100.0 * c[13] / c[14],
+                     100.0 * (c[14] - c[11] - c[12] - c[13]) / c[14]);
     HIP_TRY(hipMemset(ctx->counters.ptr, 0, sizeof c));
     if (st) {
         st->rays_primary = c[0]; st->rays_shadow = c[1]; st->rays_reflect = c[2];

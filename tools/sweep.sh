@@ -1,9 +1,6 @@
 #!/bin/bash
-run() { echo "== $*"; env "$@" timeout -k 10 100 python tools/quick_perf.py dragon 2>&1 | grep -E "ss="; }
-run CTGPU_CHUNK=0
-run CTGPU_CHUNK=64 CTGPU_WALK_THRESH=64,40,24
-run CTGPU_CHUNK=128 CTGPU_WALK_THRESH=64,40,24
-run CTGPU_CHUNK=128 CTGPU_WALK_THRESH=32,40,24
-run CTGPU_CHUNK=128 CTGPU_WALK_THRESH=16,40,24
-run CTGPU_CHUNK=128 CTGPU_WALK_THRESH=32,40,24 CTGPU_LDS_DEPTH=8
-run CTGPU_CHUNK=128 CTGPU_WALK_THRESH=32,40,24 CTGPU_LDS_DEPTH=16
+run() { echo "== $*"; env "$@" timeout -k 10 100 python tools/quick_perf.py dragon bunny 2>&1 | grep -E "ss=1"; }
+for d in 4 6 8; do
+run CTGPU_LDS_DEPTH=$d
+for w in 4 6 8; do run CTGPU_LDS_DEPTH=$d CTGPU_LIBRARY=$PWD/variants/libctgpu_w$w.so; done
+done
