@@ -34,6 +34,7 @@ constexpr int kWave = 64;
 #ifndef CT_WALK_WAVES
 #define CT_WALK_WAVES 5      // waves per SIMD the traversal kernel is register-budgeted for
 #endif
+constexpr uint32_t kShards = 8;                     // ray-queue head words (one per XCD)
 constexpr uint32_t kInvalidSample = 0xfffffffeu;   // hits[].slot of a sample that is not part of the frame
 
 struct StackEntry { uint32_t ref; float tmin; };
@@ -175,17 +176,20 @@ struct WalkStack {
     }
 };
 
+// leaf_left doubles as the lane's mode: 0 = cur is an inner node; 1 .. N = triangles left in the
+// current leaf; the values below are markers
+constexpr uint32_t kLeafUnknown = 0xfffffff0u;        // leaf entered, count comes with its first record
+constexpr uint32_t kExactPopPending = 0xfffffffdu;    // cur = parent whose RIGHT child must be re-tested exactly
+constexpr uint32_t kExactPending = 0xfffffffeu;       // redo this inner node with real divisions
+
 __device__ __forceinline__ void enter(Walker &w, uint32_t ref) {
     w.cur = ref;
     w.leaf_left = 0;
     if (ref != kNoNode && (ref & kLeafBit)) {
         w.cur = ref & ~kLeafBit;
-        w.leaf_left = 0xffffffffu;      // taken from the first record
+        w.leaf_left = kLeafUnknown;     // taken from the first record
     }
 }
-
-constexpr uint32_t kExactPending = 0xfffffffeu;      // leaf_left: redo this inner node with real divisions
-constexpr uint32_t kExactPopPending = 0xfffffffdu;   // leaf_left: cur = parent whose RIGHT child must be re-tested
 
 // Pop until an entry survives `tmin < ray.t`, the deferred half of the right child's box test
 // (bvh.cpp:205 when the reference enters node left+1).  The stored tmin is approximate (one
@@ -292,7 +296,7 @@ __device__ __forceinline__ void step_leaf(Walker &w, const TriRecord *__restrict
     const double2 b3 = *reinterpret_cast<const double2 *>(&rec->e2[0]);
     const double2 b4 = *reinterpret_cast<const double2 *>(&rec->e2[2]);
     const d3 p1 = make_d3(b0.x, b0.y, b1.x), e1 = make_d3(b1.y, b2.x, b2.y), e2 = make_d3(b3.x, b3.y, b4.x);
-    if (w.leaf_left == 0xffffffffu) w.leaf_left = (uint32_t)(__double_as_longlong(b4.y) >> 32);
+    if (w.leaf_left == kLeafUnknown) w.leaf_left = (uint32_t)(__double_as_longlong(b4.y) >> 32);
 
     const float before = w.t;
     const bool hit = triangle_test(w.o, w.d, w.t, p1, e1, e2);
@@ -339,7 +343,13 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk(const FrameParam
     const uint32_t lane = threadIdx.x;
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
     const uint64_t n_rays = W.n_samples;
-    unsigned long long *queue = W.queue + (KIND == 0 ? 0u : 1u + W.light_slot);
+    // The ray-id space is cut into kShards contiguous ranges, each with its own head word on its
+    // own 128-byte line (one head saturates near 90 dequeues/us chip-wide); a wave starts on the
+    // shard of its workgroup id (workgroups b and b+8 share an XCD under round-robin placement --
+    // speed only) and moves on to the next shard when one runs dry.
+    unsigned long long *heads = W.queue + (size_t)(KIND == 0 ? 0u : 1u + W.light_slot) * kShards * 16u;
+    const uint64_t shard_span = ((n_rays + kShards - 1) / kShards + W.chunk - 1) / W.chunk * W.chunk;
+    uint32_t shard = blockIdx.x % kShards, shards_done = 0;
     const Light shadow_light = (KIND == 1) ? P.lights[W.shadow_lights[W.light_slot]] : Light{};
     uint8_t *blocked = (KIND == 1) ? W.shadow + (size_t)W.light_slot * W.n_samples : nullptr;
     const d3 eye = make_d3(P.cam[0], P.cam[1], P.cam[2]);
@@ -361,7 +371,7 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk(const FrameParam
     for (;;) {
         const bool walking = has_ray && w.cur != kNoNode;
         const bool finished = has_ray && w.cur == kNoNode;
-        const bool want_e = walking && w.leaf_left >= kExactPopPending && w.leaf_left <= kExactPending;
+        const bool want_e = walking && w.leaf_left >= kExactPopPending;
         const bool want_b = walking && w.leaf_left != 0 && !want_e;
         const bool want_a = walking && w.leaf_left == 0;
         const unsigned long long m_a = __ballot(want_a), m_b = __ballot(want_b);
@@ -399,12 +409,23 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk(const FrameParam
                 const unsigned long long m_i = __ballot(!has_ray);
                 if (m_i == 0ull || wave_drained) break;
                 if (chunk_next >= chunk_end) {
-                    unsigned long long base = 0;
-                    if (lane == 0) base = atomicAdd(queue, (unsigned long long)W.chunk);
-                    base = __shfl(base, 0);
-                    if (base >= n_rays) { wave_drained = true; break; }
+                    // (reserving one chunk ahead to hide the atomic's round trip was tried: the chunk a
+                    // busy wave sits on at the end of the launch costs more than the latency it hides)
+                    unsigned long long offset = 0;
+                    if (lane == 0) offset = atomicAdd(heads + shard * 16u, (unsigned long long)W.chunk);
+                    offset = __shfl(offset, 0);
+                    const uint64_t base = (uint64_t)shard * shard_span + offset;
+                    if (offset >= shard_span || base >= n_rays) {     // this shard is dry: try the next one
+                        shards_done += 1;
+                        shard = (shard + 1u) % kShards;
+                        if (shards_done >= kShards) { wave_drained = true; break; }
+                        continue;
+                    }
                     chunk_next = base;
-                    chunk_end = (base + W.chunk < n_rays) ? base + W.chunk : n_rays;
+                    const uint64_t shard_end = ((uint64_t)shard + 1u) * shard_span;
+                    chunk_end = base + W.chunk;
+                    if (chunk_end > shard_end) chunk_end = shard_end;
+                    if (chunk_end > n_rays) chunk_end = n_rays;
                 }
                 const uint64_t avail = chunk_end - chunk_next;
                 const uint32_t rank = (uint32_t)__popcll(m_i & lanes_below);
@@ -449,10 +470,23 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk(const FrameParam
         // ---------------- (A) / (B): the fuller queue goes first unless the other reached its threshold
         const bool do_a = (n_a >= W.thresh_a) || (n_b < W.thresh_b && n_a >= n_b) || n_b == 0;
         if (do_a && n_a > 0) {
-            if (want_a) step_inner(w, P.nodes, st);
+            // tight loop: keep opening nodes while enough lanes want to, re-evaluating only that
+            bool more = want_a;
+            int n_more;
+            do {
+                if (more) step_inner(w, P.nodes, st);
+                more = has_ray && w.cur != kNoNode && w.leaf_left == 0;
+                n_more = __popcll(__ballot(more));
+            } while (n_more >= W.thresh_a);
             CT_STAMP(11);
         } else {
-            if (want_b) step_leaf<KIND == 1>(w, P.tris, st);
+            bool more = want_b;
+            int n_more;
+            do {
+                if (more) step_leaf<KIND == 1>(w, P.tris, st);
+                more = has_ray && w.cur != kNoNode && w.leaf_left != 0 && w.leaf_left < kExactPopPending;
+                n_more = __popcll(__ballot(more));
+            } while (n_more >= W.thresh_b);
             CT_STAMP(12);
         }
     }

@@ -87,7 +87,7 @@ struct ctgpu_ctx {
     DeviceArray<uint32_t> shadow_lights;
     uint32_t n_shadow_lights = 0;
     int cu_count = 256;
-    int walk_thresh[3] = {64, 40, 24};          // retire/fetch, inner, leaf (measured best on MI355X)
+    int walk_thresh[3] = {64, 32, 24};          // retire/fetch, inner, leaf (measured best on MI355X)
     int lds_depth = 8;                          // 6 KB of LDS per wave; deeper entries spill to HBM
     int blocks_per_cu = 0;                      // 0 = occupancy query
     int chunk = 0;                              // 0 = sized from the frame
@@ -176,7 +176,7 @@ extern "C" int ctgpu_create(int device, ctgpu_ctx **out) {
     if (const char *t = std::getenv("CTGPU_FORCE_MEGAKERNEL")) ctx->force_megakernel = std::atoi(t) != 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->cu_count = prop.multiProcessorCount;
-    HIP_TRY(ctx->queue.resize(40));
+    HIP_TRY(ctx->queue.resize(33 * 8 * 16));
     *out = ctx;
     return CTGPU_OK;
 }
@@ -499,7 +499,7 @@ int launch_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, FrameParams &P, hipS
     HIP_TRY(ctx->spill.resize((size_t)W.walk_blocks * std::max<uint32_t>(W.spill_depth, 1) * 64 * 12 / 8 + 64));
     W.coords = ctx->coords.ptr; W.hits = ctx->hits.ptr; W.shadow = ctx->shadow.ptr;
     W.queue = ctx->queue.ptr; W.spill = ctx->spill.ptr; W.shadow_lights = ctx->shadow_lights.ptr;
-    HIP_TRY(hipMemsetAsync(ctx->queue.ptr, 0, 40 * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(ctx->queue.ptr, 0, 33 * 8 * 16 * sizeof(unsigned long long), stream));
     HIP_TRY(hipMemsetAsync(ctx->shadow.ptr, 0, W.n_samples * std::max<uint32_t>(W.n_shadow_lights, 1), stream));
     launch_pipeline(P, W, ss, stream);
     HIP_TRY(hipGetLastError());

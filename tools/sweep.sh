@@ -1,6 +1,8 @@
 #!/bin/bash
-run() { echo "== $*"; env "$@" timeout -k 10 100 python tools/quick_perf.py dragon bunny 2>&1 | grep -E "ss=1"; }
-for d in 4 6 8; do
-run CTGPU_LDS_DEPTH=$d
-for w in 4 6 8; do run CTGPU_LDS_DEPTH=$d CTGPU_LIBRARY=$PWD/variants/libctgpu_w$w.so; done
-done
+run() { echo "== $*"; env "$@" timeout -k 10 100 python tools/quick_perf.py dragon bunny 2>&1 | grep -E "ss="; }
+run CTGPU_CHUNK=0
+run CTGPU_CHUNK=64
+run CTGPU_CHUNK=128
+run CTGPU_CHUNK=192
+run CTGPU_CHUNK=64 CTGPU_WALK_THRESH=32,32,24
+run CTGPU_CHUNK=64 CTGPU_WALK_THRESH=48,32,24
