@@ -41,6 +41,9 @@ def parse_args():
     ap.add_argument("--supersampling", type=int, default=-1, help="-1: scene file's setting")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-bands", type=int, default=16, help="row bands (of T) the CPU baseline samples")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="development aid: run the N-rank code path with every rank on GPU 0 and the gather "
+                         "staged through gloo (RCCL refuses two ranks on one device); numbers are meaningless")
     return ap.parse_args()
 
 
@@ -90,9 +93,14 @@ def main():
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device is visible")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     # every rank needs the assets and the native libraries; rank 0 prepares, the others wait
     if rank == 0:
@@ -113,13 +121,29 @@ def main():
     renderer = ShardedRenderer(scene.desc, rank, world, local_rank)
     stream = torch.cuda.current_stream()
 
+    def gather(tiles):
+        if world == 1:
+            return tiles
+        if args.rehearse_on_one_gpu:                      # gloo cannot move device memory: stage through the host
+            torch.cuda.synchronize()
+            staged = ca.multi_gpu.gather_to_root(tiles.cpu(), world, rank)
+            return staged.cuda() if staged is not None else None
+        return ca.multi_gpu.gather_to_root(tiles, world, rank)
+
     def sync_all():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def one_frame():
+        tiles = renderer.trace(frame)
+        gathered = gather(tiles)
+        if rank == 0:
+            _, fb = renderer._buffers_for(frame)
+            renderer.ctx.assemble(frame, renderer.part, gathered.data_ptr(), fb.data_ptr(), stream.cuda_stream)
+
     for _ in range(args.warmup):
-        renderer.frame(frame)
+        one_frame()
     sync_all()
     renderer.ctx.read_counters()          # reset the ray counters
 
@@ -132,7 +156,7 @@ def main():
         k_start[i].record(stream)
         tiles = renderer.trace(frame)
         k_end[i].record(stream)
-        gathered = ca.multi_gpu.gather_to_root(tiles, world, rank) if world > 1 else tiles
+        gathered = gather(tiles)
         if rank == 0:
             _, fb = renderer._buffers_for(frame)
             renderer.ctx.assemble(frame, renderer.part, gathered.data_ptr(), fb.data_ptr(), stream.cuda_stream)
@@ -141,7 +165,8 @@ def main():
 
     st = renderer.ctx.read_counters()
     kernel_ms = sum(a.elapsed_time(b) for a, b in zip(k_start, k_end)) / args.steps
-    totals = torch.tensor([float(st.rays), elapsed], dtype=torch.float64, device="cuda")
+    totals = torch.tensor([float(st.rays), elapsed], dtype=torch.float64,
+                          device="cpu" if args.rehearse_on_one_gpu else "cuda")
     if world > 1:
         rays_all = totals[:1].clone()
         dist.all_reduce(rays_all, op=dist.ReduceOp.SUM)
@@ -161,8 +186,11 @@ def main():
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
-    fb = renderer.frame(frame)
+    tiles = renderer.trace(frame)
+    gathered = gather(tiles)
     if rank == 0:
+        _, fb = renderer._buffers_for(frame)
+        renderer.ctx.assemble(frame, renderer.part, gathered.data_ptr(), fb.data_ptr(), stream.cuda_stream)
         host_fb.copy_(fb, non_blocking=True)
     torch.cuda.synchronize()
     to_host_ms = (time.perf_counter() - t0) * 1e3
@@ -175,8 +203,17 @@ def main():
         frame_bytes = algorithmic_bytes(work, pixels)
         launch_bytes = frame_bytes * (st.rays / args.steps) / max(work.rays, 1)   # rank 0's share of the frame
         achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
+        # HBM bytes per frame from the PMC passes of the same command (tools/collect_profiles.sh ->
+        # profiles/*_traffic.json); PMC counters cannot be collected from inside this process
+        traffic, traffic_src = None, None
+        if world == 1 and args.scene == "dragon" and args.width == 1920 and args.height == 1080 and is_ss:
+            import glob
+            found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+            if found:
+                rec = json.load(open(found[-1]))
+                traffic, traffic_src = rec["hbm_bytes_per_frame"], os.path.relpath(found[-1], ROOT)
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "kernel": "frame trace = ct_sample_grid + ct_walk<primary> + ct_walk<shadow> per light + ct_shade "
                               "(ct_walk is >95 % of it; rocprof per-kernel split in profiles/)",
                     "kernel_ms": round(kernel_ms, 4),

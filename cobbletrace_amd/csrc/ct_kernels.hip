@@ -288,12 +288,6 @@ __global__ __launch_bounds__(kWave) void ct_trace_tiles(const FrameParams P) {
         else if (n_c >= P.thresh_c) pick = 2;
         else pick = (n_a >= n_b && n_a >= n_c) ? 0 : ((n_b >= n_c) ? 1 : 2);
 
-        if (COUNT && lane == 0) {
-            // divergence statistics: phase executions and the lanes each one served
-            const int served = pick == 0 ? n_a : (pick == 1 ? n_b : n_c);
-            atomicAdd(&P.counters[5 + pick * 2], 1ull);
-            atomicAdd(&P.counters[6 + pick * 2], (unsigned long long)served);
-        }
         // ---------------- (A) inner nodes
         if (pick == 0) {
             if (want_a) {
