@@ -163,6 +163,21 @@ __device__ __forceinline__ bool ordinals_near(int32_t a, int32_t b, uint32_t ste
     return (uint32_t)(a - b) + steps <= 2u * steps;
 }
 
+// Same three decisions when ray_t > 0 is known (every ray of the wavefront pipeline: t starts at
+// 1e30f and only ever drops to hits > 0.0001f).  Raw bit patterns replace the ordinals:
+//  * tmax within 3 steps of +-0 is flagged by its magnitude bits;
+//  * for tmax >= tmin the raw-bit distance equals the ordinal distance when both have the same
+//    sign, and values of opposite sign can only be neighbours next to zero, which the first
+//    test has already flagged;
+//  * for tmin < t, t is positive and far from zero, so only a positive tmin can be near it.
+__device__ __forceinline__ bool box_verdict_positive_t(float tmin, float tmax, float ray_t, bool &pass) {
+    const int32_t bmin = __float_as_int(tmin), bmax = __float_as_int(tmax), bt = __float_as_int(ray_t);
+    const bool uncertain = (((uint32_t)bmax & 0x7fffffffu) <= 3u) | ordinals_near(bmax, bmin, 3u) |
+                           ordinals_near(bmin, bt, 2u);
+    pass = tmax >= tmin && tmin < ray_t && tmax > 0;
+    return !uncertain;
+}
+
 // The three decisions of the box test from approximate tmin / tmax (each <= 1 step off):
 // returns true when all three are certain, with the reference's verdict in `pass`.
 // (one more step of margin than the rounding argument needs, for the -0 / +0 ordinal pair)

@@ -196,10 +196,10 @@ __device__ __forceinline__ void enter(Walker &w, uint32_t ref) {
 // float step); if it is within one step of ray.t the verdict is not certain and the child
 // is parked for an exact re-test (phase E).
 __device__ __forceinline__ void pop_next(Walker &w, const WalkStack &st) {
-    const int32_t kt = float_ordinal(w.t);
+    const int32_t bt = __float_as_int(w.t);        // ray.t > 0: raw bits order like the floats do
     while (w.sp > 0) {
         const StackEntry e = st.top(w);
-        if (ordinals_near(float_ordinal(e.tmin), kt, 2u)) {
+        if (ordinals_near(__float_as_int(e.tmin), bt, 2u)) {
             w.cur = st.top_parent(w);
             w.leaf_left = kExactPopPending;
             w.sp -= 1;
@@ -226,9 +226,8 @@ __device__ __forceinline__ void step_inner(Walker &w, const WideNode *__restrict
     float ltmin, ltmax, rtmin, rtmax;
     slab_approx(w.o, w.inv, lmin, lmax, ltmin, ltmax);
     slab_approx(w.o, w.inv, rmin, rmax, rtmin, rtmax);
-    const int32_t kt = float_ordinal(w.t);
     bool lpass, rpass;
-    const bool sure = box_verdict(ltmin, ltmax, w.t, kt, lpass) & box_verdict(rtmin, rtmax, w.t, kt, rpass);
+    const bool sure = box_verdict_positive_t(ltmin, ltmax, w.t, lpass) & box_verdict_positive_t(rtmin, rtmax, w.t, rpass);
     if (!(sure & w.fast)) { w.leaf_left = kExactPending; return; }
     const uint32_t parent = w.cur;
     if (lpass) {
@@ -277,7 +276,7 @@ __device__ __forceinline__ void begin_ray(Walker &w, const FrameParams &P) {
     float tmin, tmax;
     bool pass;
     slab_approx(w.o, w.inv, P.root_min, P.root_max, tmin, tmax);
-    if (!(box_verdict(tmin, tmax, w.t, float_ordinal(w.t), pass) & w.fast)) {
+    if (!(box_verdict_positive_t(tmin, tmax, w.t, pass) & w.fast)) {
         slab(w.o, w.d, P.root_min, P.root_max, tmin, tmax);
         pass = tmax >= tmin && tmin < w.t && tmax > 0;
     }

@@ -204,3 +204,25 @@ def test_dragon_full_size_properties(scenes, gpu_ctx):
     rows = cpu_fb.any(axis=1)
     assert rows.sum() == 4 * 33
     _compare(a[rows], cpu_fb[rows], "dragon stand-in 1920x1080 bands 14-17")
+
+
+def test_both_gpu_paths_agree(scenes, monkeypatch):
+    """The wavefront pipeline (fast path) and the megakernel (general path) are two independent
+    implementations of the same semantics: bit-identical frames, identical ray counts."""
+    scene = scenes("bunny")
+    monkeypatch.setenv("CTGPU_FORCE_MEGAKERNEL", "1")
+    mega = ca.GpuContext(0)
+    monkeypatch.delenv("CTGPU_FORCE_MEGAKERNEL")
+    fast = ca.GpuContext(0)
+    mega.upload(scene.desc)
+    fast.upload(scene.desc)
+    try:
+        for ss, w, h in ((False, 1920, 1080), (True, 960, 540)):
+            frame = scene.frame(w, h, supersampling=ss, rng_seed=21)
+            a, sa = mega.render(frame)
+            b, sb = fast.render(frame)
+            assert (a == b).all()
+            assert (sa.rays_primary, sa.rays_shadow) == (sb.rays_primary, sb.rays_shadow)
+    finally:
+        mega.close()
+        fast.close()
