@@ -316,8 +316,8 @@ __device__ __forceinline__ void step_leaf(Walker &w, const TriRecord *__restrict
 // ------------------------------------------------------------------------------------
 // ct_walk: persistent traversal kernel.
 //   KIND 0  primary rays: ray index = sample id; result hits[id] = {ray.t, slot}
-//   KIND 1  shadow rays of ONE light (W.light_slot): ray index = sample id as well, but only
-//           samples whose primary ray found something get a ray; result: shadow byte of
+//   KIND 1  shadow rays of all non-ambient lights: ray index = light * n_samples + sample id, but
+//           only samples whose primary ray found something get a ray; result: shadow byte of
 //           (light, sample) set when the light is blocked
 // Ray indices are handed out in chunks of W.chunk consecutive ids: one global atomic per chunk
 // and wave (a single head word saturates near 90 dequeues/us on this chip, so per-ray or
@@ -341,16 +341,18 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk(const FrameParam
     st.overflow = P.overflow;
     const uint32_t lane = threadIdx.x;
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
-    const uint64_t n_rays = W.n_samples;
-    // The ray-id space is cut into kShards contiguous ranges, each with its own head word on its
-    // own 128-byte line (one head saturates near 90 dequeues/us chip-wide); a wave starts on the
-    // shard of its workgroup id (workgroups b and b+8 share an XCD under round-robin placement --
-    // speed only) and moves on to the next shard when one runs dry.
-    unsigned long long *heads = W.queue + (size_t)(KIND == 0 ? 0u : 1u + W.light_slot) * kShards * 16u;
-    const uint64_t shard_span = ((n_rays + kShards - 1) / kShards + W.chunk - 1) / W.chunk * W.chunk;
-    uint32_t shard = blockIdx.x % kShards, shards_done = 0;
-    const Light shadow_light = (KIND == 1) ? P.lights[W.shadow_lights[W.light_slot]] : Light{};
-    uint8_t *blocked = (KIND == 1) ? W.shadow + (size_t)W.light_slot * W.n_samples : nullptr;
+    // Ray ids: the primary walk's are the sample ids; the shadow walk's are light * n_samples + sample
+    // (which is also the index of the ray's result byte).  The id space is cut into shards -- kShards
+    // per light -- each with its own head word on its own 128-byte line (one head saturates near 90
+    // dequeues/us chip-wide); a wave starts on the shard of its workgroup id (workgroups b and b+8
+    // share an XCD under round-robin placement: speed only) and moves to the next when one runs dry.
+    const uint64_t n_samples = W.n_samples;
+    const uint32_t n_shards = (KIND == 0) ? kShards : kShards * W.n_shadow_lights;
+    unsigned long long *heads = W.queue + (size_t)(KIND == 0 ? 0u : kShards) * 16u;
+    const uint64_t shard_span = ((n_samples + kShards - 1) / kShards + W.chunk - 1) / W.chunk * W.chunk;
+    uint32_t shard = blockIdx.x % n_shards, shards_done = 0;
+    uint64_t light_base = 0;                 // first ray id of the light the current chunk belongs to
+    Light shadow_light = Light{};
     const d3 eye = make_d3(P.cam[0], P.cam[1], P.cam[2]);
 
     Walker w;
@@ -401,7 +403,7 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk(const FrameParam
         if (n_r >= W.thresh_r || (n_a == 0 && n_b == 0)) {
             if (finished) {
                 if (KIND == 0) W.hits[ray_id] = make_uint2(__float_as_uint(w.t), w.slot);
-                else if (w.t != kNoHit) blocked[ray_id] = 1;
+                else if (w.t != kNoHit) W.shadow[ray_id] = 1;         // [light][sample] == ray id
                 has_ray = false;
             }
             for (;;) {
@@ -411,20 +413,23 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk(const FrameParam
                     // (reserving one chunk ahead to hide the atomic's round trip was tried: the chunk a
                     // busy wave sits on at the end of the launch costs more than the latency it hides)
                     unsigned long long offset = 0;
-                    if (lane == 0) offset = atomicAdd(heads + shard * 16u, (unsigned long long)W.chunk);
+                    if (lane == 0) offset = atomicAdd(heads + (size_t)shard * 16u, (unsigned long long)W.chunk);
                     offset = __shfl(offset, 0);
-                    const uint64_t base = (uint64_t)shard * shard_span + offset;
-                    if (offset >= shard_span || base >= n_rays) {     // this shard is dry: try the next one
+                    const uint32_t light = shard / kShards, part = shard % kShards;
+                    const uint64_t lo = (uint64_t)part * shard_span + offset;       // sample id within the light
+                    if (offset >= shard_span || lo >= n_samples) {                   // this shard is dry: next one
                         shards_done += 1;
-                        shard = (shard + 1u) % kShards;
-                        if (shards_done >= kShards) { wave_drained = true; break; }
+                        shard = (shard + 1u) % n_shards;
+                        if (shards_done >= n_shards) { wave_drained = true; break; }
                         continue;
                     }
-                    chunk_next = base;
-                    const uint64_t shard_end = ((uint64_t)shard + 1u) * shard_span;
-                    chunk_end = base + W.chunk;
-                    if (chunk_end > shard_end) chunk_end = shard_end;
-                    if (chunk_end > n_rays) chunk_end = n_rays;
+                    uint64_t hi = lo + W.chunk;
+                    if (hi > ((uint64_t)part + 1u) * shard_span) hi = ((uint64_t)part + 1u) * shard_span;
+                    if (hi > n_samples) hi = n_samples;
+                    light_base = (uint64_t)light * n_samples;
+                    chunk_next = light_base + lo;
+                    chunk_end = light_base + hi;
+                    if (KIND == 1) shadow_light = P.lights[W.shadow_lights[light]];
                 }
                 const uint64_t avail = chunk_end - chunk_next;
                 const uint32_t rank = (uint32_t)__popcll(m_i & lanes_below);
@@ -433,8 +438,9 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk(const FrameParam
                 const uint64_t wanted = (uint64_t)__popcll(m_i);
                 chunk_next += (wanted < avail) ? wanted : avail;
                 if (take) {
+                    const uint64_t sample = id - light_base;
                     float px, py;
-                    bool live = sample_position<SS>(P, W, id, px, py);
+                    bool live = sample_position<SS>(P, W, sample, px, py);
                     if (KIND == 0) {
                         if (live) {
                             w.o = eye;
@@ -443,7 +449,7 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk(const FrameParam
                             W.hits[id] = make_uint2(__float_as_uint(kNoHit), kInvalidSample);
                         }
                     } else if (live) {
-                        const uint2 h = W.hits[id];
+                        const uint2 h = W.hits[sample];
                         live = __uint_as_float(h.x) != kNoHit;           // ClosestIntersection found something
                         if (live) {
                             // P = origin + tclosest * dir (raythread.cpp:360); tclosest = ray.t when a
@@ -599,19 +605,11 @@ void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hip
     if (ss) {
         hipLaunchKernelGGL(ct_sample_grid, dim3(pixel_blocks), dim3(256), 0, stream, P, W);
         hipLaunchKernelGGL((ct_walk<0, true>), dim3(W.walk_blocks), dim3(kWave), lds, stream, P, W);
-        for (uint32_t j = 0; j < W.n_shadow_lights; j++) {
-            PipelineParams Wj = W;
-            Wj.light_slot = j;
-            hipLaunchKernelGGL((ct_walk<1, true>), dim3(W.walk_blocks), dim3(kWave), lds, stream, P, Wj);
-        }
+        if (W.n_shadow_lights) hipLaunchKernelGGL((ct_walk<1, true>), dim3(W.walk_blocks), dim3(kWave), lds, stream, P, W);
         hipLaunchKernelGGL((ct_shade<true>), dim3(pixel_blocks), dim3(256), 0, stream, P, W);
     } else {
         hipLaunchKernelGGL((ct_walk<0, false>), dim3(W.walk_blocks), dim3(kWave), lds, stream, P, W);
-        for (uint32_t j = 0; j < W.n_shadow_lights; j++) {
-            PipelineParams Wj = W;
-            Wj.light_slot = j;
-            hipLaunchKernelGGL((ct_walk<1, false>), dim3(W.walk_blocks), dim3(kWave), lds, stream, P, Wj);
-        }
+        if (W.n_shadow_lights) hipLaunchKernelGGL((ct_walk<1, false>), dim3(W.walk_blocks), dim3(kWave), lds, stream, P, W);
         hipLaunchKernelGGL((ct_shade<false>), dim3(pixel_blocks), dim3(256), 0, stream, P, W);
     }
 }
