@@ -39,6 +39,7 @@ def parse_args():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--supersampling", type=int, default=-1, help="-1: scene file's setting")
+    ap.add_argument("--inflight", type=int, default=3, help="frames in flight (1 = strictly serial frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-bands", type=int, default=16, help="row bands (of T) the CPU baseline samples")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
@@ -118,54 +119,62 @@ def main():
     frame = scene.frame(args.width, args.height, supersampling=ss, rng_mode=ca.RNG_HASH, rng_seed=0)
     is_ss = bool(frame.flags & ca.F_SUPERSAMPLE)
 
-    renderer = ShardedRenderer(scene.desc, rank, world, local_rank)
-    stream = torch.cuda.current_stream()
+    # Frames are double-buffered (--inflight 2): frame i+1 is traced on a second stream / context
+    # while frame i's kernels drain their tail and its tiles are gathered and assembled, the way a
+    # renderer producing a stream of frames runs.  Each context owns its scene copy and scratch arrays.
+    inflight = max(1, args.inflight)
+    renderers = [ShardedRenderer(scene.desc, rank, world, local_rank) for _ in range(inflight)]
+    streams = [torch.cuda.Stream() for _ in range(inflight)]
+    renderer = renderers[0]
 
     def gather(tiles):
         if world == 1:
             return tiles
         if args.rehearse_on_one_gpu:                      # gloo cannot move device memory: stage through the host
-            torch.cuda.synchronize()
+            torch.cuda.current_stream().synchronize()
             staged = ca.multi_gpu.gather_to_root(tiles.cpu(), world, rank)
             return staged.cuda() if staged is not None else None
         return ca.multi_gpu.gather_to_root(tiles, world, rank)
 
     def sync_all():
+        torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def one_frame():
-        tiles = renderer.trace(frame)
-        gathered = gather(tiles)
-        if rank == 0:
-            _, fb = renderer._buffers_for(frame)
-            renderer.ctx.assemble(frame, renderer.part, gathered.data_ptr(), fb.data_ptr(), stream.cuda_stream)
+    def one_frame(i, events=None):
+        """Issue frame i: trace my tiles, gather to rank 0, assemble there (all asynchronous)."""
+        r, s_ = renderers[i % inflight], streams[i % inflight]
+        with torch.cuda.stream(s_):
+            if events:
+                events[0].record(s_)
+            tiles = r.trace(frame)
+            if events:
+                events[1].record(s_)
+            gathered = gather(tiles)
+            if rank == 0:
+                _, fb = r._buffers_for(frame)
+                r.ctx.assemble(frame, r.part, gathered.data_ptr(), fb.data_ptr(), s_.cuda_stream)
+                return fb
+        return None
 
-    for _ in range(args.warmup):
-        one_frame()
+    for i in range(max(args.warmup, inflight)):
+        one_frame(i)
     sync_all()
-    renderer.ctx.read_counters()          # reset the ray counters
+    for r in renderers:
+        r.ctx.read_counters()             # reset the ray counters
 
     # ---- timed region: exactly K frames
-    k_start = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    k_end = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     sync_all()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        k_start[i].record(stream)
-        tiles = renderer.trace(frame)
-        k_end[i].record(stream)
-        gathered = gather(tiles)
-        if rank == 0:
-            _, fb = renderer._buffers_for(frame)
-            renderer.ctx.assemble(frame, renderer.part, gathered.data_ptr(), fb.data_ptr(), stream.cuda_stream)
+        one_frame(i)
     sync_all()
     elapsed = time.perf_counter() - t0
 
-    st = renderer.ctx.read_counters()
-    kernel_ms = sum(a.elapsed_time(b) for a, b in zip(k_start, k_end)) / args.steps
-    totals = torch.tensor([float(st.rays), elapsed], dtype=torch.float64,
+    counted = [r.ctx.read_counters() for r in renderers]
+    my_rays = float(sum(c.rays for c in counted))
+    totals = torch.tensor([my_rays, elapsed], dtype=torch.float64,
                           device="cpu" if args.rehearse_on_one_gpu else "cuda")
     if world > 1:
         rays_all = totals[:1].clone()
@@ -174,24 +183,30 @@ def main():
         dist.all_reduce(time_max, op=dist.ReduceOp.MAX)
         total_rays, elapsed = float(rays_all.item()), float(time_max.item())
     else:
-        total_rays = float(st.rays)
+        total_rays = my_rays
     rays_per_frame = total_rays / args.steps
     ms_per_step = elapsed / args.steps * 1e3
     value = total_rays / elapsed / 1e6
 
-    if rank == 0:
-        # ---- frame -> host framebuffer (the reference's hand-off buffer), PCIe included; not `value`
-        host_fb = torch.empty(frame.height * frame.width, dtype=torch.int32).pin_memory()
-        sync_all() if world == 1 else torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
+    # ---- un-overlapped passes (outside the timed region): kernel time for the roofline, one frame's
+    # latency, and the frame -> host framebuffer hand-off (PCIe included; never `value`)
+    serial = 5
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(serial)]
+    sync_all()
     t0 = time.perf_counter()
-    tiles = renderer.trace(frame)
-    gathered = gather(tiles)
+    for k in range(serial):
+        one_frame(0, ev[k])
+        sync_all()
+    latency_ms = (time.perf_counter() - t0) / serial * 1e3
+    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / serial
+    rank0_rays_per_frame = renderers[0].ctx.read_counters().rays / serial
+    host_fb = torch.empty(frame.height * frame.width, dtype=torch.int32).pin_memory() if rank == 0 else None
+    sync_all()
+    t0 = time.perf_counter()
+    fb = one_frame(0)
     if rank == 0:
-        _, fb = renderer._buffers_for(frame)
-        renderer.ctx.assemble(frame, renderer.part, gathered.data_ptr(), fb.data_ptr(), stream.cuda_stream)
-        host_fb.copy_(fb, non_blocking=True)
+        with torch.cuda.stream(streams[0]):
+            host_fb.copy_(fb, non_blocking=True)
     torch.cuda.synchronize()
     to_host_ms = (time.perf_counter() - t0) * 1e3
 
@@ -201,7 +216,7 @@ def main():
         work = renderer.ctx.count_work(frame)           # whole frame, instrumented variant
         pixels = int(work.rays_primary // (16 if is_ss else 1))
         frame_bytes = algorithmic_bytes(work, pixels)
-        launch_bytes = frame_bytes * (st.rays / args.steps) / max(work.rays, 1)   # rank 0's share of the frame
+        launch_bytes = frame_bytes * rank0_rays_per_frame / max(work.rays, 1)     # rank 0's share of the frame
         achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
         # HBM bytes per frame from the PMC passes of the same command (tools/collect_profiles.sh ->
         # profiles/*_traffic.json); PMC counters cannot be collected from inside this process
@@ -232,6 +247,7 @@ def main():
                                     "supersampling 16 spp (hash jitter)" if is_ss else "1 spp"),
                        "rays_per_frame": int(rays_per_frame), "row_tiles": "8 rows, round-robin over %d GPU(s)" % world,
                        "collective": "RCCL gather to rank 0" if world > 1 else "none"},
+            "frames_in_flight": inflight, "ms_frame_latency": round(latency_ms, 4),
             "ms_per_frame_to_host": round(to_host_ms, 4),
             "roofline": roofline,
         }
@@ -243,7 +259,8 @@ def main():
                                              (picks, frame.num_threads, rays, seconds),
                                    "host_cores": os.cpu_count()}
         print(json.dumps(out), flush=True)
-    renderer.close()
+    for r in renderers:
+        r.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
