@@ -19,7 +19,12 @@ def short(name):
 
 
 stats = {}
-for f in glob.glob("%s/%s_stats/*/*kernel_stats.csv" % (out, tag)):
+def newest(pattern):
+    found = sorted(glob.glob(pattern), key=os.path.getmtime)
+    return found[-1:]                       # gpurun_out accumulates earlier collections: keep the latest
+
+
+for f in newest("%s/%s_stats/*/*kernel_stats.csv" % (out, tag)):
     for r in csv.DictReader(open(f)):
         k = short(r["Name"])
         if k:
@@ -27,14 +32,14 @@ for f in glob.glob("%s/%s_stats/*/*kernel_stats.csv" % (out, tag)):
 
 counters = collections.defaultdict(lambda: collections.defaultdict(list))
 for part in ("fetch", "write", "cache", "sq"):
-    for f in glob.glob("%s/%s_%s/*/*counter_collection.csv" % (out, tag, part)):
+    for f in newest("%s/%s_%s/*/*counter_collection.csv" % (out, tag, part)):
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
             if k:
                 counters[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 mean = lambda v: sum(v) / len(v) if v else 0.0
 
-launches = {"ct_sample_grid": 1, "ct_walk<0>": 1, "ct_walk<1>": 2, "ct_shade": 1, "ct_assemble": 1}
+launches = {"ct_sample_grid": 1, "ct_walk<0>": 1, "ct_walk<1>": 1, "ct_shade": 1, "ct_assemble": 1}
 lines = ["# rocprofv3 summary %s -- `python bench.py` (dragon stand-in 1920x1080, 16 spp, 1 MI355X)" % tag, "",
          "| kernel | launches/frame | avg ms | FETCH_SIZE KB | WRITE_SIZE KB | L2 hit % | L1 (TCP) hit % | VALU lane util % |",
          "|---|---|---|---|---|---|---|---|"]
