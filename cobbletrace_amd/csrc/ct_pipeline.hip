@@ -156,35 +156,56 @@ struct Walker {
 // WideNode that holds the child's box (needed only when the popped tmin is too close to
 // ray.t to be trusted, see pop_next).  Entry e of lane l: [e][l]; the first lds_depth
 // entries in LDS, deeper ones in this wave's spill area in HBM.
+// (LDS and HBM parts are addressed through address-space-qualified pointers and separate
+// branches: selecting between two generic pointers makes the compiler emit flat_load / flat_store
+// with a double wait on every push and pop.)
+typedef StackEntry __attribute__((address_space(3))) LdsEntry;
+typedef uint32_t __attribute__((address_space(3))) LdsWord;
+typedef StackEntry __attribute__((address_space(1))) HbmEntry;
+typedef uint32_t __attribute__((address_space(1))) HbmWord;
+
 struct WalkStack {
-    StackEntry *lds;          // [lds_depth][64]
-    uint32_t *lds_parent;     // [lds_depth][64]
-    StackEntry *spill;        // [spill_depth][64]
-    uint32_t *spill_parent;   // [spill_depth][64]
+    LdsEntry *lds;            // [lds_depth][64]
+    LdsWord *lds_parent;      // [lds_depth][64]
+    HbmEntry *spill;          // [spill_depth][64]
+    HbmWord *spill_parent;    // [spill_depth][64]
     uint32_t lds_depth, spill_depth, lane;
     uint32_t *overflow;
 
     __device__ __forceinline__ void push(Walker &w, uint32_t ref, float tmin, uint32_t parent) const {
-        const StackEntry e{ref, tmin};
         if (w.sp < lds_depth) {
-            lds[w.sp * kWave + lane] = e;
-            lds_parent[w.sp * kWave + lane] = parent;
+            const uint32_t at = w.sp * kWave + lane;
+            lds[at].ref = ref;
+            lds[at].tmin = tmin;
+            lds_parent[at] = parent;
         } else if (w.sp - lds_depth < spill_depth) {
-            spill[(w.sp - lds_depth) * kWave + lane] = e;
-            spill_parent[(w.sp - lds_depth) * kWave + lane] = parent;
+            const uint32_t at = (w.sp - lds_depth) * kWave + lane;
+            spill[at].ref = ref;
+            spill[at].tmin = tmin;
+            spill_parent[at] = parent;
         } else {
             atomicOr(overflow, 1u);
             return;
         }
         w.sp += 1;
     }
-    __device__ __forceinline__ StackEntry top(const Walker &w) const {       // entry sp-1
+    // entry sp-1: child reference, approximate tmin
+    __device__ __forceinline__ void top(const Walker &w, uint32_t &ref, float &tmin) const {
         const uint32_t i = w.sp - 1u;
-        return (i < lds_depth) ? lds[i * kWave + lane] : spill[(i - lds_depth) * kWave + lane];
+        if (i < lds_depth) {
+            const uint32_t at = i * kWave + lane;
+            ref = lds[at].ref;
+            tmin = lds[at].tmin;
+        } else {
+            const uint32_t at = (i - lds_depth) * kWave + lane;
+            ref = spill[at].ref;
+            tmin = spill[at].tmin;
+        }
     }
     __device__ __forceinline__ uint32_t top_parent(const Walker &w) const {
         const uint32_t i = w.sp - 1u;
-        return (i < lds_depth) ? lds_parent[i * kWave + lane] : spill_parent[(i - lds_depth) * kWave + lane];
+        if (i < lds_depth) return lds_parent[i * kWave + lane];
+        return spill_parent[(i - lds_depth) * kWave + lane];
     }
 };
 
@@ -210,15 +231,17 @@ __device__ __forceinline__ void enter(Walker &w, uint32_t ref) {
 __device__ __forceinline__ void pop_next(Walker &w, const WalkStack &st) {
     const int32_t bt = __float_as_int(w.t);        // ray.t > 0: raw bits order like the floats do
     while (w.sp > 0) {
-        const StackEntry e = st.top(w);
-        if (ordinals_near(__float_as_int(e.tmin), bt, 2u)) {
+        uint32_t ref;
+        float tmin;
+        st.top(w, ref, tmin);
+        if (ordinals_near(__float_as_int(tmin), bt, 2u)) {
             w.cur = st.top_parent(w);
             w.leaf_left = kExactPopPending;
             w.sp -= 1;
             return;
         }
         w.sp -= 1;
-        if (e.tmin < w.t) { enter(w, e.ref); return; }
+        if (tmin < w.t) { enter(w, ref); return; }
     }
     w.cur = kNoNode;
     w.leaf_left = 0;
@@ -349,15 +372,15 @@ template <int KIND, bool SS>
 __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk(const FrameParams P, const PipelineParams W) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     WalkStack st;
-    st.lds = reinterpret_cast<StackEntry *>(lds_raw);
-    st.lds_parent = reinterpret_cast<uint32_t *>(lds_raw + (size_t)W.lds_depth * kWave * sizeof(StackEntry));
+    st.lds = (LdsEntry *)lds_raw;
+    st.lds_parent = (LdsWord *)(lds_raw + (size_t)W.lds_depth * kWave * sizeof(StackEntry));
     st.lane = threadIdx.x;
     st.lds_depth = W.lds_depth;
     st.spill_depth = W.spill_depth;
     // this wave's spill area: spill_depth x 64 entries of 8 bytes, then as many parent words
     unsigned char *spill_base = reinterpret_cast<unsigned char *>(W.spill) + (size_t)blockIdx.x * W.spill_depth * kWave * 12u;
-    st.spill = reinterpret_cast<StackEntry *>(spill_base);
-    st.spill_parent = reinterpret_cast<uint32_t *>(spill_base + (size_t)W.spill_depth * kWave * sizeof(StackEntry));
+    st.spill = (HbmEntry *)spill_base;
+    st.spill_parent = (HbmWord *)(spill_base + (size_t)W.spill_depth * kWave * sizeof(StackEntry));
     st.overflow = P.overflow;
     const uint32_t lane = threadIdx.x;
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
@@ -544,14 +567,14 @@ template <bool SS>
 __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk_fused(const FrameParams P, const PipelineParams W) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     WalkStack st;
-    st.lds = reinterpret_cast<StackEntry *>(lds_raw);
-    st.lds_parent = reinterpret_cast<uint32_t *>(lds_raw + (size_t)W.lds_depth * kWave * sizeof(StackEntry));
+    st.lds = (LdsEntry *)lds_raw;
+    st.lds_parent = (LdsWord *)(lds_raw + (size_t)W.lds_depth * kWave * sizeof(StackEntry));
     st.lane = threadIdx.x;
     st.lds_depth = W.lds_depth;
     st.spill_depth = W.spill_depth;
     unsigned char *spill_base = reinterpret_cast<unsigned char *>(W.spill) + (size_t)blockIdx.x * W.spill_depth * kWave * 12u;
-    st.spill = reinterpret_cast<StackEntry *>(spill_base);
-    st.spill_parent = reinterpret_cast<uint32_t *>(spill_base + (size_t)W.spill_depth * kWave * sizeof(StackEntry));
+    st.spill = (HbmEntry *)spill_base;
+    st.spill_parent = (HbmWord *)(spill_base + (size_t)W.spill_depth * kWave * sizeof(StackEntry));
     st.overflow = P.overflow;
     const uint32_t lane = threadIdx.x;
     const unsigned long long lanes_below = (1ull << lane) - 1ull;
