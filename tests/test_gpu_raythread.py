@@ -72,3 +72,26 @@ def test_raythread_supersampled_scene_defaults(assets):
     want, _ = oracle.render(scene.desc, frame, os_threads=8)
     assert channel_diff(fb, want).max() <= 1
     host.cth_raythread_reset()
+
+
+def test_headless_application(assets, tmp_path):
+    """cobbletrace_headless = the reference's main() without SDL: parse, RayThread per frame, PPM out."""
+    import subprocess
+    from oracle import oracle
+    root = os.path.dirname(assets)
+    exe = os.path.join(root, "cobbletrace_amd", "host", "cobbletrace_headless")
+    out = tmp_path / "cube.ppm"
+    proc = subprocess.run([exe, os.path.join(assets, "scene_file_cube.json"), "--width", "320", "--height", "240",
+                           "--out", str(out), "--seed", "4"], cwd=assets, capture_output=True, text=True, timeout=120)
+    assert proc.returncode == 0, proc.stderr
+    data = out.read_bytes()
+    header = b"P6\n320 240\n255\n"
+    assert data.startswith(header)
+    rgb = np.frombuffer(data[len(header):], dtype=np.uint8).reshape(240, 320, 3).astype(np.uint32)
+    fb = rgb[..., 0] | (rgb[..., 1] << 8) | (rgb[..., 2] << 16)
+    scene = ca.HostScene(os.path.join(assets, "scene_file_cube.json"))      # T=8, supersampling on, reflective materials
+    frame = scene.frame(320, 240, rng_mode=ca.RNG_HASH, rng_seed=4)
+    want, _ = oracle.render(scene.desc, frame, os_threads=4)
+    assert channel_diff(fb, want).max() <= 1
+    # no scene file -> usage, exit 0 like Help() (cobbletrace.cpp:20-24)
+    assert subprocess.run([exe], capture_output=True).returncode == 0
