@@ -56,7 +56,6 @@ struct PipelineParams {
     uint2    *hits;              // [n_samples] {ray.t bits, closest TriRecord slot | kNoNode | invalid}
     uint8_t  *shadow;            // [n_shadow_lights][n_samples] 1 = that light is blocked
     unsigned long long *queue;   // [1 + 32 walks][8 shards][16] head words (128-byte stride) of the ray queues
-    uint32_t fused;              // 1: one ct_walk_fused launch; 0: separate primary / shadow walks
     void     *spill;             // [walk_blocks][spill_depth][64] stack entries beyond the LDS part
     const uint32_t *shadow_lights;   // [n_shadow_lights] index into lights[]
     uint64_t n_samples;

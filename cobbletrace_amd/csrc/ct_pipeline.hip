@@ -555,165 +555,6 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk(const FrameParam
 }
 
 // ------------------------------------------------------------------------------------
-// ct_walk_fused: primary AND shadow rays of a sample in one persistent launch.
-// A lane takes a sample, walks its primary ray, and -- if ClosestIntersection found something --
-// walks one any-hit ray per non-ambient light from the hit point, all without leaving its
-// registers (no hits[] / coords[] re-reads, no second launch with its own tail).  The wave
-// moves from one stage to the next together (retire/fetch runs when every lane is done), so a
-// wave is either tracing 64 primary rays or the shadow rays of its hit lanes.
-// Results: hits[sample], shadow[light][sample] -- exactly what the split kernels leave.
-// ------------------------------------------------------------------------------------
-template <bool SS>
-__global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk_fused(const FrameParams P, const PipelineParams W) {
-    extern __shared__ __align__(16) unsigned char lds_raw[];
-    WalkStack st;
-    st.lds = (LdsEntry *)lds_raw;
-    st.lds_parent = (LdsWord *)(lds_raw + (size_t)W.lds_depth * kWave * sizeof(StackEntry));
-    st.lane = threadIdx.x;
-    st.lds_depth = W.lds_depth;
-    st.spill_depth = W.spill_depth;
-    unsigned char *spill_base = reinterpret_cast<unsigned char *>(W.spill) + (size_t)blockIdx.x * W.spill_depth * kWave * 12u;
-    st.spill = (HbmEntry *)spill_base;
-    st.spill_parent = (HbmWord *)(spill_base + (size_t)W.spill_depth * kWave * sizeof(StackEntry));
-    st.overflow = P.overflow;
-    const uint32_t lane = threadIdx.x;
-    const unsigned long long lanes_below = (1ull << lane) - 1ull;
-    const uint64_t n_samples = W.n_samples;
-    unsigned long long *heads = W.queue;
-    const uint64_t shard_span = ((n_samples + kShards - 1) / kShards + W.chunk - 1) / W.chunk * W.chunk;
-    uint32_t shard = blockIdx.x % kShards, shards_done = 0;
-    const d3 eye = make_d3(P.cam[0], P.cam[1], P.cam[2]);
-
-    Walker w;
-    w.o = eye; w.d = make_d3(0, 0, 1); w.inv = make_d3(0, 0, 1);
-    w.t = kNoHit; w.slot = kNoNode; w.cur = kNoNode; w.sp = 0; w.leaf_left = 0; w.fast = false;
-    uint64_t sample = 0;
-    uint32_t stage = 0;               // 0 = primary ray, j >= 1 = shadow ray of non-ambient light j-1
-    float px = 0.0f, py = 0.0f;       // canvas position of the sample (to rebuild the primary direction)
-    float tclosest = kFarAway;        // of the primary ray, once it has hit
-    bool has_ray = false;
-    uint64_t chunk_next = 0, chunk_end = 0;
-    bool wave_drained = false;
-    uint32_t n_primary = 0, n_shadow = 0;
-
-    for (;;) {
-        const bool walking = has_ray && w.cur != kNoNode;
-        const bool finished = has_ray && w.cur == kNoNode;
-        const bool want_e = walking && w.leaf_left >= kExactPopPending;
-        const bool want_b = walking && w.leaf_left != 0 && !want_e;
-        const bool want_a = walking && w.leaf_left == 0;
-        const unsigned long long m_a = __ballot(want_a), m_b = __ballot(want_b);
-        const int n_a = __popcll(m_a), n_b = __popcll(m_b);
-        const int n_r = wave_drained ? __popcll(__ballot(finished)) : __popcll(__ballot(!walking));
-        if (__ballot(want_e) != 0ull) {
-            if (want_e) step_exact(w, P.nodes, st);
-            continue;
-        }
-        if (n_r == 0 && n_a == 0 && n_b == 0) break;
-
-        // ---------------- (R) retire finished rays; next stage of the same sample, or a new sample
-        if (n_r >= W.thresh_r || (n_a == 0 && n_b == 0)) {
-            if (finished) {
-                bool next_light = false;
-                if (stage == 0) {
-                    W.hits[sample] = make_uint2(__float_as_uint(w.t), w.slot);
-                    if (w.t != kNoHit) {                       // ClosestIntersection found something
-                        // P = origin + tclosest * dir (raythread.cpp:360); tclosest = ray.t when a triangle
-                        // was recorded, else 2^32
-                        tclosest = (w.slot != kNoNode) ? w.t : kFarAway;
-                        next_light = W.n_shadow_lights > 0;
-                    }
-                } else {
-                    if (w.t != kNoHit) W.shadow[(size_t)(stage - 1u) * n_samples + sample] = 1;
-                    next_light = stage < W.n_shadow_lights;
-                }
-                if (next_light) {
-                    const Light L = P.lights[W.shadow_lights[stage]];
-                    w.o = eye + scale((double)tclosest, primary_direction(P, px, py));
-                    w.d = (L.type == CTGPU_LIGHT_POINT) ? load_d3(L.position) - w.o : load_d3(L.direction);
-                    w.t = kNoHit;
-                    begin_ray(w, P);
-                    stage += 1;
-                    n_shadow += 1;
-                } else {
-                    has_ray = false;
-                }
-            }
-            for (;;) {
-                const unsigned long long m_i = __ballot(!has_ray);
-                if (m_i == 0ull || wave_drained) break;
-                if (chunk_next >= chunk_end) {
-                    unsigned long long offset = 0;
-                    if (lane == 0) offset = atomicAdd(heads + (size_t)shard * 16u, (unsigned long long)W.chunk);
-                    offset = __shfl(offset, 0);
-                    const uint64_t lo = (uint64_t)shard * shard_span + offset;
-                    if (offset >= shard_span || lo >= n_samples) {
-                        shards_done += 1;
-                        shard = (shard + 1u) % kShards;
-                        if (shards_done >= kShards) { wave_drained = true; break; }
-                        continue;
-                    }
-                    uint64_t hi = lo + W.chunk;
-                    if (hi > ((uint64_t)shard + 1u) * shard_span) hi = ((uint64_t)shard + 1u) * shard_span;
-                    if (hi > n_samples) hi = n_samples;
-                    chunk_next = lo;
-                    chunk_end = hi;
-                }
-                const uint64_t avail = chunk_end - chunk_next;
-                const uint32_t rank = (uint32_t)__popcll(m_i & lanes_below);
-                const bool take = !has_ray && rank < avail;
-                const uint64_t id = chunk_next + rank;
-                const uint64_t wanted = (uint64_t)__popcll(m_i);
-                chunk_next += (wanted < avail) ? wanted : avail;
-                if (take) {
-                    if (sample_position<SS>(P, W, id, px, py)) {
-                        w.o = eye;
-                        w.d = primary_direction(P, px, py);
-                        w.t = kNoHit;
-                        begin_ray(w, P);
-                        sample = id;
-                        stage = 0;
-                        has_ray = true;
-                        n_primary += 1;
-                    } else {
-                        W.hits[id] = make_uint2(__float_as_uint(kNoHit), kInvalidSample);
-                    }
-                }
-            }
-            continue;
-        }
-        // ---------------- (A) / (B)
-        const bool do_a = (n_a >= W.thresh_a) || (n_b < W.thresh_b && n_a >= n_b) || n_b == 0;
-        if (do_a && n_a > 0) {
-            bool more = want_a;
-            int n_more;
-            do {
-                if (more) step_inner(w, P.nodes, st);
-                more = has_ray && w.cur != kNoNode && w.leaf_left == 0;
-                n_more = __popcll(__ballot(more));
-            } while (n_more >= W.thresh_a);
-        } else {
-            bool more = want_b;
-            int n_more;
-            do {
-                if (more) step_leaf(w, P.tris, st, stage > 0);
-                more = has_ray && w.cur != kNoNode && w.leaf_left != 0 && w.leaf_left < kExactPopPending;
-                n_more = __popcll(__ballot(more));
-            } while (n_more >= W.thresh_b);
-        }
-    }
-
-    for (int off = 32; off > 0; off >>= 1) {
-        n_primary += __shfl_down(n_primary, off);
-        n_shadow += __shfl_down(n_shadow, off);
-    }
-    if (lane == 0) {
-        atomicAdd(&P.counters[0], (unsigned long long)n_primary);
-        atomicAdd(&P.counters[1], (unsigned long long)n_shadow);
-    }
-}
-
-// ------------------------------------------------------------------------------------
 // ct_shade: lighting of every sample of a pixel in order, running blend, pixel store.
 // raythread.cpp:353-366 (TraceRay without reflection), 275-327 (ComputeLighting with the
 // shadow decisions read from the mask), 482-498 (blend), color.h.
@@ -796,28 +637,10 @@ int pipeline_walk_occupancy(size_t lds_bytes) {
     int a = 0, b = 0;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, ct_walk<0, true>, kWave, lds_bytes);
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, ct_walk<1, true>, kWave, lds_bytes);
-    int c = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, ct_walk_fused<true>, kWave, lds_bytes);
-    a = a < b ? a : b;
-    return a < c ? a : c;
+    return a < b ? a : b;
 }
 
 void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hipStream_t stream) {
-    if (W.fused) {
-        const size_t lds_f = (size_t)W.lds_depth * kWave * 12u;
-        const uint32_t slots = (uint32_t)(ss ? W.n_samples / 16u : W.n_samples);
-        const uint32_t blocks = (slots + 255u) / 256u;
-        if (W.n_samples == 0) return;
-        if (ss) {
-            hipLaunchKernelGGL(ct_sample_grid, dim3(blocks), dim3(256), 0, stream, P, W);
-            hipLaunchKernelGGL((ct_walk_fused<true>), dim3(W.walk_blocks), dim3(kWave), lds_f, stream, P, W);
-            hipLaunchKernelGGL((ct_shade<true>), dim3(blocks), dim3(256), 0, stream, P, W);
-        } else {
-            hipLaunchKernelGGL((ct_walk_fused<false>), dim3(W.walk_blocks), dim3(kWave), lds_f, stream, P, W);
-            hipLaunchKernelGGL((ct_shade<false>), dim3(blocks), dim3(256), 0, stream, P, W);
-        }
-        return;
-    }
     const size_t lds = (size_t)W.lds_depth * kWave * 12u;      // entries + parent words
     const uint32_t pixel_slots = (uint32_t)(ss ? W.n_samples / 16u : W.n_samples);
     const uint32_t pixel_blocks = (pixel_slots + 255u) / 256u;

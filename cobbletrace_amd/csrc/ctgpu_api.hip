@@ -92,8 +92,6 @@ struct ctgpu_ctx {
     int blocks_per_cu = 0;                      // 0 = occupancy query
     int chunk = 0;                              // 0 = sized from the frame
     bool force_megakernel = false;
-    bool fused_walk = false;                    // one launch for primary + shadow rays (wins on small, shallow
-                                                // scenes; the split walks win on the dragon-sized ones)
 
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -175,7 +173,6 @@ extern "C" int ctgpu_create(int device, ctgpu_ctx **out) {
     if (const char *t = std::getenv("CTGPU_LDS_DEPTH")) ctx->lds_depth = std::max(1, std::atoi(t));
     if (const char *t = std::getenv("CTGPU_BLOCKS_PER_CU")) ctx->blocks_per_cu = std::max(0, std::atoi(t));
     if (const char *t = std::getenv("CTGPU_CHUNK")) ctx->chunk = std::max(0, std::atoi(t));
-    if (const char *t = std::getenv("CTGPU_FUSED_WALK")) ctx->fused_walk = std::atoi(t) != 0;
     if (const char *t = std::getenv("CTGPU_FORCE_MEGAKERNEL")) ctx->force_megakernel = std::atoi(t) != 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->cu_count = prop.multiProcessorCount;
@@ -493,7 +490,6 @@ int launch_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, FrameParams &P, hipS
     uint64_t chunk = ctx->chunk > 0 ? (uint64_t)ctx->chunk : (W.n_samples >= (4u << 20) ? 128u : 64u);
     chunk = std::min<uint64_t>(std::max<uint64_t>((chunk + 63) / 64 * 64, 64), 4096);
     W.chunk = (uint32_t)chunk;
-    W.fused = ctx->fused_walk ? 1u : 0u;
     W.thresh_r = ctx->walk_thresh[0]; W.thresh_a = ctx->walk_thresh[1]; W.thresh_b = ctx->walk_thresh[2];
 
     if (ss) HIP_TRY(ctx->coords.resize(W.n_samples));

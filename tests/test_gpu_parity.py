@@ -229,12 +229,11 @@ def test_both_gpu_paths_agree(scenes, monkeypatch):
 
 
 @pytest.mark.parametrize("env", [{"CTGPU_LDS_DEPTH": "1"}, {"CTGPU_LDS_DEPTH": "3", "CTGPU_CHUNK": "64"},
-                                 {"CTGPU_FUSED_WALK": "1"}, {"CTGPU_FUSED_WALK": "1", "CTGPU_LDS_DEPTH": "2"},
                                  {"CTGPU_CHUNK": "4096"}, {"CTGPU_WALK_THRESH": "8,16,8"},
                                  {"CTGPU_BLOCKS_PER_CU": "1"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_pipeline_knobs_do_not_change_pixels(env, scenes, gpu_ctx, monkeypatch):
-    """Stack spill to HBM (tiny LDS depth), the fused walk, chunk sizes, phase thresholds and the
+    """Stack spill to HBM (tiny LDS depth), chunk sizes, phase thresholds and the
     persistent grid size are performance knobs only: every setting renders the identical frame."""
     scene = scenes("bunny")
     frames = [scene.frame(640, 360, supersampling=False), scene.frame(320, 200, threads=8, supersampling=True, rng_seed=5)]
