@@ -20,8 +20,8 @@
 // which is what lets 6-8 waves share a SIMD.  The traversal stack is per lane: the first
 // P.lds_depth entries in LDS, deeper ones (rare) in a per-wave spill area in HBM.
 //
-// Scope: scenes without reflective materials, subsampling off, at most 32 non-ambient
-// lights.  Everything else takes the megakernel.  Semantics and citations: ct_device.h,
+// Scope: scenes without reflective materials and with at most 32 non-ambient lights.
+// Everything else takes the megakernel.  Semantics and citations: ct_device.h,
 // ct_kernels.hip header.
 #include "ct_params.h"
 #include "ct_raygen.h"
@@ -82,9 +82,16 @@ __device__ __forceinline__ bool pixel_in_frame(const FrameParams &P, uint32_t xi
     small_divmod(local_row, P.tile_rows, local_tile, row_in_tile);
     yi = (local_tile * P.part_count + P.part_index) * P.tile_rows + row_in_tile;
     if (xi >= P.square || local_row >= P.local_rows || yi >= P.rendered_rows) return false;
-    // off-bitmap pixels are computed and dropped by the reference (draw2d.h:11-14): not traced here
+    if (P.subsample) {
+        // rows a band actually traces (raythread.cpp:526-535): even offsets and the band's last row;
+        // the rows between are averages made by ct_assemble
+        const uint32_t off = yi % P.rows_per_band;
+        if ((off & 1u) != 0u && off != P.rows_per_band - 1u) return false;
+    }
+    // off-bitmap pixels are computed and dropped by the reference (draw2d.h:11-14): not traced here --
+    // except that with subsampling the dropped row still feeds the average stored one row above it
     const int row = P.height / 2 - ((int)yi - P.half), col = (int)xi - P.half + P.width / 2;
-    return row >= 0 && row < P.height && col >= 0 && col < P.width;
+    return col >= 0 && col < P.width && (P.subsample || (row >= 0 && row < P.height));
 }
 
 }  // namespace

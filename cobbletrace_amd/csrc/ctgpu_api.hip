@@ -457,12 +457,11 @@ int read_counters(ctgpu_ctx *ctx, ctgpu_stats *st) {
 // ------------------------------------------------------------------ one partition's trace
 namespace {
 
-// The wavefront pipeline covers what the shipped import scenes need; reflective materials,
-// subsampling and more than 32 shadow-casting lights take the megakernel.
+// The wavefront pipeline covers what the shipped import scenes need; reflective materials and
+// more than 32 shadow-casting lights take the megakernel.
 bool pipeline_eligible(const ctgpu_ctx *ctx, const ctgpu_frame_desc *f) {
     if (ctx->force_megakernel) return false;
     if (ctx->has_reflection && f->max_depth > 0) return false;
-    if (f->flags & CTGPU_F_SUBSAMPLE) return false;
     return ctx->n_shadow_lights <= 32;
 }
 

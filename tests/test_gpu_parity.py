@@ -217,8 +217,9 @@ def test_both_gpu_paths_agree(scenes, monkeypatch):
     mega.upload(scene.desc)
     fast.upload(scene.desc)
     try:
-        for ss, w, h in ((False, 1920, 1080), (True, 960, 540)):
-            frame = scene.frame(w, h, supersampling=ss, rng_seed=21)
+        for ss, sub, w, h in ((False, False, 1920, 1080), (True, False, 960, 540), (False, True, 640, 360),
+                              (True, True, 320, 250)):
+            frame = scene.frame(w, h, supersampling=ss, subsampling=sub, rng_seed=21)
             a, sa = mega.render(frame)
             b, sb = fast.render(frame)
             assert (a == b).all()
