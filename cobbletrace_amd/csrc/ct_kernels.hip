@@ -66,6 +66,10 @@ __device__ __forceinline__ void start_traversal(LaneRay &r, const FrameParams &P
     r.cur = pass ? P.root_ref : kNoNode;
     r.sp = 0;
     r.leaf_left = 0;
+    if (pass && (P.root_ref & kLeafBit)) {      // a tree that is a single leaf (<= 2 triangles, or unsplittable)
+        r.cur = P.root_ref & ~kLeafBit;
+        r.leaf_left = 0xffffffffu;               // filled from the first record
+    }
     r.tclosest = kFarAway;
     r.slot = kNoNode;
 }

@@ -251,3 +251,119 @@ def test_pipeline_knobs_do_not_change_pixels(env, scenes, gpu_ctx, monkeypatch):
             assert (got == w).all()
     finally:
         ctx.close()
+
+
+def _write_scene(tmp_path, name, triangles, lights, settings=None, camera=(0, 0, -3)):
+    import json
+    objs = [{"type": "triangle", "p1": t[0], "p2": t[1], "p3": t[2], "color": list(t[3]), "specular": t[4],
+             "reflection": 0} for t in triangles]
+    scene = {"objects": objs, "camera": {"position": list(camera)},
+             "settings": settings or {"numberOfThreads": 4, "subsampling": False, "wireframe": False,
+                                      "supersampling": False}}
+    if lights:       # an empty list is a syntax error for the reference's reader (scenefile.cpp:142), and ours
+        scene["lights"] = lights
+    path = tmp_path / name
+    path.write_text(json.dumps(scene))
+    return str(path)
+
+
+def _render_both(path, w, h, **kw):
+    scene = ca.HostScene(path)
+    ctx = ca.GpuContext(0)
+    ctx.upload(scene.desc)
+    try:
+        frame = scene.frame(w, h, **kw)
+        gpu_fb, st = ctx.render(frame)
+        cpu_fb, cst = _oracle().render(scene.desc, frame, os_threads=2)
+        return gpu_fb, cpu_fb, st, cst
+    finally:
+        ctx.close()
+
+
+def test_unusual_scenes(tmp_path):
+    """One-triangle tree (the root is a leaf), no lights at all, ambient only, more shadow-casting
+    lights than the fast path's 32 (takes the megakernel), specular -1, axis-aligned flat geometry
+    that lands box planes exactly on hit distances (exercises the uncertain-verdict paths)."""
+    tri = lambda z, c, s: ([-1.5, -1, z], [1.5, -1, z], [0, 1.5, z], c, s)
+    ambient = {"type": "ambient", "intensity": 0.3}
+    point = lambda x: {"type": "point", "intensity": 0.02, "position": [x, 2, -4]}
+    cases = {
+        "one_triangle": ([tri(2, (255, 0, 0), 50)], [ambient, point(1)]),
+        "no_lights": ([tri(2, (0, 255, 0), 50), tri(3, (0, 0, 255), 10)], []),
+        "ambient_only": ([tri(2, (10, 200, 90), -1), tri(4, (200, 10, 90), 5)], [ambient]),
+        "forty_lights": ([tri(2, (250, 250, 250), 20), tri(1, (40, 90, 250), -1), ([-4, -1.2, 0], [4, -1.2, 0], [0, -1.2, 9], (200, 200, 60), 100)],
+                         [ambient] + [point(-4 + 0.2 * i) for i in range(40)]),
+        "flat_axis_aligned": ([([-2, -1, 1], [2, -1, 1], [2, -1, 5], (255, 255, 255), 100),
+                               ([-2, -1, 1], [2, -1, 5], [-2, -1, 5], (255, 255, 255), 100),
+                               ([-1, -1, 3], [1, -1, 3], [0, 1, 3], (255, 80, 80), 10),
+                               ([-2, -1, 5], [2, -1, 5], [2, 2, 5], (80, 80, 255), 10),
+                               ([-2, -1, 5], [2, 2, 5], [-2, 2, 5], (80, 80, 255), 10)],
+                              [ambient, {"type": "point", "intensity": 0.6, "position": [0, 3, 3]},
+                               {"type": "directional", "intensity": 0.2, "direction": [0, 1, 0]}]),
+    }
+    for name, (tris, lights) in cases.items():
+        path = _write_scene(tmp_path, name + ".json", tris, lights)
+        for ss in (False, True):
+            gpu_fb, cpu_fb, st, cst = _render_both(path, 200, 160, threads=4, supersampling=ss, rng_seed=1)
+            _compare(gpu_fb, cpu_fb, "%s ss=%d" % (name, ss))
+            assert ((gpu_fb == 0) == (cpu_fb == 0)).all()
+            assert (gpu_fb != 0x333333).any() or name == "never"
+
+
+def test_empty_and_invalid_uploads():
+    ctx = ca.GpuContext(0)
+    try:
+        d = ca.SceneDesc()
+        with pytest.raises(RuntimeError, match="empty scene"):
+            ctx.upload(d)
+        scene = ca.HostScene(vertices=np.array([[0, 0, 2, 1, 0, 2, 0, 1, 2.0]]))
+        with pytest.raises(RuntimeError, match="no scene"):
+            ctx.render(scene.frame(64, 64, threads=1, supersampling=False))
+        ctx.upload(scene.desc)
+        bad = scene.frame(64, 64, threads=1, supersampling=False)
+        bad.num_threads = 0
+        with pytest.raises(RuntimeError, match="num_threads"):
+            ctx.render(bad)
+        bad = scene.frame(64, 64, threads=1, supersampling=False)
+        bad.max_depth = 11
+        with pytest.raises(RuntimeError, match="max_depth"):
+            ctx.render(bad)
+        # corrupt tree: child link out of range is rejected on the host, never reaches the device
+        nodes = (ca.Node * 1)()
+        nodes[0].count = 0
+        nodes[0].left = 7
+        d = scene.desc
+        broken = ca.SceneDesc(1, 1, 0, 0, d.vertices, d.materials, nodes, d.indexes, d.lights)
+        with pytest.raises(RuntimeError, match="child link"):
+            ctx.upload(broken)
+    finally:
+        ctx.close()
+
+
+def test_single_leaf_tree_on_every_path(monkeypatch):
+    """A scene whose BVH is one leaf: the root reference is a leaf reference.  Exercised on the
+    wavefront pipeline, the megakernel and the ray-list hook."""
+    verts = np.array([[-1.5, -1, 2, 1.5, -1, 2, 0, 1.5, 2.0], [-1.5, -1, 3, 1.5, -1, 3, 0, 1.5, 3.0]])
+    scene = ca.HostScene(vertices=verts)
+    assert scene.desc.n_nodes == 1
+    frame = scene.frame(128, 96, threads=2, supersampling=False)
+    frame.cam_pos = (C.c_double * 3)(0, 0, -3)
+    want, _ = _oracle().render(scene.desc, frame, os_threads=1)
+    for force in ("0", "1"):
+        monkeypatch.setenv("CTGPU_FORCE_MEGAKERNEL", force)
+        ctx = ca.GpuContext(0)
+        ctx.upload(scene.desc)
+        try:
+            got, _ = ctx.render(frame)
+            assert (got == want).all()
+            rays = np.zeros(1000, dtype=ca.bindings.RAY_DTYPE)
+            rng = np.random.default_rng(3)
+            rays["origin"] = [0, 0, -3]
+            rays["direction"] = np.c_[rng.normal(size=(1000, 2)) * 0.4, np.ones(1000)]
+            rays["t"] = np.float32(1e30)
+            hits, ref = ctx.trace_rays(rays), _oracle().trace_rays(scene.desc, rays)
+            assert (hits["triangle"] == ref["triangle"]).all() and (hits["found"] == ref["found"]).all()
+            assert (hits["t"].view(np.uint32) == ref["t"].view(np.uint32)).all() and ref["found"].sum() > 100
+        finally:
+            ctx.close()
+    monkeypatch.delenv("CTGPU_FORCE_MEGAKERNEL")
