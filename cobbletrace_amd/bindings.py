@@ -94,6 +94,7 @@ _GPU_SYMBOLS = {
     "ctgpu_destroy": (None, [C.c_void_p]),
     "ctgpu_upload_scene": (C.c_int, [C.c_void_p, C.POINTER(SceneDesc)]),
     "ctgpu_render": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.c_void_p, C.POINTER(Stats)]),
+    "ctgpu_render_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(FrameDesc), C.c_void_p, C.POINTER(Stats)]),
     "ctgpu_partition_pixels": (C.c_int, [C.POINTER(FrameDesc), C.POINTER(Partition), C.POINTER(C.c_uint64)]),
     "ctgpu_render_partition": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.POINTER(Partition), C.c_void_p, C.c_void_p]),
     "ctgpu_assemble": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.POINTER(Partition), C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -119,7 +120,7 @@ _HOST_SYMBOLS = {
     "cth_node_hash": (C.c_uint64, [C.c_void_p]),
     "cth_index_hash": (C.c_uint64, [C.c_void_p]),
     "cth_fnv1a64": (C.c_uint64, [C.c_void_p, C.c_uint64]),
-    "cth_raythread_options": (None, [C.c_int, C.c_uint64, C.c_int]),
+    "cth_raythread_options": (None, [C.c_int, C.c_uint64, C.c_int, C.c_int]),
     "cth_raythread_reset": (None, []),
     "cth_raythread_frames": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_char_p]),
     "cth_last_frame_stats": (None, [C.POINTER(Stats)]),
@@ -273,6 +274,17 @@ class GpuContext:
             fb = np.zeros((frame.height, frame.width), dtype=np.uint32)
         st = Stats()
         self._check(self.lib.ctgpu_render(self.handle, C.byref(frame), fb.ctypes.data, C.byref(st)))
+        return fb, st
+
+    @staticmethod
+    def render_multi(contexts, frame, fb=None):
+        """One frame split over several contexts (one per GPU) -> (uint32 [H, W], Stats)."""
+        if fb is None:
+            fb = np.zeros((frame.height, frame.width), dtype=np.uint32)
+        handles = (C.c_void_p * len(contexts))(*[c.handle for c in contexts])
+        st = Stats()
+        contexts[0]._check(contexts[0].lib.ctgpu_render_multi(handles, len(contexts), C.byref(frame), fb.ctypes.data,
+                                                              C.byref(st)))
         return fb, st
 
     def count_work(self, frame):

@@ -72,6 +72,7 @@ struct ctgpu_ctx {
 
     DeviceArray<uint32_t> tiles;       // compact tile buffer of a whole-frame render
     DeviceArray<uint32_t> fb;          // device framebuffer of ctgpu_render
+    DeviceArray<uint32_t> gathered;    // ctgpu_render_multi: every device's tile buffer, back to back
     DeviceArray<unsigned long long> counters;   // 16 words
     DeviceArray<uint32_t> overflow;    // 1 word
     DeviceArray<int32_t> rand_table;   // LIBC jitter stream
@@ -186,7 +187,7 @@ extern "C" void ctgpu_destroy(ctgpu_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     ctx->nodes.release(); ctx->tris.release(); ctx->materials.release(); ctx->lights.release();
-    ctx->tiles.release(); ctx->fb.release(); ctx->counters.release(); ctx->overflow.release();
+    ctx->tiles.release(); ctx->fb.release(); ctx->gathered.release(); ctx->counters.release(); ctx->overflow.release();
     ctx->rand_table.release(); ctx->row_ordinal.release();
     ctx->coords.release(); ctx->hits.release(); ctx->shadow.release(); ctx->queue.release(); ctx->spill.release();
     ctx->shadow_lights.release();
@@ -600,6 +601,90 @@ extern "C" int ctgpu_render(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, uint3
     st.total_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
     st.pixels_written = (r1 >= r0 && c1 >= c0) ? (uint64_t)(r1 - r0 + 1) * (uint64_t)(c1 - c0 + 1) : 0;
     if (stats) *stats = st;
+    return CTGPU_OK;
+}
+
+// ------------------------------------------------------------------ whole frame on several GPUs, one process
+// The in-process counterpart of bench.py's one-process-per-GPU loop, for hosts like RayThread
+// that own all devices: every context traces its interleaved row tiles on its own device and
+// stream, the tile buffers travel to the first context's device with peer-to-peer copies over
+// xGMI (the gather), and that device assembles and hands the frame to the host.
+extern "C" int ctgpu_render_multi(ctgpu_ctx *const *ctxs, int n_ctx, const ctgpu_frame_desc *frame, uint32_t *host_fb,
+                                  ctgpu_stats *stats) {
+    if (!ctxs || n_ctx < 1 || !host_fb) return fail(CTGPU_ERR_ARG, "ctgpu_render_multi: bad argument");
+    if (n_ctx == 1) return ctgpu_render(ctxs[0], frame, host_fb, stats);
+    for (int i = 0; i < n_ctx; i++) {
+        if (!ctxs[i]) return fail(CTGPU_ERR_ARG, "ctgpu_render_multi: null context %d", i);
+        if (!ctxs[i]->has_scene) return fail(CTGPU_ERR_NO_SCENE, "context %d has no scene", i);
+    }
+    int rc = check_frame(frame); if (rc) return rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    const Geometry g = geometry(frame);
+    ctgpu_ctx *root = ctxs[0];
+    const ctgpu_partition part0 = {8, 0, n_ctx};
+    const size_t per_part = (size_t)local_rows_of(g, &part0) * g.square;
+
+    HIP_TRY(hipSetDevice(root->device));
+    HIP_TRY(root->gathered.resize(per_part * (size_t)n_ctx));
+    HIP_TRY(root->fb.resize((size_t)frame->width * frame->height));
+
+    // trace: each device on its own stream; then its tiles go to the root's gather buffer
+    for (int i = 0; i < n_ctx; i++) {
+        ctgpu_ctx *c = ctxs[i];
+        HIP_TRY(hipSetDevice(c->device));
+        const ctgpu_partition part = {8, i, n_ctx};
+        FrameParams P;
+        rc = fill_params(c, frame, &part, false, P); if (rc) return rc;
+        HIP_TRY(c->tiles.resize(per_part));
+        P.out = c->tiles.ptr;
+        if (i == 0) HIP_TRY(hipEventRecord(root->ev0, root->stream));
+        rc = launch_frame(c, frame, P, c->stream); if (rc) return rc;
+        if (i == 0) HIP_TRY(hipEventRecord(root->ev1, root->stream));
+        HIP_TRY(hipMemcpyPeerAsync(root->gathered.ptr + per_part * (size_t)i, root->device, c->tiles.ptr, c->device,
+                                   per_part * sizeof(uint32_t), c->stream));
+        if (i != 0) {
+            HIP_TRY(hipEventRecord(c->ev1, c->stream));
+            HIP_TRY(hipSetDevice(root->device));
+            HIP_TRY(hipStreamWaitEvent(root->stream, c->ev1, 0));
+        }
+    }
+
+    // assemble on the root device and copy back the rectangle the reference writes
+    HIP_TRY(hipSetDevice(root->device));
+    FrameParams P0;
+    rc = fill_params(root, frame, &part0, false, P0); if (rc) return rc;
+    launch_assemble(P0, root->gathered.ptr, root->fb.ptr, root->stream);
+    HIP_TRY(hipGetLastError());
+    const int row_hi = frame->height / 2 + g.half, row_lo = row_hi - (int)g.rendered_rows + 1;
+    const int r0 = std::max(row_lo, 0), r1 = std::min(row_hi, frame->height - 1);
+    const int c0 = std::max(frame->width / 2 - g.half, 0), c1 = std::min(frame->width / 2 + g.half - 1, frame->width - 1);
+    if (r1 >= r0 && c1 >= c0) {
+        const size_t off = (size_t)r0 * frame->width + c0;
+        HIP_TRY(hipMemcpy2DAsync(host_fb + off, (size_t)frame->width * 4, root->fb.ptr + off, (size_t)frame->width * 4,
+                                 (size_t)(c1 - c0 + 1) * 4, (size_t)(r1 - r0 + 1), hipMemcpyDeviceToHost, root->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(root->stream));
+    const auto t1 = std::chrono::steady_clock::now();
+
+    ctgpu_stats total;
+    std::memset(&total, 0, sizeof total);
+    for (int i = 0; i < n_ctx; i++) {
+        ctgpu_ctx *c = ctxs[i];
+        HIP_TRY(hipSetDevice(c->device));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        ctgpu_stats st;
+        std::memset(&st, 0, sizeof st);
+        rc = read_counters(c, &st); if (rc) return rc;
+        rc = check_overflow(c); if (rc) return rc;
+        total.rays_primary += st.rays_primary; total.rays_shadow += st.rays_shadow; total.rays_reflect += st.rays_reflect;
+    }
+    HIP_TRY(hipSetDevice(root->device));
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, root->ev0, root->ev1));
+    total.kernel_ms = ms;                       // the root device's share of the tracing
+    total.total_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    total.pixels_written = (r1 >= r0 && c1 >= c0) ? (uint64_t)(r1 - r0 + 1) * (uint64_t)(c1 - c0 + 1) : 0;
+    if (stats) *stats = total;
     return CTGPU_OK;
 }
 

@@ -124,8 +124,8 @@ uint64_t cth_index_hash(void *p) {
 }
 
 // ---- RayThread driven from the harness: the caller's buffer becomes env->bitmap->memory
-void cth_raythread_options(int rng_mode, uint64_t seed, int device) {
-    const ct_raythread_options o{rng_mode, seed, device};
+void cth_raythread_options(int rng_mode, uint64_t seed, int device, int n_devices) {
+    const ct_raythread_options o{rng_mode, seed, device, n_devices};
     RayThreadSetOptions(&o);
 }
 

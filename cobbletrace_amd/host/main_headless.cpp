@@ -14,7 +14,7 @@
 static void usage() {
     std::fprintf(stderr,
                  "cobbletrace_headless scenefile [--width W] [--height H] [--out image.ppm]\n"
-                 "                     [--rng hash|libc] [--seed N] [--device N] [--keys wasd...]\n\n"
+                 "                     [--rng hash|libc] [--seed N] [--device N] [--gpus N] [--keys wasd...]\n\n"
                  "To run cobbletrace provide a scene file.  See assets/scene_file_1.json for an example.\n");
     std::exit(0);
 }
@@ -23,7 +23,7 @@ int main(int argc, char **argv) {
     if (argc < 2) usage();
     int width = 640, height = 640;
     std::string out = "cobbletrace.ppm", keys;
-    ct_raythread_options opt{CTGPU_RNG_HASH, 0, 0};
+    ct_raythread_options opt{CTGPU_RNG_HASH, 0, 0, 1};
     for (int i = 2; i < argc; i++) {
         const std::string a = argv[i];
         auto need = [&](const char *name) -> const char * {
@@ -36,6 +36,7 @@ int main(int argc, char **argv) {
         else if (a == "--rng") opt.rng_mode = std::strcmp(need("--rng"), "libc") == 0 ? CTGPU_RNG_LIBC : CTGPU_RNG_HASH;
         else if (a == "--seed") opt.rng_seed = std::strtoull(need("--seed"), nullptr, 10);
         else if (a == "--device") opt.device = std::atoi(need("--device"));
+        else if (a == "--gpus") opt.n_devices = std::atoi(need("--gpus"));
         else if (a == "--keys") keys = need("--keys");
         else usage();
     }

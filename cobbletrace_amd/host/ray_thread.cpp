@@ -18,7 +18,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <string>
+#include <vector>
 
 namespace {
 
@@ -31,6 +33,8 @@ struct GpuApi {
     decltype(&ctgpu_destroy) destroy = nullptr;
     decltype(&ctgpu_upload_scene) upload_scene = nullptr;
     decltype(&ctgpu_render) render = nullptr;
+    decltype(&ctgpu_render_multi) render_multi = nullptr;
+    decltype(&ctgpu_device_count) device_count = nullptr;
 };
 
 [[noreturn]] void die(const char *what, const char *detail) {
@@ -63,6 +67,8 @@ GpuApi &gpu() {
     RESOLVE(destroy, "ctgpu_destroy");
     RESOLVE(upload_scene, "ctgpu_upload_scene");
     RESOLVE(render, "ctgpu_render");
+    RESOLVE(render_multi, "ctgpu_render_multi");
+    RESOLVE(device_count, "ctgpu_device_count");
 #undef RESOLVE
     if (api.abi_version() != CTGPU_ABI_VERSION) die("libctgpu.so ABI mismatch", path.c_str());
     return api;
@@ -73,9 +79,9 @@ struct BossState {
     bool changes_pending = true;          // the first call renders (raythread.cpp:547)
     float yaw = 0, pitch = 0, roll = 0;
     ct::PackedScene *packed = nullptr;
-    ctgpu_ctx *ctx = nullptr;
+    std::vector<ctgpu_ctx *> ctxs;        // one per GPU the frame is split over
     uint64_t rand_consumed = 0;           // LIBC jitter mode: rand() calls used by earlier frames
-    ct_raythread_options options{CTGPU_RNG_HASH, 0, 0};
+    ct_raythread_options options{CTGPU_RNG_HASH, 0, 0, 1};
     ctgpu_stats last_stats{};
 };
 
@@ -137,7 +143,7 @@ void RayThreadSetOptions(const ct_raythread_options *opt) {
 
 void RayThreadReset(void) {
     BossState &b = boss();
-    if (b.ctx) gpu().destroy(b.ctx);
+    for (ctgpu_ctx *c : b.ctxs) gpu().destroy(c);
     delete b.packed;
     const ct_raythread_options keep = b.options;
     b = BossState();
@@ -153,9 +159,19 @@ bool RayThread(environment_t *env, scene_t *scene) {
     if (!b.initialised) {
         b.packed = new ct::PackedScene();
         b.packed->build_from(scene);
-        if (api.create(b.options.device, &b.ctx) != CTGPU_OK) die("ctgpu_create", api.last_error());
+        // one context per GPU, the scene replicated on each (it is small against 288 GB): the GPUs
+        // take the place of the reference's worker threads (raythread.cpp:596-618)
+        int visible = 0;
+        if (api.device_count(&visible) != CTGPU_OK || visible < 1) die("ctgpu_device_count", api.last_error());
+        int wanted = b.options.n_devices > 1 ? b.options.n_devices : 1;
+        if (const char *env = std::getenv("CT_RAYTHREAD_DEVICES")) wanted = std::max(1, std::atoi(env));
         const ctgpu_scene_desc desc = b.packed->desc();
-        if (api.upload_scene(b.ctx, &desc) != CTGPU_OK) die("ctgpu_upload_scene", api.last_error());
+        for (int i = 0; i < wanted; i++) {
+            ctgpu_ctx *ctx = nullptr;
+            if (api.create((b.options.device + i) % visible, &ctx) != CTGPU_OK) die("ctgpu_create", api.last_error());
+            if (api.upload_scene(ctx, &desc) != CTGPU_OK) die("ctgpu_upload_scene", api.last_error());
+            b.ctxs.push_back(ctx);
+        }
         b.initialised = true;
     }
 
@@ -182,8 +198,8 @@ bool RayThread(environment_t *env, scene_t *scene) {
     frame.max_depth = 10;                 // TraceRay(..., 10, ...) raythread.cpp:474,508
 
     ctgpu_stats stats;
-    if (api.render(b.ctx, &frame, (uint32_t *)env->bitmap->memory, &stats) != CTGPU_OK)
-        die("ctgpu_render", api.last_error());
+    if (api.render_multi(b.ctxs.data(), (int)b.ctxs.size(), &frame, (uint32_t *)env->bitmap->memory, &stats) != CTGPU_OK)
+        die("ctgpu_render_multi", api.last_error());
     b.last_stats = stats;
     if (scene->settings.supersampling) {
         // one worker's rand() calls per frame: every column of the square x every traced row

@@ -153,7 +153,10 @@ bool RayThread(environment_t *env, scene_t *scene);
 struct ct_raythread_options {
     int      rng_mode;     /* CTGPU_RNG_* from ctgpu.h; default CTGPU_RNG_HASH     */
     uint64_t rng_seed;     /* hash-mode seed, default 0                             */
-    int      device;       /* HIP device ordinal, default 0                         */
+    int      device;       /* first HIP device ordinal, default 0                   */
+    int      n_devices;    /* GPUs to split every frame over (row tiles, peer-to-peer gather);
+                              0 or 1 = one GPU.  Ordinals wrap around the visible devices, so a
+                              larger count than GPUs present still works (contexts share a GPU). */
 };
 void RayThreadSetOptions(const ct_raythread_options *opt);
 /* Releases device buffers and the function-local state so that a new scene can

@@ -14,6 +14,8 @@
  *                               IntersectBVHClosest / ComputeLighting -> CanvasPutPixel
  *                               raythread.cpp:437-543, 353-386, 197-228, 275-350, 176-184;
  *                               bvh.cpp:147-222; color.h:18-126; draw2d.h:8-20
+ *   ctgpu_render_multi          the same with the row bands of HandleUpdates (raythread.cpp:574-588)
+ *                               dealt to several GPUs of one process
  *   ctgpu_render_partition /    the row-band split of HandleUpdates (raythread.cpp:574-588)
  *   ctgpu_assemble              re-cut into interleaved row tiles for N GPUs, and the merge of
  *                               the per-GPU tiles into the caller's framebuffer
@@ -142,6 +144,14 @@ int  ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *scene);
 /* One whole frame on this context's GPU into a caller-owned host framebuffer
  * (width*height uint32).  Synchronous.  stats may be NULL. */
 int  ctgpu_render(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, uint32_t *host_fb, ctgpu_stats *stats);
+
+/* The same frame split over several contexts of THIS process (one per GPU; contexts on the same
+ * device are allowed and behave like separate GPUs): interleaved row tiles, peer-to-peer gather to
+ * the first context's device, assembly there.  All contexts must hold the same scene.  This is
+ * what RayThread uses when it is given more than one device (raythread.cpp:574-618 had one
+ * worker thread per band). */
+int  ctgpu_render_multi(ctgpu_ctx *const *ctxs, int n_ctx, const ctgpu_frame_desc *frame, uint32_t *host_fb,
+                        ctgpu_stats *stats);
 
 /* Multi-GPU building blocks (device pointers; `stream` is a hipStream_t or NULL).
  * ctgpu_partition_pixels: number of uint32 a partition's compact tile buffer holds

@@ -23,7 +23,7 @@ def test_raythread_renders_and_tracks_the_camera(assets):
     from oracle import oracle
     host = ca.host_library()
     host.cth_raythread_reset()
-    host.cth_raythread_options(ca.RNG_HASH, 11, 0)
+    host.cth_raythread_options(ca.RNG_HASH, 11, 0, 1)
     scene = ca.HostScene(os.path.join(assets, "scene_import.json"))
     scene.set_settings(threads=8, supersampling=0)
     w, h = 320, 240
@@ -64,7 +64,7 @@ def test_raythread_supersampled_scene_defaults(assets):
     from oracle import oracle
     host = ca.host_library()
     host.cth_raythread_reset()
-    host.cth_raythread_options(ca.RNG_HASH, 0, 0)
+    host.cth_raythread_options(ca.RNG_HASH, 0, 0, 1)
     scene = ca.HostScene(os.path.join(assets, "scene_import_bunny.json"))       # T=32, supersampling on
     w, h = 480, 256
     fb, _ = _frames(scene, w, h)
@@ -95,3 +95,40 @@ def test_headless_application(assets, tmp_path):
     assert channel_diff(fb, want).max() <= 1
     # no scene file -> usage, exit 0 like Help() (cobbletrace.cpp:20-24)
     assert subprocess.run([exe], capture_output=True).returncode == 0
+
+
+def test_raythread_over_several_devices(assets):
+    """RayThread splitting every frame over 3 contexts (device ordinals wrap around the GPUs present,
+    so on a one-GPU box they share it): interleaved row tiles, peer-to-peer gather, assembly -- the
+    image is bit-identical to the one-context frame."""
+    host = ca.host_library()
+    images = []
+    for n in (1, 3):
+        host.cth_raythread_reset()
+        host.cth_raythread_options(ca.RNG_HASH, 2, 0, n)
+        scene = ca.HostScene(os.path.join(assets, "scene_import_bunny.json"))
+        fb, _ = _frames(scene, 640, 400, b"w")
+        images.append(fb)
+    host.cth_raythread_reset()
+    host.cth_raythread_options(ca.RNG_HASH, 0, 0, 1)
+    assert (images[0] == images[1]).all() and (images[0] != 0).any()
+
+
+def test_render_multi_matches_single(scenes, gpu_ctx):
+    scene = scenes("import")
+    single = gpu_ctx("import")
+    ctxs = []
+    try:
+        for _ in range(4):
+            c = ca.GpuContext(0)
+            c.upload(scene.desc)
+            ctxs.append(c)
+        for ss, sub in ((False, False), (True, False), (False, True)):
+            frame = scene.frame(500, 300, threads=6, supersampling=ss, subsampling=sub, rng_seed=8)
+            want, sw = single.render(frame)
+            got, sg = ca.GpuContext.render_multi(ctxs, frame)
+            assert (got == want).all()
+            assert sg.rays == sw.rays
+    finally:
+        for c in ctxs:
+            c.close()
