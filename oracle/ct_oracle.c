@@ -608,3 +608,116 @@ int cto_bvhtest_render(const ctgpu_scene_desc *scene, uint32_t *fb, uint64_t *hi
     if (hit_pixels) *hit_pixels = hits;
     return CTGPU_OK;
 }
+
+/* ------------------------------------------------------------------ packet-coherence experiment
+ * How many lanes of a 64-ray group want each node the group visits, if the group walks the tree
+ * TOGETHER in the reference's DFS order (every ray keeps exactly its own visits; the group visits
+ * the union)?  Inputs for a design decision, not part of the parity checks. */
+typedef struct { ray r; float tclosest; uint32_t closest; int active; int any_hit; } packet_lane;
+
+static void packet_walk(const ctgpu_scene_desc *sc, packet_lane *lanes, const unsigned char *in_mask, int n,
+                        uint32_t node_id, uint64_t *stats) {
+    const ctgpu_node *node = &sc->nodes[node_id];
+    unsigned char mask[64];
+    int any = 0, wanted = 0;
+    for (int i = 0; i < n; i++) {
+        mask[i] = 0;
+        if (!in_mask[i] || !lanes[i].active) continue;
+        wanted++;
+        if (slab_test(&lanes[i].r, node->bmin, node->bmax)) { mask[i] = 1; any = 1; }
+    }
+    if (wanted == 0) return;
+    stats[0] += 1;                 /* group visits  */
+    stats[1] += (uint64_t)wanted;  /* lane visits   */
+    if (!any) return;
+    if (node->count > 0) {
+        for (uint32_t k = 0; k < node->count; k++) {
+            const uint32_t tri = sc->indexes[node->first + k];
+            int lanes_here = 0;
+            for (int i = 0; i < n; i++) {
+                if (!mask[i] || !lanes[i].active) continue;
+                lanes_here++;
+                const int hit = triangle_test(&lanes[i].r, sc->vertices + (size_t)tri * 9);
+                if (hit && lanes[i].r.t != kNoHit && lanes[i].r.t < lanes[i].tclosest) {
+                    lanes[i].closest = tri;
+                    lanes[i].tclosest = lanes[i].r.t;
+                }
+                if (lanes[i].any_hit && lanes[i].r.t != kNoHit) lanes[i].active = 0;
+            }
+            if (lanes_here) { stats[2] += 1; stats[3] += (uint64_t)lanes_here; }
+        }
+        return;
+    }
+    packet_walk(sc, lanes, mask, n, node->left, stats);
+    packet_walk(sc, lanes, mask, n, node->left + 1, stats);
+}
+
+/* stats[0..3]: primary group visits, lane visits, group triangle tests, lane triangle tests;
+ * stats[4..7]: the same for shadow rays (any-hit), grouped like their primary samples. */
+int cto_packet_stats(const ctgpu_scene_desc *sc, const ctgpu_frame_desc *f, int group_w, int group_h,
+                     uint64_t stats[8]) {
+    memset(stats, 0, 8 * sizeof(uint64_t));
+    const geometry g = frame_geometry(f);
+    const int rows = g.bands * g.rows_per_band;
+    const int ss = (f->flags & CTGPU_F_SUPERSAMPLE) != 0;
+    const int per_pixel = ss ? 16 : 1;
+    frame_job job;
+    memset(&job, 0, sizeof job);
+    job.scene = sc; job.frame = f; job.g = g;
+    const v3 eye = v3_load(f->cam_pos);
+    unsigned char all[64];
+    memset(all, 1, sizeof all);
+    for (int y0 = -g.half + 1; y0 < -g.half + rows; y0 += group_h) {
+        for (int x0 = -g.half; x0 < g.half; x0 += group_w) {
+            packet_lane lanes[64];
+            int n = 0;
+            for (int yy = 0; yy < group_h; yy++) for (int xx = 0; xx < group_w; xx++) {
+                const int x = x0 + xx, y = y0 + yy;
+                if (x >= g.half || y >= -g.half + rows) continue;
+                float sx = (float)x;
+                for (int xs = 0; xs < (ss ? 4 : 1); xs++) {
+                    float sy = (float)y;
+                    for (int ys = 0; ys < (ss ? 4 : 1); ys++) {
+                        float px = (float)x, py = (float)y;
+                        float rx = 0, ry = 0;
+                        if (ss) {
+                            const float jitter = 0.25f / 8.0f;
+                            rx = (float)jitter_int(&job, x, y, xs * 4 + ys, 0) / 2147483648.0f;
+                            ry = (float)jitter_int(&job, x, y, xs * 4 + ys, 1) / 2147483648.0f;
+                            rx = (rx * (2.0f * jitter)) - jitter; ry = (ry * (2.0f * jitter)) - jitter;
+                            sx += rx; sy += ry; px = sx; py = sy;
+                        }
+                        double dir[3];
+                        cto_primary_direction(f->height, px, py, f->cam_rot, dir);
+                        if (n < 64) {
+                            lanes[n].r.origin = eye; lanes[n].r.direction = v3_load(dir); lanes[n].r.t = kNoHit;
+                            lanes[n].tclosest = kFarAway; lanes[n].closest = 0; lanes[n].active = 1; lanes[n].any_hit = 0;
+                            n++;
+                        }
+                        if (ss) { sy -= ry; sy += 0.25f; sx -= rx; }
+                    }
+                    if (ss) sx += 0.25f;
+                }
+            }
+            (void)per_pixel;
+            packet_walk(sc, lanes, all, n, 0, stats);
+            /* shadow rays of the hits, one group per non-ambient light */
+            for (uint32_t li = 0; li < sc->n_lights; li++) {
+                const ctgpu_light *light = &sc->lights[li];
+                if (light->type == CTGPU_LIGHT_AMBIENT) continue;
+                packet_lane sh[64];
+                int m = 0;
+                for (int i = 0; i < n; i++) {
+                    if (lanes[i].r.t == kNoHit) continue;
+                    const v3 p = v3_add(lanes[i].r.origin, v3_scale((double)lanes[i].tclosest, lanes[i].r.direction));
+                    sh[m].r.origin = p;
+                    sh[m].r.direction = light->type == CTGPU_LIGHT_POINT ? v3_sub(v3_load(light->position), p) : v3_load(light->direction);
+                    sh[m].r.t = kNoHit; sh[m].tclosest = kFarAway; sh[m].closest = 0; sh[m].active = 1; sh[m].any_hit = 1;
+                    m++;
+                }
+                if (m) packet_walk(sc, sh, all, m, 0, stats + 4);
+            }
+        }
+    }
+    return CTGPU_OK;
+}

@@ -79,6 +79,10 @@ uint64_t cto_fnv1a64(const void *data, uint64_t n);
 void cto_bvhtest_triangles(double verts[256 * 9]);
 int  cto_bvhtest_render(const ctgpu_scene_desc *scene, uint32_t *fb_640x640, uint64_t *hit_pixels);
 
+/* Design experiment: lane utilisation if 64-ray groups walked the tree together (see ct_oracle.c). */
+int cto_packet_stats(const ctgpu_scene_desc *scene, const ctgpu_frame_desc *frame, int group_w, int group_h,
+                     uint64_t stats[8]);
+
 #ifdef __cplusplus
 }
 #endif
