@@ -62,11 +62,13 @@ struct PipelineParams {
     uint32_t n_shadow_lights;
     uint32_t lds_depth, spill_depth, walk_blocks;
     uint32_t chunk;              // ray ids a wave reserves per queue atomic (multiple of 64)
+    uint32_t packet;             // 1: supersampled frames use ct_walk_packet (shared walk per wave)
     int32_t  thresh_r, thresh_a, thresh_b;
 };
 
 uint64_t pipeline_sample_count(const FrameParams &P, bool ss);
 int  pipeline_walk_occupancy(size_t lds_bytes);
+int  pipeline_packet_occupancy(uint32_t depth);
 void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hipStream_t stream);
 
 void launch_trace_tiles(const FrameParams &P, uint32_t n_tiles, bool ss, bool reflect, bool count, hipStream_t stream);

@@ -567,6 +567,235 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk(const FrameParam
 }
 
 // ------------------------------------------------------------------------------------
+// ct_walk_packet: the 64 rays of a wave walk the tree TOGETHER (supersampled frames).
+// The reference visits nodes in one fixed order for every ray (left subtree, then right), so a
+// group of rays can share one walk over the UNION of their nodes: a lane takes part in a node
+// exactly when the reference would have entered it for that lane's ray (its own box verdicts, its
+// own ray.t), and sits masked out otherwise.  For the 4 pixels x 16 samples a wave holds the rays
+// are nearly parallel, so the union is barely larger than one ray's set -- and everything that was
+// per-lane becomes per-wave: the node is fetched once with scalar loads (no 7 KB of L1 traffic per
+// step), the stack holds one {node, lane mask} entry per level instead of 64, and pushing / popping
+// is scalar work.  Per lane only the deferred tmin of a pushed right child is kept (LDS).
+// Semantics, verdict margins and the exact fallback are those of ct_walk.
+// ------------------------------------------------------------------------------------
+struct PacketStack {
+    LdsWord *ref;          // [depth]      child reference
+    LdsWord *parent;       // [depth]      WideNode holding that child's box (exact re-test at pop)
+    LdsWord *mask_lo;      // [depth]      lanes that passed the child's box when it was pushed
+    LdsWord *mask_hi;      // [depth]
+    float __attribute__((address_space(3))) *tmin;   // [depth][64] approximate tmin per lane
+    static __host__ __device__ size_t bytes(uint32_t depth) { return (size_t)depth * (16u + 256u); }
+};
+
+template <int KIND>
+__global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk_packet(const FrameParams P, const PipelineParams W) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const uint32_t depth = W.lds_depth + W.spill_depth;         // the whole tree depth lives in LDS here
+    PacketStack st;
+    st.ref = (LdsWord *)lds_raw;
+    st.parent = st.ref + depth;
+    st.mask_lo = st.parent + depth;
+    st.mask_hi = st.mask_lo + depth;
+    st.tmin = (float __attribute__((address_space(3))) *)(st.mask_hi + depth);
+
+    const uint32_t lane = threadIdx.x;
+    const unsigned long long lane_bit = 1ull << lane, lanes_below = lane_bit - 1ull;
+    const uint64_t n_samples = W.n_samples;
+    const uint32_t n_shards = (KIND == 0) ? kShards : kShards * W.n_shadow_lights;
+    unsigned long long *heads = W.queue + (size_t)(KIND == 0 ? 0u : kShards) * 16u;
+    const uint64_t shard_span = ((n_samples + kShards - 1) / kShards + W.chunk - 1) / W.chunk * W.chunk;
+    uint32_t shard = blockIdx.x % n_shards, shards_done = 0;
+    uint64_t light_base = 0;
+    Light shadow_light = Light{};
+    const d3 eye = make_d3(P.cam[0], P.cam[1], P.cam[2]);
+
+    d3 o = eye, d = make_d3(0, 0, 1), inv = make_d3(0, 0, 1);
+    float t = kNoHit;
+    uint32_t slot = kNoNode;
+    bool fast = false, has_ray = false;
+    uint64_t ray_id = 0;
+    uint64_t chunk_next = 0, chunk_end = 0;
+    bool wave_drained = false;
+    uint32_t n_traced = 0;
+
+    for (;;) {
+        // ---------------- fetch a packet: every lane gets a ray (or stays empty at the end)
+        has_ray = false;
+        for (;;) {
+            const unsigned long long m_i = __ballot(!has_ray);
+            if (m_i == 0ull || wave_drained) break;
+            if (chunk_next >= chunk_end) {
+                unsigned long long offset = 0;
+                if (lane == 0) offset = atomicAdd(heads + (size_t)shard * 16u, (unsigned long long)W.chunk);
+                offset = __shfl(offset, 0);
+                const uint32_t light = shard / kShards, part = shard % kShards;
+                const uint64_t lo = (uint64_t)part * shard_span + offset;
+                if (offset >= shard_span || lo >= n_samples) {
+                    shards_done += 1;
+                    shard = (shard + 1u) % n_shards;
+                    if (shards_done >= n_shards) wave_drained = true;
+                    continue;
+                }
+                uint64_t hi = lo + W.chunk;
+                if (hi > ((uint64_t)part + 1u) * shard_span) hi = ((uint64_t)part + 1u) * shard_span;
+                if (hi > n_samples) hi = n_samples;
+                light_base = (uint64_t)light * n_samples;
+                chunk_next = light_base + lo;
+                chunk_end = light_base + hi;
+                if (KIND == 1) shadow_light = P.lights[W.shadow_lights[light]];
+                // a packet never mixes lights (its rays should point the same way): start a new one
+                if (KIND == 1 && m_i != ~0ull) break;
+            }
+            const uint64_t avail = chunk_end - chunk_next;
+            const uint32_t rank = (uint32_t)__popcll(m_i & lanes_below);
+            const bool take = !has_ray && rank < avail;
+            const uint64_t id = chunk_next + rank;
+            const uint64_t wanted = (uint64_t)__popcll(m_i);
+            chunk_next += (wanted < avail) ? wanted : avail;
+            if (take) {
+                const uint64_t sample = id - light_base;
+                float px, py;
+                bool live = sample_position<true>(P, W, sample, px, py);
+                if (KIND == 0) {
+                    if (live) { o = eye; d = primary_direction(P, px, py); }
+                    else W.hits[id] = make_uint2(__float_as_uint(kNoHit), kInvalidSample);
+                } else if (live) {
+                    const uint2 h = W.hits[sample];
+                    live = __uint_as_float(h.x) != kNoHit;
+                    if (live) {
+                        const float tclosest = (h.y != kNoNode) ? __uint_as_float(h.x) : kFarAway;
+                        o = eye + scale((double)tclosest, primary_direction(P, px, py));
+                        d = (shadow_light.type == CTGPU_LIGHT_POINT) ? load_d3(shadow_light.position) - o
+                                                                     : load_d3(shadow_light.direction);
+                    }
+                }
+                if (live) {
+                    t = kNoHit;
+                    slot = kNoNode;
+                    fast = direction_allows_fast_slab(d);
+                    inv = make_d3(quick_reciprocal(d.x), quick_reciprocal(d.y), quick_reciprocal(d.z));
+                    ray_id = id;
+                    has_ray = true;
+                    n_traced += 1;
+                }
+            }
+            if (KIND == 0) break;          // primary packets: one aligned run of 64 samples, no top-up
+        }
+        if (__ballot(has_ray) == 0ull) {
+            if (wave_drained) break;
+            continue;
+        }
+
+        // ---------------- root box (bvh.cpp:205 at rootNodeIdx)
+        bool active = has_ray;             // any-hit lanes drop out once ray.t has moved
+        uint32_t cur;
+        unsigned long long mask;
+        {
+            bool pass = false;
+            if (has_ray) {
+                float tmin, tmax;
+                slab_approx(o, inv, P.root_min, P.root_max, tmin, tmax);
+                if (!(box_verdict_positive_t(tmin, tmax, t, pass) & fast)) {
+                    slab(o, d, P.root_min, P.root_max, tmin, tmax);
+                    pass = tmax >= tmin && tmin < t && tmax > 0;
+                }
+            }
+            mask = __ballot(pass);
+            cur = P.root_ref;
+        }
+        uint32_t sp = 0;
+
+        // ---------------- the shared walk
+        while (mask != 0ull) {
+            const bool mine = (mask & lane_bit) != 0ull && active;
+            if (cur & kLeafBit) {
+                // leaf: every triangle in index order, each lane keeps its own closest hit
+                const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cur & ~kLeafBit));
+                const uint32_t count = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.tris[first].remaining);
+                for (uint32_t k = 0; k < count; k++) {
+                    const TriRecord *rec = P.tris + first + k;
+                    if (mine && active) {
+                        const d3 p1 = load_d3(rec->p1), e1 = load_d3(rec->e1), e2 = load_d3(rec->e2);
+                        const float before = t;
+                        const bool hit = triangle_test(o, d, t, p1, e1, e2);
+                        const float tclosest = (slot != kNoNode) ? before : kFarAway;      // bvh.cpp:212-215
+                        if (hit && t != kNoHit && t < tclosest) slot = first + k;
+                        if (KIND == 1 && t != kNoHit) active = false;                      // raythread.cpp:303-307
+                    }
+                }
+                mask = 0ull;               // fall through to the pop below
+            } else {
+                const uint32_t node_id = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
+                const WideNode *n = P.nodes + node_id;
+                bool lpass = false, rpass = false;
+                float rtmin = 0.0f;
+                if (mine) {
+                    float ltmin, ltmax, rtmax;
+                    slab_approx(o, inv, n->lmin, n->lmax, ltmin, ltmax);
+                    slab_approx(o, inv, n->rmin, n->rmax, rtmin, rtmax);
+                    const bool sure = box_verdict_positive_t(ltmin, ltmax, t, lpass) & box_verdict_positive_t(rtmin, rtmax, t, rpass);
+                    if (!(sure & fast)) {              // rare: the reference's divisions decide
+                        slab(o, d, n->lmin, n->lmax, ltmin, ltmax);
+                        slab(o, d, n->rmin, n->rmax, rtmin, rtmax);
+                        lpass = ltmax >= ltmin && ltmin < t && ltmax > 0;
+                        rpass = rtmax >= rtmin && rtmin < t && rtmax > 0;
+                    }
+                }
+                const unsigned long long lm = __ballot(lpass), rm = __ballot(rpass);
+                const uint32_t lref = n->lref, rref = n->rref;
+                if (lm != 0ull && rm != 0ull) {
+                    // the right child waits; each lane's `tmin < ray.t` is re-evaluated when it is popped
+                    if (sp >= depth) { atomicOr(P.overflow, 1u); break; }
+                    if (lane == 0) {
+                        st.ref[sp] = rref;
+                        st.parent[sp] = node_id;
+                        st.mask_lo[sp] = (uint32_t)rm;
+                        st.mask_hi[sp] = (uint32_t)(rm >> 32);
+                    }
+                    st.tmin[sp * kWave + lane] = rtmin;
+                    sp += 1;
+                    cur = lref; mask = lm;
+                    continue;
+                }
+                if (lm != 0ull) { cur = lref; mask = lm; continue; }
+                if (rm != 0ull) { cur = rref; mask = rm; continue; }
+                mask = 0ull;
+            }
+            // ---------------- pop: next pending right child some lane still wants
+            while (mask == 0ull && sp > 0) {
+                sp -= 1;
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const unsigned long long pushed = (unsigned long long)st.mask_lo[sp] | ((unsigned long long)st.mask_hi[sp] << 32);
+                bool keep = false;
+                if ((pushed & lane_bit) != 0ull && active) {
+                    const float tmin = st.tmin[sp * kWave + lane];
+                    if (ordinals_near(__float_as_int(tmin), __float_as_int(t), 2u)) {
+                        // too close to ray.t to trust the approximate tmin: the whole test, exactly
+                        const WideNode *pn = P.nodes + st.parent[sp];
+                        float etmin, etmax;
+                        slab(o, d, pn->rmin, pn->rmax, etmin, etmax);
+                        keep = etmax >= etmin && etmin < t && etmax > 0;
+                    } else {
+                        keep = tmin < t;
+                    }
+                }
+                mask = __ballot(keep);
+                cur = st.ref[sp];
+            }
+        }
+
+        // ---------------- retire the packet
+        if (has_ray) {
+            if (KIND == 0) W.hits[ray_id] = make_uint2(__float_as_uint(t), slot);
+            else if (t != kNoHit) W.shadow[ray_id] = 1;
+        }
+    }
+
+    for (int off = 32; off > 0; off >>= 1) n_traced += __shfl_down(n_traced, off);
+    if (lane == 0) atomicAdd(&P.counters[KIND == 0 ? 0 : 1], (unsigned long long)n_traced);
+}
+
+// ------------------------------------------------------------------------------------
 // ct_shade: lighting of every sample of a pixel in order, running blend, pixel store.
 // raythread.cpp:353-366 (TraceRay without reflection), 275-327 (ComputeLighting with the
 // shadow decisions read from the mask), 482-498 (blend), color.h.
@@ -652,7 +881,25 @@ int pipeline_walk_occupancy(size_t lds_bytes) {
     return a < b ? a : b;
 }
 
+int pipeline_packet_occupancy(uint32_t depth) {
+    int a = 0, b = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, ct_walk_packet<0>, kWave, PacketStack::bytes(depth));
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, ct_walk_packet<1>, kWave, PacketStack::bytes(depth));
+    return a < b ? a : b;
+}
+
 void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hipStream_t stream) {
+    if (W.packet && ss) {
+        const uint32_t slots = (uint32_t)(W.n_samples / 16u);
+        const uint32_t blocks = (slots + 255u) / 256u;
+        const size_t lds_p = PacketStack::bytes(W.lds_depth + W.spill_depth);
+        if (W.n_samples == 0) return;
+        hipLaunchKernelGGL(ct_sample_grid, dim3(blocks), dim3(256), 0, stream, P, W);
+        hipLaunchKernelGGL((ct_walk_packet<0>), dim3(W.walk_blocks), dim3(kWave), lds_p, stream, P, W);
+        if (W.n_shadow_lights) hipLaunchKernelGGL((ct_walk_packet<1>), dim3(W.walk_blocks), dim3(kWave), lds_p, stream, P, W);
+        hipLaunchKernelGGL((ct_shade<true>), dim3(blocks), dim3(256), 0, stream, P, W);
+        return;
+    }
     const size_t lds = (size_t)W.lds_depth * kWave * 12u;      // entries + parent words
     const uint32_t pixel_slots = (uint32_t)(ss ? W.n_samples / 16u : W.n_samples);
     const uint32_t pixel_blocks = (pixel_slots + 255u) / 256u;

@@ -92,6 +92,7 @@ struct ctgpu_ctx {
     int lds_depth = 8;                          // 6 KB of LDS per wave; deeper entries spill to HBM
     int blocks_per_cu = 0;                      // 0 = occupancy query
     int chunk = 0;                              // 0 = sized from the frame
+    bool packet_walk = true;                    // ct_walk_packet for supersampled frames (CTGPU_PACKET=0: per-lane walk)
     bool force_megakernel = false;
 
     hipStream_t stream = nullptr;
@@ -174,6 +175,7 @@ extern "C" int ctgpu_create(int device, ctgpu_ctx **out) {
     if (const char *t = std::getenv("CTGPU_LDS_DEPTH")) ctx->lds_depth = std::max(1, std::atoi(t));
     if (const char *t = std::getenv("CTGPU_BLOCKS_PER_CU")) ctx->blocks_per_cu = std::max(0, std::atoi(t));
     if (const char *t = std::getenv("CTGPU_CHUNK")) ctx->chunk = std::max(0, std::atoi(t));
+    if (const char *t = std::getenv("CTGPU_PACKET")) ctx->packet_walk = std::atoi(t) != 0;
     if (const char *t = std::getenv("CTGPU_FORCE_MEGAKERNEL")) ctx->force_megakernel = std::atoi(t) != 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->cu_count = prop.multiProcessorCount;
@@ -480,7 +482,10 @@ int launch_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, FrameParams &P, hipS
     W.lds_depth = std::min<uint32_t>((uint32_t)ctx->lds_depth, std::max<uint32_t>(ctx->tree_depth, 1));
     W.spill_depth = std::max<uint32_t>(ctx->tree_depth, 1) - W.lds_depth;
     const size_t lds_bytes = (size_t)W.lds_depth * 64 * 12;
-    int per_cu = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : pipeline_walk_occupancy(lds_bytes);
+    W.packet = (ctx->packet_walk && ss) ? 1u : 0u;
+    int per_cu = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu
+                                        : (W.packet ? pipeline_packet_occupancy(W.lds_depth + W.spill_depth)
+                                                    : pipeline_walk_occupancy(lds_bytes));
     if (per_cu < 1) per_cu = 1;
     const uint64_t waves_needed = (W.n_samples + 63) / 64;
     W.walk_blocks = (uint32_t)std::min<uint64_t>((uint64_t)per_cu * ctx->cu_count, std::max<uint64_t>(waves_needed, 1));

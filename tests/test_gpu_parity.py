@@ -367,3 +367,26 @@ def test_single_leaf_tree_on_every_path(monkeypatch):
         finally:
             ctx.close()
     monkeypatch.delenv("CTGPU_FORCE_MEGAKERNEL")
+
+
+def test_packet_walk_variant(scenes, gpu_ctx, monkeypatch):
+    """ct_walk_packet (the wave's 64 rays share one walk, default for supersampled frames) and the
+    per-lane ct_walk render the identical supersampled frame."""
+    monkeypatch.setenv("CTGPU_PACKET", "0")
+    ctxs = {}
+    try:
+        for name in ("bunny", "import"):
+            ctxs[name] = ca.GpuContext(0)
+            ctxs[name].upload(scenes(name).desc)
+        monkeypatch.delenv("CTGPU_PACKET")
+        for name, w, h, t in (("bunny", 640, 360, 32), ("import", 480, 270, 8), ("bunny", 200, 160, 1)):
+            scene = scenes(name)
+            for sub in (False, True):
+                frame = scene.frame(w, h, threads=t, supersampling=True, subsampling=sub, rng_seed=5)
+                want, sw = gpu_ctx(name).render(frame)
+                got, sg = ctxs[name].render(frame)
+                assert (got == want).all(), (name, w, h, sub)
+                assert sg.rays == sw.rays
+    finally:
+        for c in ctxs.values():
+            c.close()
