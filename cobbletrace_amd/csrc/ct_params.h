@@ -63,12 +63,13 @@ struct PipelineParams {
     uint32_t lds_depth, spill_depth, walk_blocks;
     uint32_t chunk;              // ray ids a wave reserves per queue atomic (multiple of 64)
     uint32_t packet;             // 1: supersampled frames use ct_walk_packet (shared walk per wave)
+    uint32_t packet_lds_levels;  // stack levels whose per-lane tmin lives in LDS (deeper ones in HBM)
     int32_t  thresh_r, thresh_a, thresh_b;
 };
 
 uint64_t pipeline_sample_count(const FrameParams &P, bool ss);
 int  pipeline_walk_occupancy(size_t lds_bytes);
-int  pipeline_packet_occupancy(uint32_t depth);
+int  pipeline_packet_occupancy(uint32_t depth, uint32_t lds_levels);
 void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hipStream_t stream);
 
 void launch_trace_tiles(const FrameParams &P, uint32_t n_tiles, bool ss, bool reflect, bool count, hipStream_t stream);

@@ -578,25 +578,82 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk(const FrameParam
 // is scalar work.  Per lane only the deferred tmin of a pushed right child is kept (LDS).
 // Semantics, verdict margins and the exact fallback are those of ct_walk.
 // ------------------------------------------------------------------------------------
+// One WideNode through the scalar cache into SGPRs (the address is wave-uniform).  hipcc will not
+// pick s_load here on its own -- the kernel also stores to global memory, so it cannot prove the
+// node array unclobbered -- and vector loads of a uniform address cost 26 VGPRs per lane.
+typedef int sgpr16_t __attribute__((ext_vector_type(16)));
+struct ScalarNode {
+    sgpr16_t a, b;            // bytes 0..63, 64..127 of the node
+    __device__ __forceinline__ double f64(int i) const {      // i-th double of the node (0..11)
+        const int lo = (i < 8) ? a[2 * i] : b[2 * (i - 8)];
+        const int hi = (i < 8) ? a[2 * i + 1] : b[2 * (i - 8) + 1];
+        return __hiloint2double(hi, lo);
+    }
+    __device__ __forceinline__ uint32_t lref() const { return (uint32_t)b[8]; }
+    __device__ __forceinline__ uint32_t rref() const { return (uint32_t)b[9]; }
+};
+__device__ __forceinline__ ScalarNode scalar_load_node(const WideNode *n) {
+    ScalarNode r;
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(r.a), "=&s"(r.b)
+                 : "s"(n)
+                 : "memory");
+    return r;
+}
+
+typedef int sgpr4_t __attribute__((ext_vector_type(4)));
+struct ScalarTri {
+    sgpr16_t a;               // p1 xyz, e1 xyz, e2 xy
+    sgpr4_t b;                // e2 z, triangle, remaining
+    __device__ __forceinline__ double f64(int i) const {      // i-th double of the record (0..8)
+        const int lo = (i < 8) ? a[2 * i] : b[0];
+        const int hi = (i < 8) ? a[2 * i + 1] : b[1];
+        return __hiloint2double(hi, lo);
+    }
+};
+__device__ __forceinline__ ScalarTri scalar_load_tri(const TriRecord *t) {
+    ScalarTri r;
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(r.a), "=&s"(r.b)
+                 : "s"(t)
+                 : "memory");
+    return r;
+}
+
 struct PacketStack {
     LdsWord *ref;          // [depth]      child reference
     LdsWord *parent;       // [depth]      WideNode holding that child's box (exact re-test at pop)
     LdsWord *mask_lo;      // [depth]      lanes that passed the child's box when it was pushed
     LdsWord *mask_hi;      // [depth]
-    float __attribute__((address_space(3))) *tmin;   // [depth][64] approximate tmin per lane
-    static __host__ __device__ size_t bytes(uint32_t depth) { return (size_t)depth * (16u + 256u); }
+    float __attribute__((address_space(3))) *tmin;        // [lds_levels][64] approximate tmin per lane
+    float __attribute__((address_space(1))) *tmin_spill;  // [depth - lds_levels][64] deeper levels, in HBM
+    uint32_t lds_levels;
+    static __host__ __device__ size_t bytes(uint32_t depth, uint32_t lds_levels) {
+        return (size_t)depth * 16u + (size_t)lds_levels * 256u;
+    }
+    __device__ __forceinline__ void put_tmin(uint32_t level, uint32_t lane, float v) const {
+        if (level < lds_levels) tmin[level * kWave + lane] = v;
+        else tmin_spill[(level - lds_levels) * kWave + lane] = v;
+    }
+    __device__ __forceinline__ float get_tmin(uint32_t level, uint32_t lane) const {
+        if (level < lds_levels) return tmin[level * kWave + lane];
+        return tmin_spill[(level - lds_levels) * kWave + lane];
+    }
 };
 
 template <int KIND>
 __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk_packet(const FrameParams P, const PipelineParams W) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    const uint32_t depth = W.lds_depth + W.spill_depth;         // the whole tree depth lives in LDS here
+    const uint32_t depth = W.lds_depth + W.spill_depth;         // pending right children never exceed the tree depth
     PacketStack st;
     st.ref = (LdsWord *)lds_raw;
     st.parent = st.ref + depth;
     st.mask_lo = st.parent + depth;
     st.mask_hi = st.mask_lo + depth;
     st.tmin = (float __attribute__((address_space(3))) *)(st.mask_hi + depth);
+    st.lds_levels = W.packet_lds_levels < depth ? W.packet_lds_levels : depth;
+    st.tmin_spill = (float __attribute__((address_space(1))) *)(reinterpret_cast<unsigned char *>(W.spill) +
+                                                                (size_t)blockIdx.x * depth * kWave * 12u);
 
     const uint32_t lane = threadIdx.x;
     const unsigned long long lane_bit = 1ull << lane, lanes_below = lane_bit - 1ull;
@@ -713,9 +770,10 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk_packet(const Fra
                 const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cur & ~kLeafBit));
                 const uint32_t count = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.tris[first].remaining);
                 for (uint32_t k = 0; k < count; k++) {
-                    const TriRecord *rec = P.tris + first + k;
+                    const ScalarTri tr = scalar_load_tri(P.tris + first + k);
                     if (mine && active) {
-                        const d3 p1 = load_d3(rec->p1), e1 = load_d3(rec->e1), e2 = load_d3(rec->e2);
+                        const d3 p1 = make_d3(tr.f64(0), tr.f64(1), tr.f64(2)), e1 = make_d3(tr.f64(3), tr.f64(4), tr.f64(5)),
+                                 e2 = make_d3(tr.f64(6), tr.f64(7), tr.f64(8));
                         const float before = t;
                         const bool hit = triangle_test(o, d, t, p1, e1, e2);
                         const float tclosest = (slot != kNoNode) ? before : kFarAway;      // bvh.cpp:212-215
@@ -727,22 +785,25 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk_packet(const Fra
             } else {
                 const uint32_t node_id = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
                 const WideNode *n = P.nodes + node_id;
+                const ScalarNode sn = scalar_load_node(n);
                 bool lpass = false, rpass = false;
                 float rtmin = 0.0f;
                 if (mine) {
+                    const double lmin[3] = {sn.f64(0), sn.f64(1), sn.f64(2)}, lmax[3] = {sn.f64(3), sn.f64(4), sn.f64(5)};
+                    const double rmin[3] = {sn.f64(6), sn.f64(7), sn.f64(8)}, rmax[3] = {sn.f64(9), sn.f64(10), sn.f64(11)};
                     float ltmin, ltmax, rtmax;
-                    slab_approx(o, inv, n->lmin, n->lmax, ltmin, ltmax);
-                    slab_approx(o, inv, n->rmin, n->rmax, rtmin, rtmax);
+                    slab_approx(o, inv, lmin, lmax, ltmin, ltmax);
+                    slab_approx(o, inv, rmin, rmax, rtmin, rtmax);
                     const bool sure = box_verdict_positive_t(ltmin, ltmax, t, lpass) & box_verdict_positive_t(rtmin, rtmax, t, rpass);
                     if (!(sure & fast)) {              // rare: the reference's divisions decide
-                        slab(o, d, n->lmin, n->lmax, ltmin, ltmax);
-                        slab(o, d, n->rmin, n->rmax, rtmin, rtmax);
+                        slab(o, d, lmin, lmax, ltmin, ltmax);
+                        slab(o, d, rmin, rmax, rtmin, rtmax);
                         lpass = ltmax >= ltmin && ltmin < t && ltmax > 0;
                         rpass = rtmax >= rtmin && rtmin < t && rtmax > 0;
                     }
                 }
                 const unsigned long long lm = __ballot(lpass), rm = __ballot(rpass);
-                const uint32_t lref = n->lref, rref = n->rref;
+                const uint32_t lref = sn.lref(), rref = sn.rref();
                 if (lm != 0ull && rm != 0ull) {
                     // the right child waits; each lane's `tmin < ray.t` is re-evaluated when it is popped
                     if (sp >= depth) { atomicOr(P.overflow, 1u); break; }
@@ -752,7 +813,7 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk_packet(const Fra
                         st.mask_lo[sp] = (uint32_t)rm;
                         st.mask_hi[sp] = (uint32_t)(rm >> 32);
                     }
-                    st.tmin[sp * kWave + lane] = rtmin;
+                    st.put_tmin(sp, lane, rtmin);
                     sp += 1;
                     cur = lref; mask = lm;
                     continue;
@@ -768,7 +829,7 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk_packet(const Fra
                 const unsigned long long pushed = (unsigned long long)st.mask_lo[sp] | ((unsigned long long)st.mask_hi[sp] << 32);
                 bool keep = false;
                 if ((pushed & lane_bit) != 0ull && active) {
-                    const float tmin = st.tmin[sp * kWave + lane];
+                    const float tmin = st.get_tmin(sp, lane);
                     if (ordinals_near(__float_as_int(tmin), __float_as_int(t), 2u)) {
                         // too close to ray.t to trust the approximate tmin: the whole test, exactly
                         const WideNode *pn = P.nodes + st.parent[sp];
@@ -881,10 +942,10 @@ int pipeline_walk_occupancy(size_t lds_bytes) {
     return a < b ? a : b;
 }
 
-int pipeline_packet_occupancy(uint32_t depth) {
+int pipeline_packet_occupancy(uint32_t depth, uint32_t lds_levels) {
     int a = 0, b = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, ct_walk_packet<0>, kWave, PacketStack::bytes(depth));
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, ct_walk_packet<1>, kWave, PacketStack::bytes(depth));
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, ct_walk_packet<0>, kWave, PacketStack::bytes(depth, lds_levels));
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, ct_walk_packet<1>, kWave, PacketStack::bytes(depth, lds_levels));
     return a < b ? a : b;
 }
 
@@ -892,7 +953,8 @@ void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hip
     if (W.packet && ss) {
         const uint32_t slots = (uint32_t)(W.n_samples / 16u);
         const uint32_t blocks = (slots + 255u) / 256u;
-        const size_t lds_p = PacketStack::bytes(W.lds_depth + W.spill_depth);
+        const uint32_t depth_p = W.lds_depth + W.spill_depth;
+        const size_t lds_p = PacketStack::bytes(depth_p, W.packet_lds_levels < depth_p ? W.packet_lds_levels : depth_p);
         if (W.n_samples == 0) return;
         hipLaunchKernelGGL(ct_sample_grid, dim3(blocks), dim3(256), 0, stream, P, W);
         hipLaunchKernelGGL((ct_walk_packet<0>), dim3(W.walk_blocks), dim3(kWave), lds_p, stream, P, W);

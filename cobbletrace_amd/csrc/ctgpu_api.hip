@@ -92,6 +92,7 @@ struct ctgpu_ctx {
     int lds_depth = 8;                          // 6 KB of LDS per wave; deeper entries spill to HBM
     int blocks_per_cu = 0;                      // 0 = occupancy query
     int chunk = 0;                              // 0 = sized from the frame
+    int packet_lds_levels = 14;                 // per-lane tmin levels kept in LDS by the packet walk
     bool packet_walk = true;                    // ct_walk_packet for supersampled frames (CTGPU_PACKET=0: per-lane walk)
     bool force_megakernel = false;
 
@@ -176,6 +177,7 @@ extern "C" int ctgpu_create(int device, ctgpu_ctx **out) {
     if (const char *t = std::getenv("CTGPU_BLOCKS_PER_CU")) ctx->blocks_per_cu = std::max(0, std::atoi(t));
     if (const char *t = std::getenv("CTGPU_CHUNK")) ctx->chunk = std::max(0, std::atoi(t));
     if (const char *t = std::getenv("CTGPU_PACKET")) ctx->packet_walk = std::atoi(t) != 0;
+    if (const char *t = std::getenv("CTGPU_PACKET_LDS_LEVELS")) ctx->packet_lds_levels = std::max(1, std::atoi(t));
     if (const char *t = std::getenv("CTGPU_FORCE_MEGAKERNEL")) ctx->force_megakernel = std::atoi(t) != 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->cu_count = prop.multiProcessorCount;
@@ -483,8 +485,9 @@ int launch_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, FrameParams &P, hipS
     W.spill_depth = std::max<uint32_t>(ctx->tree_depth, 1) - W.lds_depth;
     const size_t lds_bytes = (size_t)W.lds_depth * 64 * 12;
     W.packet = (ctx->packet_walk && ss) ? 1u : 0u;
+    W.packet_lds_levels = (uint32_t)ctx->packet_lds_levels;
     int per_cu = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu
-                                        : (W.packet ? pipeline_packet_occupancy(W.lds_depth + W.spill_depth)
+                                        : (W.packet ? pipeline_packet_occupancy(W.lds_depth + W.spill_depth, std::min<uint32_t>((uint32_t)ctx->packet_lds_levels, W.lds_depth + W.spill_depth))
                                                     : pipeline_walk_occupancy(lds_bytes));
     if (per_cu < 1) per_cu = 1;
     const uint64_t waves_needed = (W.n_samples + 63) / 64;
@@ -501,7 +504,7 @@ int launch_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, FrameParams &P, hipS
     HIP_TRY(ctx->hits.resize(W.n_samples));
     HIP_TRY(ctx->shadow.resize(W.n_samples * std::max<uint32_t>(W.n_shadow_lights, 1)));
     if (W.n_samples >= 0xfffffff0ull) return fail(CTGPU_ERR_ARG, "frame too large: %llu samples", (unsigned long long)W.n_samples);
-    HIP_TRY(ctx->spill.resize((size_t)W.walk_blocks * std::max<uint32_t>(W.spill_depth, 1) * 64 * 12 / 8 + 64));
+    HIP_TRY(ctx->spill.resize((size_t)W.walk_blocks * (size_t)(W.lds_depth + W.spill_depth) * 64 * 12 / 8 + 64));
     W.coords = ctx->coords.ptr; W.hits = ctx->hits.ptr; W.shadow = ctx->shadow.ptr;
     W.queue = ctx->queue.ptr; W.spill = ctx->spill.ptr; W.shadow_lights = ctx->shadow_lights.ptr;
     HIP_TRY(hipMemsetAsync(ctx->queue.ptr, 0, 33 * 8 * 16 * sizeof(unsigned long long), stream));

@@ -1,4 +1,5 @@
 #!/bin/bash
-run() { echo "== $*"; env "$@" timeout -k 10 100 python tools/quick_perf.py dragon bunny 2>&1 | grep -E "ss="; }
-run CTGPU_POOL=0
-for t in 4 8 16 24 32 48; do run CTGPU_POOL=1 CTGPU_POOL_THRESH=$t; done
+run() { echo "== $*"; env "$@" timeout -k 10 100 python tools/quick_perf.py dragon bunny 2>&1 | grep -E "ss=1"; }
+run CTGPU_PACKET_LDS_LEVELS=14
+for w in 6 8; do run CTGPU_PACKET_LDS_LEVELS=10 CTGPU_LIBRARY=$PWD/variants/libctgpu_w$w.so; done
+run CTGPU_PACKET_LDS_LEVELS=6 CTGPU_LIBRARY=$PWD/variants/libctgpu_w8.so
