@@ -27,6 +27,17 @@ struct alignas(128) WideNode {
 };
 static_assert(sizeof(WideNode) == 128, "WideNode must be one 128-byte line");
 
+// The same inner node with its twelve planes rounded to binary32: what the shared (packet) walk
+// reads on every visit -- one 64-byte scalar load.  It only FILTERS: a verdict taken from these
+// planes carries an error bound (box_verdict_f32 below) and anything inside the bound is redone
+// from the WideNode.
+struct alignas(64) NodeF32 {
+    float lmin[3], lmax[3], rmin[3], rmax[3];
+    uint32_t lref, rref;
+    uint32_t pad_[2];
+};
+static_assert(sizeof(NodeF32) == 64, "NodeF32 is one s_load_dwordx16");
+
 // One record per triangle, stored in LEAF ORDER (the order of bvh indexes[]), so a leaf
 // is a contiguous run and no index indirection is needed while traversing.
 // e1 = p2 - p1 and e2 = p3 - p1 are the D differences the reference recomputes on every
@@ -190,6 +201,66 @@ __device__ __forceinline__ bool box_verdict(float tmin, float tmax, float ray_t,
                            ordinals_near(kmax, 0, 3u);
     pass = tmax >= tmin && tmin < ray_t && tmax > 0;
     return !uncertain;
+}
+
+// ---------------------------------------------------------------- slab test, binary32 filter
+// Level 0 of the packet walk.  Per ray, once:  invf = F(inv),  noi = -F(o * inv)  (per axis), so a
+// plane parameter is ONE binary32 fma,  t^ = fma(F(b), invf, noi),  against the reference's
+// e = F((b - o) /D d).  With T = (b - o)/d in real arithmetic and B >= |b| for every plane of the
+// tree (plane_bound, taken over all nodes at upload):
+//     |t^ - T| <= 1.001 * (B |invf| 2^-23 + |noi| 2^-24)  +  1.001 * 2^-24 |t^|
+//                 [roundings of F(b), invf, noi]             [rounding of the fma]
+//     |e  - T| <= (2^-24 + 2^-51) |T| + 2^-150                [the reference's own roundings]
+// so  |e - t^| <= 1.01 E + 2^-22.9 |t^| + 2^-150  with  E = max over axes of the first bracket.
+// ray_filter() stores  e = 1.5 E + 2^-120  and the verdict uses  M(t) = e + 2^-21 |t|,  which leaves
+// more than 0.49 E + 2^-21.4 |t| for the binary32 roundings of the comparisons themselves.
+// t -> t -+ M(t) is increasing, min / max are monotone, so the reference's tmin / tmax lie within
+// M of the filter's; a decision is taken only when it holds over that whole interval.
+// The bound needs finite, non-overflowing operands: ray_filter() sets e = +inf (every verdict
+// uncertain, nothing is decided here) unless each |d| is in [2^-90, 2^90] and E < 2^80; and with
+// e finite every product is below 2^81, so t^ is finite and an inf / NaN can only come from e.
+struct RayFilter {
+    float inv[3], noi[3];
+    float e;
+};
+__device__ __forceinline__ RayFilter ray_filter(const d3 &o, const d3 &d, const d3 &inv, const float *plane_bound) {
+    RayFilter f;
+    f.inv[0] = (float)inv.x; f.inv[1] = (float)inv.y; f.inv[2] = (float)inv.z;
+    f.noi[0] = -(float)(o.x * inv.x); f.noi[1] = -(float)(o.y * inv.y); f.noi[2] = -(float)(o.z * inv.z);
+    auto ok = [](double c) {
+        const uint32_t e = ((uint32_t)__double2hiint(c) >> 20) & 0x7FFu;
+        return e >= 1023u - 90u && e < 1023u + 90u;
+    };
+    float E = 0.0f;
+    for (int a = 0; a < 3; a++) {
+        const float ea = __builtin_fmaf(plane_bound[a] * __builtin_fabsf(f.inv[a]), 0x1p-23f, __builtin_fabsf(f.noi[a]) * 0x1p-24f);
+        E = (ea > E || !(ea == ea)) ? ea : E;          // a NaN sticks
+    }
+    const bool usable = ok(d.x) && ok(d.y) && ok(d.z) && E < 0x1p80f;
+    f.e = usable ? __builtin_fmaf(E, 1.5f, 0x1p-120f) : __builtin_inff();
+    return f;
+}
+__device__ __forceinline__ void slab_f32(const RayFilter &f, const float *bmin, const float *bmax, float &tmin, float &tmax) {
+    const float tx1 = __builtin_fmaf(bmin[0], f.inv[0], f.noi[0]), tx2 = __builtin_fmaf(bmax[0], f.inv[0], f.noi[0]);
+    const float ty1 = __builtin_fmaf(bmin[1], f.inv[1], f.noi[1]), ty2 = __builtin_fmaf(bmax[1], f.inv[1], f.noi[1]);
+    const float tz1 = __builtin_fmaf(bmin[2], f.inv[2], f.noi[2]), tz2 = __builtin_fmaf(bmax[2], f.inv[2], f.noi[2]);
+    tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx1, tx2), __builtin_fminf(ty1, ty2)), __builtin_fminf(tz1, tz2));
+    tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx1, tx2), __builtin_fmaxf(ty1, ty2)), __builtin_fmaxf(tz1, tz2));
+}
+__device__ __forceinline__ float filter_margin(float t, float e) { return __builtin_fmaf(__builtin_fabsf(t), 0x1p-21f, e); }
+// The reference's  tmax >= tmin && tmin < ray.t && tmax > 0  holds when the least of
+//   tmax - tmin,  ray.t - tmin,  tmax      exceeds what the errors can take away, and fails when that
+// least value is below minus the same: one margin 2 M(max |t|) >= M(tmin) + M(tmax) serves all three.
+// Returns +1 (certainly passes), -1 (certainly fails) as the sign of `verdict`; |verdict| <= margin is undecided.
+__device__ __forceinline__ void box_verdict_f32(float tmin, float tmax, float e, float ray_t, float &least, float &margin) {
+    margin = __builtin_fmaf(__builtin_fmaxf(__builtin_fabsf(tmin), __builtin_fabsf(tmax)), 0x1p-20f, e + e);
+    least = __builtin_fminf(__builtin_fminf(tmax - tmin, ray_t - tmin), tmax);
+}
+// the deferred  tmin < ray.t  of a pushed child (ray.t may have dropped since): decided -> keep
+__device__ __forceinline__ bool deferred_verdict_f32(float tmin, float e, float ray_t, bool &keep) {
+    const float m = filter_margin(tmin, e);
+    keep = tmin + m < ray_t;
+    return keep | (tmin - m > ray_t);
 }
 
 // true when every component of d is non-zero and comfortably inside the binary64 normal range

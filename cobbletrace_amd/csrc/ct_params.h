@@ -13,6 +13,7 @@ namespace ctd {
 struct FrameParams {
     // scene (device pointers)
     const WideNode  *nodes;
+    const NodeF32   *nodes32;     // the same nodes, planes in binary32 (packet walk, level 0)
     const TriRecord *tris;
     const Material  *materials;
     const Light     *lights;
@@ -21,6 +22,7 @@ struct FrameParams {
     uint32_t slot_of_triangle0;   // TriRecord slot holding scene triangle 0
     uint32_t stack_depth;         // LDS stack entries per lane
     double   root_min[3], root_max[3];
+    float    plane_bound[3];      // >= |plane| of every box in the tree, per axis (+inf: no filter)
 
     // frame
     int32_t  width, height, half; // bitmap size; half = height/2

@@ -601,6 +601,18 @@ __device__ __forceinline__ ScalarNode scalar_load_node(const WideNode *n) {
     return r;
 }
 
+struct ScalarNode32 {
+    sgpr16_t a;
+    __device__ __forceinline__ float f32(int i) const { return __int_as_float(a[i]); }
+    __device__ __forceinline__ uint32_t lref() const { return (uint32_t)a[12]; }
+    __device__ __forceinline__ uint32_t rref() const { return (uint32_t)a[13]; }
+};
+__device__ __forceinline__ ScalarNode32 scalar_load_node32(const NodeF32 *n) {
+    ScalarNode32 r;
+    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(r.a) : "s"(n) : "memory");
+    return r;
+}
+
 typedef int sgpr4_t __attribute__((ext_vector_type(4)));
 struct ScalarTri {
     sgpr16_t a;               // p1 xyz, e1 xyz, e2 xy
@@ -666,18 +678,31 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk_packet(const Fra
     Light shadow_light = Light{};
     const d3 eye = make_d3(P.cam[0], P.cam[1], P.cam[2]);
 
-    d3 o = eye, d = make_d3(0, 0, 1), inv = make_d3(0, 0, 1);
+    d3 o = eye, d = make_d3(0, 0, 1);
+    RayFilter rf = RayFilter{};
     float t = kNoHit;
     uint32_t slot = kNoNode;
-    bool fast = false, has_ray = false;
+    bool has_ray = false, root_pass = false;
     uint64_t ray_id = 0;
     uint64_t chunk_next = 0, chunk_end = 0;
     bool wave_drained = false;
     uint32_t n_traced = 0;
+#ifdef CT_WALK_STATS
+    unsigned long long pk_n[6] = {0, 0, 0, 0, 0, 0}, pk_cyc[3] = {0, 0, 0};
+    const unsigned long long pk_begin = __builtin_amdgcn_s_memtime();
+#define PK_COUNT(i, v) do { pk_n[i] += (unsigned long long)(v); } while (0)
+#define PK_T0() const unsigned long long pk_t0 = __builtin_amdgcn_s_memtime()
+#define PK_T1(i) do { pk_cyc[i] += __builtin_amdgcn_s_memtime() - pk_t0; } while (0)
+#else
+#define PK_COUNT(i, v) do {} while (0)
+#define PK_T0() do {} while (0)
+#define PK_T1(i) do {} while (0)
+#endif
 
     for (;;) {
         // ---------------- fetch a packet: every lane gets a ray (or stays empty at the end)
         has_ray = false;
+        root_pass = false;
         for (;;) {
             const unsigned long long m_i = __ballot(!has_ray);
             if (m_i == 0ull || wave_drained) break;
@@ -729,11 +754,18 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk_packet(const Fra
                 if (live) {
                     t = kNoHit;
                     slot = kNoNode;
-                    fast = direction_allows_fast_slab(d);
-                    inv = make_d3(quick_reciprocal(d.x), quick_reciprocal(d.y), quick_reciprocal(d.z));
+                    const d3 inv = make_d3(quick_reciprocal(d.x), quick_reciprocal(d.y), quick_reciprocal(d.z));
+                    rf = ray_filter(o, d, inv, P.plane_bound);
                     ray_id = id;
                     has_ray = true;
                     n_traced += 1;
+                    // root box (bvh.cpp:205 at rootNodeIdx)
+                    float tmin, tmax;
+                    slab_approx(o, inv, P.root_min, P.root_max, tmin, tmax);
+                    if (!(box_verdict_positive_t(tmin, tmax, t, root_pass) & direction_allows_fast_slab(d))) {
+                        slab(o, d, P.root_min, P.root_max, tmin, tmax);
+                        root_pass = tmax >= tmin && tmin < t && tmax > 0;
+                    }
                 }
             }
             if (KIND == 0) break;          // primary packets: one aligned run of 64 samples, no top-up
@@ -743,67 +775,86 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk_packet(const Fra
             continue;
         }
 
-        // ---------------- root box (bvh.cpp:205 at rootNodeIdx)
-        bool active = has_ray;             // any-hit lanes drop out once ray.t has moved
-        uint32_t cur;
-        unsigned long long mask;
-        {
-            bool pass = false;
-            if (has_ray) {
-                float tmin, tmax;
-                slab_approx(o, inv, P.root_min, P.root_max, tmin, tmax);
-                if (!(box_verdict_positive_t(tmin, tmax, t, pass) & fast)) {
-                    slab(o, d, P.root_min, P.root_max, tmin, tmax);
-                    pass = tmax >= tmin && tmin < t && tmax > 0;
-                }
-            }
-            mask = __ballot(pass);
-            cur = P.root_ref;
-        }
+        // lanes still tracing (a shadow ray stops at its first hit, raythread.cpp:303-307); every
+        // lane mask below is wave-uniform and stays inside it
+        unsigned long long tracing = __ballot(has_ray);
+        uint32_t cur = P.root_ref;
+        unsigned long long mask = __ballot(root_pass);
         uint32_t sp = 0;
+#ifdef CT_SKIP_WALK                        // diagnostic build: time ray set-up and retirement alone
+        if (KIND == CT_SKIP_WALK) mask = 0ull;
+#endif
 
         // ---------------- the shared walk
         while (mask != 0ull) {
-            const bool mine = (mask & lane_bit) != 0ull && active;
             if (cur & kLeafBit) {
                 // leaf: every triangle in index order, each lane keeps its own closest hit
-                const uint32_t first = (uint32_t)__builtin_amdgcn_readfirstlane((int)(cur & ~kLeafBit));
+                const uint32_t first = cur & ~kLeafBit;
                 const uint32_t count = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.tris[first].remaining);
+                const bool mine = (mask & lane_bit) != 0ull;
+                PK_T0();
+                PK_COUNT(2, count);
+                PK_COUNT(3, (uint64_t)count * __popcll(mask));
                 for (uint32_t k = 0; k < count; k++) {
                     const ScalarTri tr = scalar_load_tri(P.tris + first + k);
-                    if (mine && active) {
+                    if (mine && (KIND == 0 || t == kNoHit)) {
                         const d3 p1 = make_d3(tr.f64(0), tr.f64(1), tr.f64(2)), e1 = make_d3(tr.f64(3), tr.f64(4), tr.f64(5)),
                                  e2 = make_d3(tr.f64(6), tr.f64(7), tr.f64(8));
                         const float before = t;
                         const bool hit = triangle_test(o, d, t, p1, e1, e2);
                         const float tclosest = (slot != kNoNode) ? before : kFarAway;      // bvh.cpp:212-215
                         if (hit && t != kNoHit && t < tclosest) slot = first + k;
-                        if (KIND == 1 && t != kNoHit) active = false;                      // raythread.cpp:303-307
                     }
                 }
-                mask = 0ull;               // fall through to the pop below
+                if (KIND == 1) tracing = __ballot(has_ray && t == kNoHit);
+                mask = 0ull;               // on to the pop below
+                PK_T1(1);
             } else {
-                const uint32_t node_id = (uint32_t)__builtin_amdgcn_readfirstlane((int)cur);
-                const WideNode *n = P.nodes + node_id;
-                const ScalarNode sn = scalar_load_node(n);
-                bool lpass = false, rpass = false;
-                float rtmin = 0.0f;
-                if (mine) {
-                    const double lmin[3] = {sn.f64(0), sn.f64(1), sn.f64(2)}, lmax[3] = {sn.f64(3), sn.f64(4), sn.f64(5)};
-                    const double rmin[3] = {sn.f64(6), sn.f64(7), sn.f64(8)}, rmax[3] = {sn.f64(9), sn.f64(10), sn.f64(11)};
-                    float ltmin, ltmax, rtmax;
-                    slab_approx(o, inv, lmin, lmax, ltmin, ltmax);
-                    slab_approx(o, inv, rmin, rmax, rtmin, rtmax);
-                    const bool sure = box_verdict_positive_t(ltmin, ltmax, t, lpass) & box_verdict_positive_t(rtmin, rtmax, t, rpass);
-                    if (!(sure & fast)) {              // rare: the reference's divisions decide
-                        slab(o, d, lmin, lmax, ltmin, ltmax);
-                        slab(o, d, rmin, rmax, rtmin, rtmax);
-                        lpass = ltmax >= ltmin && ltmin < t && ltmax > 0;
-                        rpass = rtmax >= rtmin && rtmin < t && rtmax > 0;
+                PK_T0();
+                PK_COUNT(0, 1);
+                PK_COUNT(1, __popcll(mask));
+                const uint32_t node_id = cur;
+                const ScalarNode32 sf = scalar_load_node32(P.nodes32 + node_id);
+                // level 0: binary32 planes, verdicts with an error bound.  Every lane computes (the
+                // masked-out ones on stale rays, harmlessly) and the verdicts leave the vector unit
+                // as wave masks: no per-lane flag crosses a branch.
+                const float lmin[3] = {sf.f32(0), sf.f32(1), sf.f32(2)}, lmax[3] = {sf.f32(3), sf.f32(4), sf.f32(5)};
+                const float rmin[3] = {sf.f32(6), sf.f32(7), sf.f32(8)}, rmax[3] = {sf.f32(9), sf.f32(10), sf.f32(11)};
+                float ltmin, ltmax, rtmin, rtmax, lleast, lmargin, rleast, rmargin;
+                slab_f32(rf, lmin, lmax, ltmin, ltmax);
+                slab_f32(rf, rmin, rmax, rtmin, rtmax);
+                box_verdict_f32(ltmin, ltmax, rf.e, t, lleast, lmargin);
+                box_verdict_f32(rtmin, rtmax, rf.e, t, rleast, rmargin);
+                const unsigned long long l_yes = __ballot(lleast > lmargin), l_no = __ballot(lleast < -lmargin);
+                const unsigned long long r_yes = __ballot(rleast > rmargin), r_no = __ballot(rleast < -rmargin);
+                unsigned long long lm = l_yes & mask, rm = r_yes & mask;
+                const unsigned long long unsure = mask & ~((l_yes | l_no) & (r_yes | r_no));
+                if (unsure != 0ull) {
+                    PK_COUNT(4, 1);
+                    // level 1 (some lane sits inside the bound): binary64 planes, one-step margins;
+                    // level 2 (rarer still): the reference's divisions
+                    const ScalarNode sn = scalar_load_node(P.nodes + node_id);
+                    bool lpass = false, rpass = false;
+                    if ((unsure & lane_bit) != 0ull) {
+                        const double lmin[3] = {sn.f64(0), sn.f64(1), sn.f64(2)}, lmax[3] = {sn.f64(3), sn.f64(4), sn.f64(5)};
+                        const double rmin[3] = {sn.f64(6), sn.f64(7), sn.f64(8)}, rmax[3] = {sn.f64(9), sn.f64(10), sn.f64(11)};
+                        const d3 inv = make_d3(quick_reciprocal(d.x), quick_reciprocal(d.y), quick_reciprocal(d.z));
+                        float ltmin, ltmax, rtmin64, rtmax;
+                        slab_approx(o, inv, lmin, lmax, ltmin, ltmax);
+                        slab_approx(o, inv, rmin, rmax, rtmin64, rtmax);
+                        const bool sure = box_verdict_positive_t(ltmin, ltmax, t, lpass) & box_verdict_positive_t(rtmin64, rtmax, t, rpass);
+                        if (!(sure & direction_allows_fast_slab(d))) {
+                            slab(o, d, lmin, lmax, ltmin, ltmax);
+                            slab(o, d, rmin, rmax, rtmin64, rtmax);
+                            lpass = ltmax >= ltmin && ltmin < t && ltmax > 0;
+                            rpass = rtmax >= rtmin64 && rtmin64 < t && rtmax > 0;
+                        }
                     }
+                    lm = (lm & ~unsure) | __ballot(lpass);
+                    rm = (rm & ~unsure) | __ballot(rpass);
                 }
-                const unsigned long long lm = __ballot(lpass), rm = __ballot(rpass);
-                const uint32_t lref = sn.lref(), rref = sn.rref();
+                const uint32_t lref = sf.lref(), rref = sf.rref();
+                PK_T1(0);
                 if (lm != 0ull && rm != 0ull) {
                     // the right child waits; each lane's `tmin < ray.t` is re-evaluated when it is popped
                     if (sp >= depth) { atomicOr(P.overflow, 1u); break; }
@@ -824,24 +875,28 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk_packet(const Fra
             }
             // ---------------- pop: next pending right child some lane still wants
             while (mask == 0ull && sp > 0) {
+                PK_T0();
+                PK_COUNT(5, 1);
                 sp -= 1;
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                const unsigned long long pushed = (unsigned long long)st.mask_lo[sp] | ((unsigned long long)st.mask_hi[sp] << 32);
+                const uint32_t pushed_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.mask_lo[sp]);
+                const uint32_t pushed_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.mask_hi[sp]);
+                const unsigned long long pushed = ((unsigned long long)pushed_lo | ((unsigned long long)pushed_hi << 32)) & tracing;
+                if (pushed == 0ull) continue;
                 bool keep = false;
-                if ((pushed & lane_bit) != 0ull && active) {
-                    const float tmin = st.get_tmin(sp, lane);
-                    if (ordinals_near(__float_as_int(tmin), __float_as_int(t), 2u)) {
-                        // too close to ray.t to trust the approximate tmin: the whole test, exactly
+                if ((pushed & lane_bit) != 0ull) {
+                    const float tmin = st.get_tmin(sp, lane);          // the filter's tmin, good to M(tmin)
+                    if (!deferred_verdict_f32(tmin, rf.e, t, keep)) {
+                        // too close to ray.t to trust: the whole test, exactly
                         const WideNode *pn = P.nodes + st.parent[sp];
                         float etmin, etmax;
                         slab(o, d, pn->rmin, pn->rmax, etmin, etmax);
                         keep = etmax >= etmin && etmin < t && etmax > 0;
-                    } else {
-                        keep = tmin < t;
                     }
                 }
                 mask = __ballot(keep);
-                cur = st.ref[sp];
+                cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.ref[sp]);
+                PK_T1(2);
             }
         }
 
@@ -852,6 +907,13 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk_packet(const Fra
         }
     }
 
+#ifdef CT_WALK_STATS
+    if (lane == 0 && KIND == W.thresh_a) {     // diagnostic build: CTGPU_WALK_THRESH=r,<kind>,b picks the kernel
+        for (int k = 0; k < 6; k++) atomicAdd(&P.counters[5 + k], pk_n[k]);
+        for (int k = 0; k < 3; k++) atomicAdd(&P.counters[11 + k], pk_cyc[k]);
+        atomicAdd(&P.counters[14], __builtin_amdgcn_s_memtime() - pk_begin);
+    }
+#endif
     for (int off = 32; off > 0; off >>= 1) n_traced += __shfl_down(n_traced, off);
     if (lane == 0) atomicAdd(&P.counters[KIND == 0 ? 0 : 1], (unsigned long long)n_traced);
 }

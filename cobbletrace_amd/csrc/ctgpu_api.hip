@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -66,6 +67,8 @@ struct ctgpu_ctx {
     double root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
 
     DeviceArray<WideNode> nodes;
+    DeviceArray<NodeF32> nodes32;
+    float plane_bound[3] = {0, 0, 0};
     DeviceArray<TriRecord> tris;
     DeviceArray<Material> materials;
     DeviceArray<Light> lights;
@@ -247,6 +250,31 @@ extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
         w.rref = child_ref(n.left + 1);
     }
 
+    // binary32 copy of the planes for the packet walk's filter, and the bound its error term needs
+    std::vector<NodeF32> narrow(wide.size());
+    std::memset(narrow.data(), 0, narrow.size() * sizeof(NodeF32));
+    double bound[3] = {0, 0, 0};
+    bool bound_ok = true;
+    for (uint32_t i = 0; i < M; i++) {
+        const ctgpu_node &n = s->nodes[i];
+        for (int c = 0; c < 3; c++) {
+            const double lo = std::fabs(n.bmin[c]), hi = std::fabs(n.bmax[c]);
+            if (!(lo <= 1e30) || !(hi <= 1e30)) bound_ok = false;      // also catches NaN
+            bound[c] = std::max(bound[c], std::max(lo, hi));
+        }
+    }
+    for (int c = 0; c < 3; c++)
+        ctx->plane_bound[c] = bound_ok ? std::nextafterf((float)bound[c], INFINITY) : INFINITY;
+    for (size_t i = 0; i < wide.size(); i++) {
+        const WideNode &w = wide[i];
+        NodeF32 &f = narrow[i];
+        for (int c = 0; c < 3; c++) {
+            f.lmin[c] = (float)w.lmin[c]; f.lmax[c] = (float)w.lmax[c];
+            f.rmin[c] = (float)w.rmin[c]; f.rmax[c] = (float)w.rmax[c];
+        }
+        f.lref = w.lref; f.rref = w.rref;
+    }
+
     // leaf-ordered triangle records; a tree walk gives depth and the leaf extents
     std::vector<TriRecord> recs(N);
     std::vector<uint32_t> remaining(N, 1);
@@ -294,6 +322,8 @@ extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
     HIP_TRY(ctx->materials.resize(N));
     HIP_TRY(ctx->lights.resize(std::max<uint32_t>(s->n_lights, 1)));
     HIP_TRY(hipMemcpy(ctx->nodes.ptr, wide.data(), wide.size() * sizeof(WideNode), hipMemcpyHostToDevice));
+    HIP_TRY(ctx->nodes32.resize(narrow.size()));
+    HIP_TRY(hipMemcpy(ctx->nodes32.ptr, narrow.data(), narrow.size() * sizeof(NodeF32), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(ctx->tris.ptr, recs.data(), (size_t)N * sizeof(TriRecord), hipMemcpyHostToDevice));
     static_assert(sizeof(Material) == sizeof(ctgpu_material), "material layout");
     static_assert(sizeof(Light) == sizeof(ctgpu_light), "light layout");
@@ -379,13 +409,14 @@ int fill_params(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, const ctgpu_partition
                 FrameParams &P) {
     const Geometry g = geometry(f);
     std::memset(&P, 0, sizeof P);
-    P.nodes = ctx->nodes.ptr; P.tris = ctx->tris.ptr; P.materials = ctx->materials.ptr; P.lights = ctx->lights.ptr;
+    P.nodes = ctx->nodes.ptr; P.nodes32 = ctx->nodes32.ptr; P.tris = ctx->tris.ptr; P.materials = ctx->materials.ptr; P.lights = ctx->lights.ptr;
     P.n_lights = ctx->n_lights;
     P.root_ref = ctx->root_ref;
     P.slot_of_triangle0 = ctx->slot_of_triangle0;
     // pending right siblings never exceed the tree depth; COUNT mode also parks rejected ones
     P.stack_depth = std::max<uint32_t>(ctx->tree_depth, 2);
     (void)count_mode;
+    std::memcpy(P.plane_bound, ctx->plane_bound, 12);
     std::memcpy(P.root_min, ctx->root_min, 24);
     std::memcpy(P.root_max, ctx->root_max, 24);
     P.width = f->width; P.height = f->height; P.half = g.half;
@@ -445,7 +476,13 @@ int read_counters(ctgpu_ctx *ctx, ctgpu_stats *st) {
         std::fprintf(stderr, "phases: A %llu x %.1f lanes (%.0f cyc each), B %llu x %.1f lanes (%.0f cyc), C %llu x %.1f lanes (%.0f cyc)\n", c[5],
                      (double)c[6] / c[5], (double)c[11] / c[5], c[7], c[7] ? (double)c[8] / c[7] : 0.0, c[7] ? (double)c[12] / c[7] : 0.0,
                      c[9], c[9] ? (double)c[10] / c[9] : 0.0, c[9] ? (double)c[13] / c[9] : 0.0);
-    if (std::getenv("CTGPU_DEBUG_PHASES") && c[14])
+    if (std::getenv("CTGPU_DEBUG_PACKET") && c[14])
+        std::fprintf(stderr, "packet walk: inner %llu (%.1f lanes, %.0f cyc each; level 1 on %.3f%%), leaf triangles %llu (%.1f lanes; %.0f cyc each), "
+                     "pops %llu (%.0f cyc each); wave cycles %llu: inner %.1f%% leaf %.1f%% pop %.1f%% other %.1f%%\n",
+                     c[5], (double)c[6] / c[5], (double)c[11] / c[5], 100.0 * c[9] / c[5], c[7], c[7] ? (double)c[8] / c[7] : 0.0,
+                     c[7] ? (double)c[12] / c[7] : 0.0, c[10], c[10] ? (double)c[13] / c[10] : 0.0, c[14], 100.0 * c[11] / c[14],
+                     100.0 * c[12] / c[14], 100.0 * c[13] / c[14], 100.0 * (c[14] - c[11] - c[12] - c[13]) / c[14]);
+    else if (std::getenv("CTGPU_DEBUG_PHASES") && c[14])
         std::fprintf(stderr, "wave lifetime cycles total %llu: A %.1f%% B %.1f%% R %.1f%% other %.1f%%\n", c[14],
                      100.0 * c[11] / c[14], 100.0 * c[12] / c[14], 100.0 * c[13] / c[14],
                      100.0 * (c[14] - c[11] - c[12] - c[13]) / c[14]);
