@@ -617,6 +617,7 @@ typedef int sgpr4_t __attribute__((ext_vector_type(4)));
 struct ScalarTri {
     sgpr16_t a;               // p1 xyz, e1 xyz, e2 xy
     sgpr4_t b;                // e2 z, triangle, remaining
+    __device__ __forceinline__ uint32_t remaining() const { return (uint32_t)b[3]; }
     __device__ __forceinline__ double f64(int i) const {      // i-th double of the record (0..8)
         const int lo = (i < 8) ? a[2 * i] : b[0];
         const int hi = (i < 8) ? a[2 * i + 1] : b[1];
@@ -790,13 +791,16 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk_packet(const Fra
             if (cur & kLeafBit) {
                 // leaf: every triangle in index order, each lane keeps its own closest hit
                 const uint32_t first = cur & ~kLeafBit;
-                const uint32_t count = (uint32_t)__builtin_amdgcn_readfirstlane((int)P.tris[first].remaining);
                 const bool mine = (mask & lane_bit) != 0ull;
                 PK_T0();
-                PK_COUNT(2, count);
-                PK_COUNT(3, (uint64_t)count * __popcll(mask));
+                uint32_t count = 1;        // the first record says how many the leaf holds
                 for (uint32_t k = 0; k < count; k++) {
                     const ScalarTri tr = scalar_load_tri(P.tris + first + k);
+                    if (k == 0) {
+                        count = tr.remaining();
+                        PK_COUNT(2, count);
+                        PK_COUNT(3, (uint64_t)count * __popcll(mask));
+                    }
                     if (mine && (KIND == 0 || t == kNoHit)) {
                         const d3 p1 = make_d3(tr.f64(0), tr.f64(1), tr.f64(2)), e1 = make_d3(tr.f64(3), tr.f64(4), tr.f64(5)),
                                  e2 = make_d3(tr.f64(6), tr.f64(7), tr.f64(8));
