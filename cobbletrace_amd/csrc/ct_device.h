@@ -27,16 +27,24 @@ struct alignas(128) WideNode {
 };
 static_assert(sizeof(WideNode) == 128, "WideNode must be one 128-byte line");
 
-// The same inner node with its twelve planes rounded to binary32: what the shared (packet) walk
-// reads on every visit -- one 64-byte scalar load.  It only FILTERS: a verdict taken from these
-// planes carries an error bound (box_verdict_f32 below) and anything inside the bound is redone
-// from the WideNode.
-struct alignas(64) NodeF32 {
-    float lmin[3], lmax[3], rmin[3], rmax[3];
-    uint32_t lref, rref;
-    uint32_t pad_[2];
+// What the shared (packet) walk reads: the tree with every second level folded away.  A QuadNode
+// stands for one inner node X of the reference tree and lists, in the reference's visiting order,
+// the boxes the reference tests below X before it can reach anything else: for each child c of X,
+// c's two children when c is an inner node whose children's boxes lie inside c's own box
+// (checked at upload), otherwise c itself.  Skipping c's own test is exact: every plane parameter
+// F((b - o) /D d) is monotone in b, so for nested boxes tmin(c) <= tmin(g) and tmax(c) >= tmax(g)
+// in the reference's arithmetic, ray.t only shrinks, and hence g passes => c passed; g's own test
+// is the one the reference makes on entering g.  Half as many dependent fetches per ray.
+// Planes are rounded to binary32 -- they only FILTER: a verdict taken from them carries an error
+// bound (box_verdict_f32 below) and anything inside the bound is redone from the WideNode the
+// entry came from (quad_source[]).
+struct alignas(128) QuadNode {
+    float plane[4][3][2];         // [entry][axis]{min, max}: one packed fma serves both planes of an axis
+    uint32_t ref[4];              // entry: kLeafBit | first TriRecord slot, or a QuadNode index
+    uint32_t count;               // entries in use (2..4)
+    uint32_t pad_[3];
 };
-static_assert(sizeof(NodeF32) == 64, "NodeF32 is one s_load_dwordx16");
+static_assert(sizeof(QuadNode) == 128, "QuadNode is two s_load_dwordx16");
 
 // One record per triangle, stored in LEAF ORDER (the order of bvh indexes[]), so a leaf
 // is a contiguous run and no index indirection is needed while traversing.
@@ -95,6 +103,30 @@ __device__ __forceinline__ void slab(const d3 &o, const d3 &d, const double *bmi
     tmax = lesser(tmax, greater(ty1, ty2));
     const float tz1 = (float)((bmin[2] - o.z) / d.z);
     const float tz2 = (float)((bmax[2] - o.z) / d.z);
+    tmin = greater(tmin, lesser(tz1, tz2));
+    tmax = lesser(tmax, greater(tz1, tz2));
+}
+
+// The same arithmetic for the rare fallback inside a register-tight kernel: the scheduler may not
+// overlap the six divisions (each needs about ten temporaries), so they run one after another.
+__device__ __forceinline__ void slab_in_sequence(const d3 &o, const d3 &d, const double *bmin, const double *bmax,
+                                                 float &tmin, float &tmax) {
+    const float tx1 = (float)((bmin[0] - o.x) / d.x);
+    __builtin_amdgcn_sched_barrier(0);
+    const float tx2 = (float)((bmax[0] - o.x) / d.x);
+    __builtin_amdgcn_sched_barrier(0);
+    tmin = lesser(tx1, tx2);
+    tmax = greater(tx1, tx2);
+    const float ty1 = (float)((bmin[1] - o.y) / d.y);
+    __builtin_amdgcn_sched_barrier(0);
+    const float ty2 = (float)((bmax[1] - o.y) / d.y);
+    __builtin_amdgcn_sched_barrier(0);
+    tmin = greater(tmin, lesser(ty1, ty2));
+    tmax = lesser(tmax, greater(ty1, ty2));
+    const float tz1 = (float)((bmin[2] - o.z) / d.z);
+    __builtin_amdgcn_sched_barrier(0);
+    const float tz2 = (float)((bmax[2] - o.z) / d.z);
+    __builtin_amdgcn_sched_barrier(0);
     tmin = greater(tmin, lesser(tz1, tz2));
     tmax = lesser(tmax, greater(tz1, tz2));
 }
@@ -219,41 +251,50 @@ __device__ __forceinline__ bool box_verdict(float tmin, float tmax, float ray_t,
 // The bound needs finite, non-overflowing operands: ray_filter() sets e = +inf (every verdict
 // uncertain, nothing is decided here) unless each |d| is in [2^-90, 2^90] and E < 2^80; and with
 // e finite every product is below 2^81, so t^ is finite and an inf / NaN can only come from e.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct RayFilter {
-    float inv[3], noi[3];
-    float e;
+    // four register pairs, laid out for the packed fma's operand selects (no splat copies):
+    f32x2 inv_xy, noi_xy;         // {inv.x, inv.y}, {noi.x, noi.y}
+    f32x2 inv_z_e2, noi_z_e;      // {inv.z, 2 e},   {noi.z, e}
 };
 __device__ __forceinline__ RayFilter ray_filter(const d3 &o, const d3 &d, const d3 &inv, const float *plane_bound) {
-    RayFilter f;
-    f.inv[0] = (float)inv.x; f.inv[1] = (float)inv.y; f.inv[2] = (float)inv.z;
-    f.noi[0] = -(float)(o.x * inv.x); f.noi[1] = -(float)(o.y * inv.y); f.noi[2] = -(float)(o.z * inv.z);
+    const float fi[3] = {(float)inv.x, (float)inv.y, (float)inv.z};
+    const float fo[3] = {-(float)(o.x * inv.x), -(float)(o.y * inv.y), -(float)(o.z * inv.z)};
     auto ok = [](double c) {
         const uint32_t e = ((uint32_t)__double2hiint(c) >> 20) & 0x7FFu;
         return e >= 1023u - 90u && e < 1023u + 90u;
     };
     float E = 0.0f;
     for (int a = 0; a < 3; a++) {
-        const float ea = __builtin_fmaf(plane_bound[a] * __builtin_fabsf(f.inv[a]), 0x1p-23f, __builtin_fabsf(f.noi[a]) * 0x1p-24f);
+        const float ea = __builtin_fmaf(plane_bound[a] * __builtin_fabsf(fi[a]), 0x1p-23f, __builtin_fabsf(fo[a]) * 0x1p-24f);
         E = (ea > E || !(ea == ea)) ? ea : E;          // a NaN sticks
     }
     const bool usable = ok(d.x) && ok(d.y) && ok(d.z) && E < 0x1p80f;
-    f.e = usable ? __builtin_fmaf(E, 1.5f, 0x1p-120f) : __builtin_inff();
+    const float e = usable ? __builtin_fmaf(E, 1.5f, 0x1p-120f) : __builtin_inff();
+    RayFilter f;
+    f.inv_xy = f32x2{fi[0], fi[1]};  f.noi_xy = f32x2{fo[0], fo[1]};
+    f.inv_z_e2 = f32x2{fi[2], e + e}; f.noi_z_e = f32x2{fo[2], e};
     return f;
 }
-__device__ __forceinline__ void slab_f32(const RayFilter &f, const float *bmin, const float *bmax, float &tmin, float &tmax) {
-    const float tx1 = __builtin_fmaf(bmin[0], f.inv[0], f.noi[0]), tx2 = __builtin_fmaf(bmax[0], f.inv[0], f.noi[0]);
-    const float ty1 = __builtin_fmaf(bmin[1], f.inv[1], f.noi[1]), ty2 = __builtin_fmaf(bmax[1], f.inv[1], f.noi[1]);
-    const float tz1 = __builtin_fmaf(bmin[2], f.inv[2], f.noi[2]), tz2 = __builtin_fmaf(bmax[2], f.inv[2], f.noi[2]);
-    tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx1, tx2), __builtin_fminf(ty1, ty2)), __builtin_fminf(tz1, tz2));
-    tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx1, tx2), __builtin_fmaxf(ty1, ty2)), __builtin_fmaxf(tz1, tz2));
+// One box from {min, max} plane pairs (wave-uniform, in scalar registers): three packed fmas --
+// written out because the operand selects are what lets {inv.x, inv.y} serve both x and y without
+// a splat copy per axis (the compiler makes the copies, 6 more registers) -- then the reference's
+// min / max pattern.
+__device__ __forceinline__ void slab_pairs_f32(const RayFilter &f, f32x2 px, f32x2 py, f32x2 pz, float &tmin, float &tmax) {
+    f32x2 tx, ty, tz;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(tx) : "s"(px), "v"(f.inv_xy), "v"(f.noi_xy));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[1,1,1]" : "=v"(ty) : "s"(py), "v"(f.inv_xy), "v"(f.noi_xy));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(tz) : "s"(pz), "v"(f.inv_z_e2), "v"(f.noi_z_e));
+    tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx.x, tx.y), __builtin_fminf(ty.x, ty.y)), __builtin_fminf(tz.x, tz.y));
+    tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx.x, tx.y), __builtin_fmaxf(ty.x, ty.y)), __builtin_fmaxf(tz.x, tz.y));
 }
 __device__ __forceinline__ float filter_margin(float t, float e) { return __builtin_fmaf(__builtin_fabsf(t), 0x1p-21f, e); }
 // The reference's  tmax >= tmin && tmin < ray.t && tmax > 0  holds when the least of
 //   tmax - tmin,  ray.t - tmin,  tmax      exceeds what the errors can take away, and fails when that
 // least value is below minus the same: one margin 2 M(max |t|) >= M(tmin) + M(tmax) serves all three.
 // Returns +1 (certainly passes), -1 (certainly fails) as the sign of `verdict`; |verdict| <= margin is undecided.
-__device__ __forceinline__ void box_verdict_f32(float tmin, float tmax, float e, float ray_t, float &least, float &margin) {
-    margin = __builtin_fmaf(__builtin_fmaxf(__builtin_fabsf(tmin), __builtin_fabsf(tmax)), 0x1p-20f, e + e);
+__device__ __forceinline__ void box_verdict_f32(float tmin, float tmax, float two_e, float ray_t, float &least, float &margin) {
+    margin = __builtin_fmaf(__builtin_fmaxf(__builtin_fabsf(tmin), __builtin_fabsf(tmax)), 0x1p-20f, two_e);
     least = __builtin_fminf(__builtin_fminf(tmax - tmin, ray_t - tmin), tmax);
 }
 // the deferred  tmin < ray.t  of a pushed child (ray.t may have dropped since): decided -> keep

@@ -13,7 +13,9 @@ namespace ctd {
 struct FrameParams {
     // scene (device pointers)
     const WideNode  *nodes;
-    const NodeF32   *nodes32;     // the same nodes, planes in binary32 (packet walk, level 0)
+    const QuadNode  *quads;       // the tree folded to four-wide nodes, binary32 planes (packet walk)
+    const uint32_t  *quad_source; // [quad][entry] WideNode index * 2 + side: where that entry's binary64 box is
+    uint32_t quad_root;           // root reference of the folded tree (a leaf reference for a one-leaf tree)
     const TriRecord *tris;
     const Material  *materials;
     const Light     *lights;
@@ -66,6 +68,7 @@ struct PipelineParams {
     uint32_t chunk;              // ray ids a wave reserves per queue atomic (multiple of 64)
     uint32_t packet;             // 1: supersampled frames use ct_walk_packet (shared walk per wave)
     uint32_t packet_lds_levels;  // stack levels whose per-lane tmin lives in LDS (deeper ones in HBM)
+    uint32_t packet_depth;       // most entries the folded tree can have pending at once
     int32_t  thresh_r, thresh_a, thresh_b;
 };
 

@@ -31,6 +31,9 @@ using namespace ctd;
 namespace {
 
 constexpr int kWave = 64;
+#ifndef CT_PACKET_WAVES
+#define CT_PACKET_WAVES 6    // the packet walk needs fewer registers: six waves per SIMD (80 VGPRs)
+#endif
 #ifndef CT_WALK_WAVES
 #define CT_WALK_WAVES 5      // waves per SIMD the traversal kernel is register-budgeted for
 #endif
@@ -601,15 +604,24 @@ __device__ __forceinline__ ScalarNode scalar_load_node(const WideNode *n) {
     return r;
 }
 
-struct ScalarNode32 {
-    sgpr16_t a;
-    __device__ __forceinline__ float f32(int i) const { return __int_as_float(a[i]); }
-    __device__ __forceinline__ uint32_t lref() const { return (uint32_t)a[12]; }
-    __device__ __forceinline__ uint32_t rref() const { return (uint32_t)a[13]; }
+struct ScalarQuad {
+    sgpr16_t a, b;            // bytes 0..63, 64..127 of the QuadNode
+    __device__ __forceinline__ f32x2 planes(int entry, int axis) const {       // {min, max} of entry's box on axis
+        const int i = entry * 3 + axis;
+        f32x2 r;
+        r.x = __int_as_float((i < 8) ? a[2 * i] : b[2 * (i - 8)]);
+        r.y = __int_as_float((i < 8) ? a[2 * i + 1] : b[2 * (i - 8) + 1]);
+        return r;
+    }
+    __device__ __forceinline__ uint32_t ref(int entry) const { return (uint32_t)b[8 + entry]; }
+    __device__ __forceinline__ uint32_t count() const { return (uint32_t)b[12]; }
 };
-__device__ __forceinline__ ScalarNode32 scalar_load_node32(const NodeF32 *n) {
-    ScalarNode32 r;
-    asm volatile("s_load_dwordx16 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(r.a) : "s"(n) : "memory");
+__device__ __forceinline__ ScalarQuad scalar_load_quad(const QuadNode *n) {
+    ScalarQuad r;
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(r.a), "=&s"(r.b)
+                 : "s"(n)
+                 : "memory");
     return r;
 }
 
@@ -635,7 +647,7 @@ __device__ __forceinline__ ScalarTri scalar_load_tri(const TriRecord *t) {
 
 struct PacketStack {
     LdsWord *ref;          // [depth]      child reference
-    LdsWord *parent;       // [depth]      WideNode holding that child's box (exact re-test at pop)
+    LdsWord *parent;       // [depth]      QuadNode * 4 + entry the box belongs to (exact re-test at pop)
     LdsWord *mask_lo;      // [depth]      lanes that passed the child's box when it was pushed
     LdsWord *mask_hi;      // [depth]
     float __attribute__((address_space(3))) *tmin;        // [lds_levels][64] approximate tmin per lane
@@ -655,9 +667,9 @@ struct PacketStack {
 };
 
 template <int KIND>
-__global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk_packet(const FrameParams P, const PipelineParams W) {
+__global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const FrameParams P, const PipelineParams W) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    const uint32_t depth = W.lds_depth + W.spill_depth;         // pending right children never exceed the tree depth
+    const uint32_t depth = W.packet_depth;                      // most entries the folded tree leaves pending
     PacketStack st;
     st.ref = (LdsWord *)lds_raw;
     st.parent = st.ref + depth;
@@ -669,14 +681,14 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk_packet(const Fra
                                                                 (size_t)blockIdx.x * depth * kWave * 12u);
 
     const uint32_t lane = threadIdx.x;
-    const unsigned long long lane_bit = 1ull << lane, lanes_below = lane_bit - 1ull;
+    // (a wave mask becomes a lane predicate with inverse_ballot: the mask goes straight into EXEC)
     const uint64_t n_samples = W.n_samples;
     const uint32_t n_shards = (KIND == 0) ? kShards : kShards * W.n_shadow_lights;
     unsigned long long *heads = W.queue + (size_t)(KIND == 0 ? 0u : kShards) * 16u;
     const uint64_t shard_span = ((n_samples + kShards - 1) / kShards + W.chunk - 1) / W.chunk * W.chunk;
     uint32_t shard = blockIdx.x % n_shards, shards_done = 0;
     uint64_t light_base = 0;
-    Light shadow_light = Light{};
+    uint32_t light_index = 0;                // lights[] entry of the shadow rays in the current chunk
     const d3 eye = make_d3(P.cam[0], P.cam[1], P.cam[2]);
 
     d3 o = eye, d = make_d3(0, 0, 1);
@@ -684,7 +696,8 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk_packet(const Fra
     float t = kNoHit;
     uint32_t slot = kNoNode;
     bool has_ray = false, root_pass = false;
-    uint64_t ray_id = 0;
+    uint64_t ray_id = 0;          // shadow packets: per lane; primary packets: packet_base + lane
+    uint64_t packet_base = 0;
     uint64_t chunk_next = 0, chunk_end = 0;
     bool wave_drained = false;
     uint32_t n_traced = 0;
@@ -710,7 +723,8 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk_packet(const Fra
             if (chunk_next >= chunk_end) {
                 unsigned long long offset = 0;
                 if (lane == 0) offset = atomicAdd(heads + (size_t)shard * 16u, (unsigned long long)W.chunk);
-                offset = __shfl(offset, 0);
+                offset = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)offset) |
+                         ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(offset >> 32)) << 32);
                 const uint32_t light = shard / kShards, part = shard % kShards;
                 const uint64_t lo = (uint64_t)part * shard_span + offset;
                 if (offset >= shard_span || lo >= n_samples) {
@@ -725,14 +739,15 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk_packet(const Fra
                 light_base = (uint64_t)light * n_samples;
                 chunk_next = light_base + lo;
                 chunk_end = light_base + hi;
-                if (KIND == 1) shadow_light = P.lights[W.shadow_lights[light]];
+                if (KIND == 1) light_index = (uint32_t)__builtin_amdgcn_readfirstlane((int)W.shadow_lights[light]);
                 // a packet never mixes lights (its rays should point the same way): start a new one
                 if (KIND == 1 && m_i != ~0ull) break;
             }
             const uint64_t avail = chunk_end - chunk_next;
-            const uint32_t rank = (uint32_t)__popcll(m_i & lanes_below);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_i >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_i, 0u));
             const bool take = !has_ray && rank < avail;
             const uint64_t id = chunk_next + rank;
+            if (KIND == 0) packet_base = chunk_next;      // every lane is free here: rank == lane
             const uint64_t wanted = (uint64_t)__popcll(m_i);
             chunk_next += (wanted < avail) ? wanted : avail;
             if (take) {
@@ -748,6 +763,7 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk_packet(const Fra
                     if (live) {
                         const float tclosest = (h.y != kNoNode) ? __uint_as_float(h.x) : kFarAway;
                         o = eye + scale((double)tclosest, primary_direction(P, px, py));
+                        const Light &shadow_light = P.lights[light_index];
                         d = (shadow_light.type == CTGPU_LIGHT_POINT) ? load_d3(shadow_light.position) - o
                                                                      : load_d3(shadow_light.direction);
                     }
@@ -757,9 +773,8 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk_packet(const Fra
                     slot = kNoNode;
                     const d3 inv = make_d3(quick_reciprocal(d.x), quick_reciprocal(d.y), quick_reciprocal(d.z));
                     rf = ray_filter(o, d, inv, P.plane_bound);
-                    ray_id = id;
+                    if (KIND == 1) ray_id = id;
                     has_ray = true;
-                    n_traced += 1;
                     // root box (bvh.cpp:205 at rootNodeIdx)
                     float tmin, tmax;
                     slab_approx(o, inv, P.root_min, P.root_max, tmin, tmax);
@@ -771,6 +786,7 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk_packet(const Fra
             }
             if (KIND == 0) break;          // primary packets: one aligned run of 64 samples, no top-up
         }
+        n_traced += (uint32_t)__popcll(__ballot(has_ray));
         if (__ballot(has_ray) == 0ull) {
             if (wave_drained) break;
             continue;
@@ -779,7 +795,7 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk_packet(const Fra
         // lanes still tracing (a shadow ray stops at its first hit, raythread.cpp:303-307); every
         // lane mask below is wave-uniform and stays inside it
         unsigned long long tracing = __ballot(has_ray);
-        uint32_t cur = P.root_ref;
+        uint32_t cur = P.quad_root;
         unsigned long long mask = __ballot(root_pass);
         uint32_t sp = 0;
 #ifdef CT_SKIP_WALK                        // diagnostic build: time ray set-up and retirement alone
@@ -791,7 +807,7 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk_packet(const Fra
             if (cur & kLeafBit) {
                 // leaf: every triangle in index order, each lane keeps its own closest hit
                 const uint32_t first = cur & ~kLeafBit;
-                const bool mine = (mask & lane_bit) != 0ull;
+                const bool mine = __builtin_amdgcn_inverse_ballot_w64(mask);
                 PK_T0();
                 uint32_t count = 1;        // the first record says how many the leaf holds
                 for (uint32_t k = 0; k < count; k++) {
@@ -818,66 +834,82 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk_packet(const Fra
                 PK_COUNT(0, 1);
                 PK_COUNT(1, __popcll(mask));
                 const uint32_t node_id = cur;
-                const ScalarNode32 sf = scalar_load_node32(P.nodes32 + node_id);
+                const ScalarQuad sq = scalar_load_quad(P.quads + node_id);
                 // level 0: binary32 planes, verdicts with an error bound.  Every lane computes (the
                 // masked-out ones on stale rays, harmlessly) and the verdicts leave the vector unit
                 // as wave masks: no per-lane flag crosses a branch.
-                const float lmin[3] = {sf.f32(0), sf.f32(1), sf.f32(2)}, lmax[3] = {sf.f32(3), sf.f32(4), sf.f32(5)};
-                const float rmin[3] = {sf.f32(6), sf.f32(7), sf.f32(8)}, rmax[3] = {sf.f32(9), sf.f32(10), sf.f32(11)};
-                float ltmin, ltmax, rtmin, rtmax, lleast, lmargin, rleast, rmargin;
-                slab_f32(rf, lmin, lmax, ltmin, ltmax);
-                slab_f32(rf, rmin, rmax, rtmin, rtmax);
-                box_verdict_f32(ltmin, ltmax, rf.e, t, lleast, lmargin);
-                box_verdict_f32(rtmin, rtmax, rf.e, t, rleast, rmargin);
-                const unsigned long long l_yes = __ballot(lleast > lmargin), l_no = __ballot(lleast < -lmargin);
-                const unsigned long long r_yes = __ballot(rleast > rmargin), r_no = __ballot(rleast < -rmargin);
-                unsigned long long lm = l_yes & mask, rm = r_yes & mask;
-                const unsigned long long unsure = mask & ~((l_yes | l_no) & (r_yes | r_no));
+                float tmin[4];
+                unsigned long long enter[4], unsure_of[4], unsure = 0ull;
+                const uint32_t n_entries = sq.count();
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    float tmax, least, margin;
+                    slab_pairs_f32(rf, sq.planes(k, 0), sq.planes(k, 1), sq.planes(k, 2), tmin[k], tmax);
+                    box_verdict_f32(tmin[k], tmax, rf.inv_z_e2.y, t, least, margin);
+                    const unsigned long long yes = __ballot(least > margin), no = __ballot(least < -margin);
+                    const bool used = (uint32_t)k < n_entries;
+                    enter[k] = used ? (yes & mask) : 0ull;
+                    unsure_of[k] = used ? (mask & ~(yes | no)) : 0ull;
+                    unsure |= unsure_of[k];
+                }
                 if (unsure != 0ull) {
                     PK_COUNT(4, 1);
                     // level 1 (some lane sits inside the bound): binary64 planes, one-step margins;
-                    // level 2 (rarer still): the reference's divisions
-                    const ScalarNode sn = scalar_load_node(P.nodes + node_id);
-                    bool lpass = false, rpass = false;
-                    if ((unsure & lane_bit) != 0ull) {
-                        const double lmin[3] = {sn.f64(0), sn.f64(1), sn.f64(2)}, lmax[3] = {sn.f64(3), sn.f64(4), sn.f64(5)};
-                        const double rmin[3] = {sn.f64(6), sn.f64(7), sn.f64(8)}, rmax[3] = {sn.f64(9), sn.f64(10), sn.f64(11)};
-                        const d3 inv = make_d3(quick_reciprocal(d.x), quick_reciprocal(d.y), quick_reciprocal(d.z));
-                        float ltmin, ltmax, rtmin64, rtmax;
-                        slab_approx(o, inv, lmin, lmax, ltmin, ltmax);
-                        slab_approx(o, inv, rmin, rmax, rtmin64, rtmax);
-                        const bool sure = box_verdict_positive_t(ltmin, ltmax, t, lpass) & box_verdict_positive_t(rtmin64, rtmax, t, rpass);
-                        if (!(sure & direction_allows_fast_slab(d))) {
-                            slab(o, d, lmin, lmax, ltmin, ltmax);
-                            slab(o, d, rmin, rmax, rtmin64, rtmax);
-                            lpass = ltmax >= ltmin && ltmin < t && ltmax > 0;
-                            rpass = rtmax >= rtmin64 && rtmin64 < t && rtmax > 0;
+                    // level 2 (rarer still): the reference's divisions.  One box at a time, planes by
+                    // vector load: this path is rare and must stay light on registers (it would
+                    // otherwise set the kernel's occupancy).
+                    uint32_t todo = 0u, passed = 0u;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) todo |= __builtin_amdgcn_inverse_ballot_w64(unsure_of[k]) ? (1u << k) : 0u;
+                    if (todo != 0u) {
+                        const bool fast = direction_allows_fast_slab(d);
+#pragma nounroll
+                        for (uint32_t k = 0; k < n_entries; k++) {
+                            if (((todo >> k) & 1u) == 0u) continue;
+                            const uint32_t source = P.quad_source[node_id * 4u + k];
+                            const double *bmin = P.nodes[source >> 1].lmin + (source & 1u) * 6u, *bmax = bmin + 3;
+                            const d3 inv = make_d3(quick_reciprocal(d.x), quick_reciprocal(d.y), quick_reciprocal(d.z));
+                            float tmin64, tmax64;
+                            bool pass;
+                            slab_approx(o, inv, bmin, bmax, tmin64, tmax64);
+                            if (!(box_verdict_positive_t(tmin64, tmax64, t, pass) & fast)) {
+                                slab_in_sequence(o, d, bmin, bmax, tmin64, tmax64);
+                                pass = tmax64 >= tmin64 && tmin64 < t && tmax64 > 0;
+                            }
+                            passed |= pass ? (1u << k) : 0u;
                         }
                     }
-                    lm = (lm & ~unsure) | __ballot(lpass);
-                    rm = (rm & ~unsure) | __ballot(rpass);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) enter[k] = (enter[k] & ~unsure_of[k]) | __ballot(((passed >> k) & 1u) != 0u);
                 }
-                const uint32_t lref = sf.lref(), rref = sf.rref();
                 PK_T1(0);
-                if (lm != 0ull && rm != 0ull) {
-                    // the right child waits; each lane's `tmin < ray.t` is re-evaluated when it is popped
-                    if (sp >= depth) { atomicOr(P.overflow, 1u); break; }
-                    if (lane == 0) {
-                        st.ref[sp] = rref;
-                        st.parent[sp] = node_id;
-                        st.mask_lo[sp] = (uint32_t)rm;
-                        st.mask_hi[sp] = (uint32_t)(rm >> 32);
+                // the first entry some lane enters comes next; later ones wait on the stack (last
+                // first), each lane's `tmin < ray.t` re-evaluated when the entry is popped
+                const uint32_t first_entry = enter[0] ? 0u : enter[1] ? 1u : enter[2] ? 2u : enter[3] ? 3u : 4u;
+                bool overflow = false;
+#pragma unroll
+                for (int k = 3; k >= 1; k--) {
+                    if ((uint32_t)k > first_entry && enter[k] != 0ull) {
+                        if (sp >= depth) { overflow = true; break; }
+                        if (lane == 0) {
+                            st.ref[sp] = sq.ref(k);
+                            st.parent[sp] = node_id * 4u + (uint32_t)k;
+                            st.mask_lo[sp] = (uint32_t)enter[k];
+                            st.mask_hi[sp] = (uint32_t)(enter[k] >> 32);
+                        }
+                        st.put_tmin(sp, lane, tmin[k]);
+                        sp += 1;
                     }
-                    st.put_tmin(sp, lane, rtmin);
-                    sp += 1;
-                    cur = lref; mask = lm;
+                }
+                if (overflow) { atomicOr(P.overflow, 1u); break; }
+                if (first_entry < 4u) {
+                    cur = first_entry == 0u ? sq.ref(0) : first_entry == 1u ? sq.ref(1) : first_entry == 2u ? sq.ref(2) : sq.ref(3);
+                    mask = first_entry == 0u ? enter[0] : first_entry == 1u ? enter[1] : first_entry == 2u ? enter[2] : enter[3];
                     continue;
                 }
-                if (lm != 0ull) { cur = lref; mask = lm; continue; }
-                if (rm != 0ull) { cur = rref; mask = rm; continue; }
                 mask = 0ull;
             }
-            // ---------------- pop: next pending right child some lane still wants
+            // ---------------- pop: next pending entry some lane still wants
             while (mask == 0ull && sp > 0) {
                 PK_T0();
                 PK_COUNT(5, 1);
@@ -888,13 +920,14 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk_packet(const Fra
                 const unsigned long long pushed = ((unsigned long long)pushed_lo | ((unsigned long long)pushed_hi << 32)) & tracing;
                 if (pushed == 0ull) continue;
                 bool keep = false;
-                if ((pushed & lane_bit) != 0ull) {
+                if (__builtin_amdgcn_inverse_ballot_w64(pushed)) {
                     const float tmin = st.get_tmin(sp, lane);          // the filter's tmin, good to M(tmin)
-                    if (!deferred_verdict_f32(tmin, rf.e, t, keep)) {
+                    if (!deferred_verdict_f32(tmin, rf.noi_z_e.y, t, keep)) {
                         // too close to ray.t to trust: the whole test, exactly
-                        const WideNode *pn = P.nodes + st.parent[sp];
+                        const uint32_t source = P.quad_source[st.parent[sp]];
+                        const double *bmin = P.nodes[source >> 1].lmin + (source & 1u) * 6u;
                         float etmin, etmax;
-                        slab(o, d, pn->rmin, pn->rmax, etmin, etmax);
+                        slab_in_sequence(o, d, bmin, bmin + 3, etmin, etmax);
                         keep = etmax >= etmin && etmin < t && etmax > 0;
                     }
                 }
@@ -906,7 +939,7 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk_packet(const Fra
 
         // ---------------- retire the packet
         if (has_ray) {
-            if (KIND == 0) W.hits[ray_id] = make_uint2(__float_as_uint(t), slot);
+            if (KIND == 0) W.hits[packet_base + lane] = make_uint2(__float_as_uint(t), slot);
             else if (t != kNoHit) W.shadow[ray_id] = 1;
         }
     }
@@ -918,7 +951,6 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk_packet(const Fra
         atomicAdd(&P.counters[14], __builtin_amdgcn_s_memtime() - pk_begin);
     }
 #endif
-    for (int off = 32; off > 0; off >>= 1) n_traced += __shfl_down(n_traced, off);
     if (lane == 0) atomicAdd(&P.counters[KIND == 0 ? 0 : 1], (unsigned long long)n_traced);
 }
 
@@ -1019,7 +1051,7 @@ void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hip
     if (W.packet && ss) {
         const uint32_t slots = (uint32_t)(W.n_samples / 16u);
         const uint32_t blocks = (slots + 255u) / 256u;
-        const uint32_t depth_p = W.lds_depth + W.spill_depth;
+        const uint32_t depth_p = W.packet_depth;
         const size_t lds_p = PacketStack::bytes(depth_p, W.packet_lds_levels < depth_p ? W.packet_lds_levels : depth_p);
         if (W.n_samples == 0) return;
         hipLaunchKernelGGL(ct_sample_grid, dim3(blocks), dim3(256), 0, stream, P, W);

@@ -67,7 +67,9 @@ struct ctgpu_ctx {
     double root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
 
     DeviceArray<WideNode> nodes;
-    DeviceArray<NodeF32> nodes32;
+    DeviceArray<QuadNode> quads;
+    DeviceArray<uint32_t> quad_source;
+    uint32_t quad_root = 0, quad_pending = 1;
     float plane_bound[3] = {0, 0, 0};
     DeviceArray<TriRecord> tris;
     DeviceArray<Material> materials;
@@ -193,7 +195,7 @@ extern "C" void ctgpu_destroy(ctgpu_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    ctx->nodes.release(); ctx->tris.release(); ctx->materials.release(); ctx->lights.release();
+    ctx->nodes.release(); ctx->quads.release(); ctx->quad_source.release(); ctx->tris.release(); ctx->materials.release(); ctx->lights.release();
     ctx->tiles.release(); ctx->fb.release(); ctx->gathered.release(); ctx->counters.release(); ctx->overflow.release();
     ctx->rand_table.release(); ctx->row_ordinal.release();
     ctx->coords.release(); ctx->hits.release(); ctx->shadow.release(); ctx->queue.release(); ctx->spill.release();
@@ -250,9 +252,7 @@ extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
         w.rref = child_ref(n.left + 1);
     }
 
-    // binary32 copy of the planes for the packet walk's filter, and the bound its error term needs
-    std::vector<NodeF32> narrow(wide.size());
-    std::memset(narrow.data(), 0, narrow.size() * sizeof(NodeF32));
+    // ---- the folded tree of the packet walk (QuadNode, ct_device.h) and the bound its filter needs
     double bound[3] = {0, 0, 0};
     bool bound_ok = true;
     for (uint32_t i = 0; i < M; i++) {
@@ -265,15 +265,67 @@ extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
     }
     for (int c = 0; c < 3; c++)
         ctx->plane_bound[c] = bound_ok ? std::nextafterf((float)bound[c], INFINITY) : INFINITY;
-    for (size_t i = 0; i < wide.size(); i++) {
-        const WideNode &w = wide[i];
-        NodeF32 &f = narrow[i];
-        for (int c = 0; c < 3; c++) {
-            f.lmin[c] = (float)w.lmin[c]; f.lmax[c] = (float)w.lmax[c];
-            f.rmin[c] = (float)w.rmin[c]; f.rmax[c] = (float)w.rmax[c];
+
+    // an inner node may be folded into its parent's QuadNode when its children's boxes lie inside its own
+    auto folds = [&](uint32_t id) {
+        const ctgpu_node &c = s->nodes[id];
+        if (c.count) return false;
+        for (uint32_t side = 0; side < 2; side++) {
+            const ctgpu_node &g = s->nodes[c.left + side];
+            for (int a = 0; a < 3; a++)
+                if (!(g.bmin[a] >= c.bmin[a] && g.bmax[a] <= c.bmax[a])) return false;
         }
-        f.lref = w.lref; f.rref = w.rref;
+        return true;
+    };
+    std::vector<QuadNode> quads;
+    std::vector<uint32_t> quad_source;
+    std::vector<uint32_t> quad_of(M, kNoNode), quad_head;          // reference node heading each QuadNode
+    auto quad_for = [&](uint32_t id) {
+        if (quad_of[id] == kNoNode) {
+            quad_of[id] = (uint32_t)quad_head.size();
+            quad_head.push_back(id);
+        }
+        return quad_of[id];
+    };
+    uint32_t quad_root = kLeafBit | 0u;
+    if (s->nodes[0].count == 0) quad_root = quad_for(0);
+    for (size_t q = 0; q < quad_head.size(); q++) {                 // quad_head grows while we go
+        const uint32_t head = quad_head[q];
+        QuadNode node;
+        std::memset(&node, 0, sizeof node);
+        uint32_t source[4] = {0, 0, 0, 0};
+        auto add = [&](uint32_t id, uint32_t parent, uint32_t side) {
+            const ctgpu_node &e = s->nodes[id];
+            const uint32_t k = node.count++;
+            for (int a = 0; a < 3; a++) { node.plane[k][a][0] = (float)e.bmin[a]; node.plane[k][a][1] = (float)e.bmax[a]; }
+            node.ref[k] = e.count ? (kLeafBit | e.first) : quad_for(id);
+            source[k] = wide_of[parent] * 2u + side;
+        };
+        for (uint32_t side = 0; side < 2; side++) {
+            const uint32_t c = s->nodes[head].left + side;
+            if (folds(c)) { add(s->nodes[c].left, c, 0); add(s->nodes[c].left + 1, c, 1); }
+            else add(c, head, side);
+        }
+        quads.push_back(node);
+        quad_source.insert(quad_source.end(), source, source + 4);
     }
+    // most entries ever waiting on the packet walk's stack: along a path, every QuadNode leaves count-1 behind
+    uint32_t quad_pending = 1;
+    if (!quads.empty()) {
+        std::vector<std::pair<uint32_t, uint32_t>> todo;
+        todo.push_back({quad_root, 0u});
+        size_t steps = 0;
+        while (!todo.empty()) {
+            const auto [q, before] = todo.back();
+            todo.pop_back();
+            if (++steps > quads.size()) return fail(CTGPU_ERR_ARG, "node links form a cycle");
+            const QuadNode &node = quads[q];
+            quad_pending = std::max(quad_pending, before + node.count - 1u);
+            for (uint32_t k = 0; k < node.count; k++)
+                if (!(node.ref[k] & kLeafBit)) todo.push_back({node.ref[k], before + node.count - 1u - k});
+        }
+    }
+    if (quads.empty()) { quads.emplace_back(); std::memset(&quads[0], 0, sizeof(QuadNode)); quad_source.assign(4, 0u); }
 
     // leaf-ordered triangle records; a tree walk gives depth and the leaf extents
     std::vector<TriRecord> recs(N);
@@ -322,8 +374,12 @@ extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
     HIP_TRY(ctx->materials.resize(N));
     HIP_TRY(ctx->lights.resize(std::max<uint32_t>(s->n_lights, 1)));
     HIP_TRY(hipMemcpy(ctx->nodes.ptr, wide.data(), wide.size() * sizeof(WideNode), hipMemcpyHostToDevice));
-    HIP_TRY(ctx->nodes32.resize(narrow.size()));
-    HIP_TRY(hipMemcpy(ctx->nodes32.ptr, narrow.data(), narrow.size() * sizeof(NodeF32), hipMemcpyHostToDevice));
+    HIP_TRY(ctx->quads.resize(quads.size()));
+    HIP_TRY(hipMemcpy(ctx->quads.ptr, quads.data(), quads.size() * sizeof(QuadNode), hipMemcpyHostToDevice));
+    HIP_TRY(ctx->quad_source.resize(quad_source.size()));
+    HIP_TRY(hipMemcpy(ctx->quad_source.ptr, quad_source.data(), quad_source.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    ctx->quad_root = quad_root;
+    ctx->quad_pending = quad_pending;
     HIP_TRY(hipMemcpy(ctx->tris.ptr, recs.data(), (size_t)N * sizeof(TriRecord), hipMemcpyHostToDevice));
     static_assert(sizeof(Material) == sizeof(ctgpu_material), "material layout");
     static_assert(sizeof(Light) == sizeof(ctgpu_light), "light layout");
@@ -409,7 +465,7 @@ int fill_params(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, const ctgpu_partition
                 FrameParams &P) {
     const Geometry g = geometry(f);
     std::memset(&P, 0, sizeof P);
-    P.nodes = ctx->nodes.ptr; P.nodes32 = ctx->nodes32.ptr; P.tris = ctx->tris.ptr; P.materials = ctx->materials.ptr; P.lights = ctx->lights.ptr;
+    P.nodes = ctx->nodes.ptr; P.quads = ctx->quads.ptr; P.quad_source = ctx->quad_source.ptr; P.quad_root = ctx->quad_root; P.tris = ctx->tris.ptr; P.materials = ctx->materials.ptr; P.lights = ctx->lights.ptr;
     P.n_lights = ctx->n_lights;
     P.root_ref = ctx->root_ref;
     P.slot_of_triangle0 = ctx->slot_of_triangle0;
@@ -522,9 +578,10 @@ int launch_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, FrameParams &P, hipS
     W.spill_depth = std::max<uint32_t>(ctx->tree_depth, 1) - W.lds_depth;
     const size_t lds_bytes = (size_t)W.lds_depth * 64 * 12;
     W.packet = (ctx->packet_walk && ss) ? 1u : 0u;
-    W.packet_lds_levels = (uint32_t)ctx->packet_lds_levels;
+    W.packet_depth = ctx->quad_pending;
+    W.packet_lds_levels = std::min<uint32_t>((uint32_t)ctx->packet_lds_levels, W.packet_depth);
     int per_cu = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu
-                                        : (W.packet ? pipeline_packet_occupancy(W.lds_depth + W.spill_depth, std::min<uint32_t>((uint32_t)ctx->packet_lds_levels, W.lds_depth + W.spill_depth))
+                                        : (W.packet ? pipeline_packet_occupancy(W.packet_depth, W.packet_lds_levels)
                                                     : pipeline_walk_occupancy(lds_bytes));
     if (per_cu < 1) per_cu = 1;
     const uint64_t waves_needed = (W.n_samples + 63) / 64;
@@ -541,7 +598,7 @@ int launch_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, FrameParams &P, hipS
     HIP_TRY(ctx->hits.resize(W.n_samples));
     HIP_TRY(ctx->shadow.resize(W.n_samples * std::max<uint32_t>(W.n_shadow_lights, 1)));
     if (W.n_samples >= 0xfffffff0ull) return fail(CTGPU_ERR_ARG, "frame too large: %llu samples", (unsigned long long)W.n_samples);
-    HIP_TRY(ctx->spill.resize((size_t)W.walk_blocks * (size_t)(W.lds_depth + W.spill_depth) * 64 * 12 / 8 + 64));
+    HIP_TRY(ctx->spill.resize((size_t)W.walk_blocks * (size_t)std::max(W.lds_depth + W.spill_depth, W.packet_depth) * 64 * 12 / 8 + 64));
     W.coords = ctx->coords.ptr; W.hits = ctx->hits.ptr; W.shadow = ctx->shadow.ptr;
     W.queue = ctx->queue.ptr; W.spill = ctx->spill.ptr; W.shadow_lights = ctx->shadow_lights.ptr;
     HIP_TRY(hipMemsetAsync(ctx->queue.ptr, 0, 33 * 8 * 16 * sizeof(unsigned long long), stream));
