@@ -645,16 +645,15 @@ __device__ __forceinline__ ScalarTri scalar_load_tri(const TriRecord *t) {
     return r;
 }
 
+// LDS / HBM part of the packet walk's stack (the wave-uniform {entry reference, lane mask} of each
+// level sit in vector registers, see ct_walk_packet; at most 64 levels)
 struct PacketStack {
-    LdsWord *ref;          // [depth]      child reference
     LdsWord *parent;       // [depth]      QuadNode * 4 + entry the box belongs to (exact re-test at pop)
-    LdsWord *mask_lo;      // [depth]      lanes that passed the child's box when it was pushed
-    LdsWord *mask_hi;      // [depth]
     float __attribute__((address_space(3))) *tmin;        // [lds_levels][64] approximate tmin per lane
     float __attribute__((address_space(1))) *tmin_spill;  // [depth - lds_levels][64] deeper levels, in HBM
     uint32_t lds_levels;
     static __host__ __device__ size_t bytes(uint32_t depth, uint32_t lds_levels) {
-        return (size_t)depth * 16u + (size_t)lds_levels * 256u;
+        return (size_t)((depth + 3u) & ~3u) * 4u + (size_t)lds_levels * 256u;
     }
     __device__ __forceinline__ void put_tmin(uint32_t level, uint32_t lane, float v) const {
         if (level < lds_levels) tmin[level * kWave + lane] = v;
@@ -671,11 +670,8 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const uint32_t depth = W.packet_depth;                      // most entries the folded tree leaves pending
     PacketStack st;
-    st.ref = (LdsWord *)lds_raw;
-    st.parent = st.ref + depth;
-    st.mask_lo = st.parent + depth;
-    st.mask_hi = st.mask_lo + depth;
-    st.tmin = (float __attribute__((address_space(3))) *)(st.mask_hi + depth);
+    st.parent = (LdsWord *)lds_raw;
+    st.tmin = (float __attribute__((address_space(3))) *)(st.parent + ((depth + 3u) & ~3u));
     st.lds_levels = W.packet_lds_levels < depth ? W.packet_lds_levels : depth;
     st.tmin_spill = (float __attribute__((address_space(1))) *)(reinterpret_cast<unsigned char *>(W.spill) +
                                                                 (size_t)blockIdx.x * depth * kWave * 12u);
@@ -691,7 +687,9 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
     uint32_t light_index = 0;                // lights[] entry of the shadow rays in the current chunk
     const d3 eye = make_d3(P.cam[0], P.cam[1], P.cam[2]);
 
-    d3 o = eye, d = make_d3(0, 0, 1);
+    // ray origin: the eye for every primary ray (kept in scalar registers), per lane for shadow rays
+    d3 shadow_o = eye, d = make_d3(0, 0, 1);
+#define RAY_O (KIND == 0 ? eye : shadow_o)
     RayFilter rf = RayFilter{};
     float t = kNoHit;
     uint32_t slot = kNoNode;
@@ -755,16 +753,16 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                 float px, py;
                 bool live = sample_position<true>(P, W, sample, px, py);
                 if (KIND == 0) {
-                    if (live) { o = eye; d = primary_direction(P, px, py); }
+                    if (live) d = primary_direction(P, px, py);
                     else W.hits[id] = make_uint2(__float_as_uint(kNoHit), kInvalidSample);
                 } else if (live) {
                     const uint2 h = W.hits[sample];
                     live = __uint_as_float(h.x) != kNoHit;
                     if (live) {
                         const float tclosest = (h.y != kNoNode) ? __uint_as_float(h.x) : kFarAway;
-                        o = eye + scale((double)tclosest, primary_direction(P, px, py));
+                        shadow_o = eye + scale((double)tclosest, primary_direction(P, px, py));
                         const Light &shadow_light = P.lights[light_index];
-                        d = (shadow_light.type == CTGPU_LIGHT_POINT) ? load_d3(shadow_light.position) - o
+                        d = (shadow_light.type == CTGPU_LIGHT_POINT) ? load_d3(shadow_light.position) - shadow_o
                                                                      : load_d3(shadow_light.direction);
                     }
                 }
@@ -772,14 +770,14 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                     t = kNoHit;
                     slot = kNoNode;
                     const d3 inv = make_d3(quick_reciprocal(d.x), quick_reciprocal(d.y), quick_reciprocal(d.z));
-                    rf = ray_filter(o, d, inv, P.plane_bound);
+                    rf = ray_filter(RAY_O, d, inv, P.plane_bound);
                     if (KIND == 1) ray_id = id;
                     has_ray = true;
                     // root box (bvh.cpp:205 at rootNodeIdx)
                     float tmin, tmax;
-                    slab_approx(o, inv, P.root_min, P.root_max, tmin, tmax);
+                    slab_approx(RAY_O, inv, P.root_min, P.root_max, tmin, tmax);
                     if (!(box_verdict_positive_t(tmin, tmax, t, root_pass) & direction_allows_fast_slab(d))) {
-                        slab(o, d, P.root_min, P.root_max, tmin, tmax);
+                        slab(RAY_O, d, P.root_min, P.root_max, tmin, tmax);
                         root_pass = tmax >= tmin && tmin < t && tmax > 0;
                     }
                 }
@@ -798,6 +796,9 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
         uint32_t cur = P.quad_root;
         unsigned long long mask = __ballot(root_pass);
         uint32_t sp = 0;
+        // the wave-uniform part of the stack lives in three vector registers, entry i in lane i
+        // (read back with v_readlane, the level as lane select): no LDS round trip on a pop
+        int stack_ref = 0, stack_mask_lo = 0, stack_mask_hi = 0;
 #ifdef CT_SKIP_WALK                        // diagnostic build: time ray set-up and retirement alone
         if (KIND == CT_SKIP_WALK) mask = 0ull;
 #endif
@@ -821,7 +822,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                         const d3 p1 = make_d3(tr.f64(0), tr.f64(1), tr.f64(2)), e1 = make_d3(tr.f64(3), tr.f64(4), tr.f64(5)),
                                  e2 = make_d3(tr.f64(6), tr.f64(7), tr.f64(8));
                         const float before = t;
-                        const bool hit = triangle_test(o, d, t, p1, e1, e2);
+                        const bool hit = triangle_test(RAY_O, d, t, p1, e1, e2);
                         const float tclosest = (slot != kNoNode) ? before : kFarAway;      // bvh.cpp:212-215
                         if (hit && t != kNoHit && t < tclosest) slot = first + k;
                     }
@@ -871,9 +872,9 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                             const d3 inv = make_d3(quick_reciprocal(d.x), quick_reciprocal(d.y), quick_reciprocal(d.z));
                             float tmin64, tmax64;
                             bool pass;
-                            slab_approx(o, inv, bmin, bmax, tmin64, tmax64);
+                            slab_approx(RAY_O, inv, bmin, bmax, tmin64, tmax64);
                             if (!(box_verdict_positive_t(tmin64, tmax64, t, pass) & fast)) {
-                                slab_in_sequence(o, d, bmin, bmax, tmin64, tmax64);
+                                slab_in_sequence(RAY_O, d, bmin, bmax, tmin64, tmax64);
                                 pass = tmax64 >= tmin64 && tmin64 < t && tmax64 > 0;
                             }
                             passed |= pass ? (1u << k) : 0u;
@@ -891,12 +892,11 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                 for (int k = 3; k >= 1; k--) {
                     if ((uint32_t)k > first_entry && enter[k] != 0ull) {
                         if (sp >= depth) { overflow = true; break; }
-                        if (lane == 0) {
-                            st.ref[sp] = sq.ref(k);
-                            st.parent[sp] = node_id * 4u + (uint32_t)k;
-                            st.mask_lo[sp] = (uint32_t)enter[k];
-                            st.mask_hi[sp] = (uint32_t)(enter[k] >> 32);
-                        }
+                        const bool level = lane == sp;       // (v_writelane cannot take value and lane select from two scalar registers)
+                        stack_ref = level ? (int)sq.ref(k) : stack_ref;
+                        stack_mask_lo = level ? (int)(uint32_t)enter[k] : stack_mask_lo;
+                        stack_mask_hi = level ? (int)(uint32_t)(enter[k] >> 32) : stack_mask_hi;
+                        if (lane == 0) st.parent[sp] = node_id * 4u + (uint32_t)k;       // read on the exact path only
                         st.put_tmin(sp, lane, tmin[k]);
                         sp += 1;
                     }
@@ -914,9 +914,8 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                 PK_T0();
                 PK_COUNT(5, 1);
                 sp -= 1;
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                const uint32_t pushed_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.mask_lo[sp]);
-                const uint32_t pushed_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.mask_hi[sp]);
+                const uint32_t pushed_lo = (uint32_t)__builtin_amdgcn_readlane(stack_mask_lo, (int)sp);
+                const uint32_t pushed_hi = (uint32_t)__builtin_amdgcn_readlane(stack_mask_hi, (int)sp);
                 const unsigned long long pushed = ((unsigned long long)pushed_lo | ((unsigned long long)pushed_hi << 32)) & tracing;
                 if (pushed == 0ull) continue;
                 bool keep = false;
@@ -924,15 +923,16 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                     const float tmin = st.get_tmin(sp, lane);          // the filter's tmin, good to M(tmin)
                     if (!deferred_verdict_f32(tmin, rf.noi_z_e.y, t, keep)) {
                         // too close to ray.t to trust: the whole test, exactly
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                         const uint32_t source = P.quad_source[st.parent[sp]];
                         const double *bmin = P.nodes[source >> 1].lmin + (source & 1u) * 6u;
                         float etmin, etmax;
-                        slab_in_sequence(o, d, bmin, bmin + 3, etmin, etmax);
+                        slab_in_sequence(RAY_O, d, bmin, bmin + 3, etmin, etmax);
                         keep = etmax >= etmin && etmin < t && etmax > 0;
                     }
                 }
                 mask = __ballot(keep);
-                cur = (uint32_t)__builtin_amdgcn_readfirstlane((int)st.ref[sp]);
+                cur = (uint32_t)__builtin_amdgcn_readlane(stack_ref, (int)sp);
                 PK_T1(2);
             }
         }
@@ -953,6 +953,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
 #endif
     if (lane == 0) atomicAdd(&P.counters[KIND == 0 ? 0 : 1], (unsigned long long)n_traced);
 }
+#undef RAY_O
 
 // ------------------------------------------------------------------------------------
 // ct_shade: lighting of every sample of a pixel in order, running blend, pixel store.
