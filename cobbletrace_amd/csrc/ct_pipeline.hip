@@ -105,30 +105,46 @@ __device__ __forceinline__ bool pixel_in_frame(const FrameParams &P, uint32_t xi
 // does, including the float add/subtract residue that carries from sample to sample.
 // ------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ct_sample_grid(const FrameParams P, const PipelineParams W) {
+    // the 16 positions of a pixel are a sequential chain, so a lane owns a pixel; they leave through
+    // LDS so that the block stores its 4096 positions as whole cache lines, not 8 bytes per line
+    __shared__ float stage_x[256 * 17], stage_y[256 * 17];              // row stride 17: conflict-free both ways
     const uint64_t pixel_slot = (uint64_t)blockIdx.x * 256u + threadIdx.x;      // id >> 4
-    if (pixel_slot * 16u >= W.n_samples) return;
-    const PixelOfSample px = pixel_of<true>(P, pixel_slot * 16u);
-    uint32_t yi;
-    if (!pixel_in_frame(P, px.xi, px.local_row, yi)) return;
-    const float fx = (float)((int)px.xi - P.half), fy = (float)((int)yi - P.half);
-    const float jitter = 0.25f / 8.0f;
-    float run_x = fx;
-    for (uint32_t xs = 0; xs < 4; xs++) {
-        float run_y = fy;
-        for (uint32_t ys = 0; ys < 4; ys++) {
-            const uint32_t s = xs * 4u + ys;
-            float jx = (float)jitter_int(P, px.xi, yi, s, 0) / 2147483648.0f;
-            float jy = (float)jitter_int(P, px.xi, yi, s, 1) / 2147483648.0f;
-            jx = (jx * (2.0f * jitter)) - jitter;
-            jy = (jy * (2.0f * jitter)) - jitter;
-            run_x += jx;
-            run_y += jy;
-            W.coords[pixel_slot * 16u + s] = make_float2(run_x, run_y);
-            run_y -= jy;
-            run_y += 0.25f;
-            run_x -= jx;
+    bool live = pixel_slot * 16u < W.n_samples;
+    PixelOfSample px = PixelOfSample{};
+    uint32_t yi = 0;
+    if (live) {
+        px = pixel_of<true>(P, pixel_slot * 16u);
+        live = pixel_in_frame(P, px.xi, px.local_row, yi);
+    }
+    if (live) {
+        const float fx = (float)((int)px.xi - P.half), fy = (float)((int)yi - P.half);
+        const float jitter = 0.25f / 8.0f;
+        float run_x = fx;
+        for (uint32_t xs = 0; xs < 4; xs++) {
+            float run_y = fy;
+            for (uint32_t ys = 0; ys < 4; ys++) {
+                const uint32_t s = xs * 4u + ys;
+                float jx = (float)jitter_int(P, px.xi, yi, s, 0) / 2147483648.0f;
+                float jy = (float)jitter_int(P, px.xi, yi, s, 1) / 2147483648.0f;
+                jx = (jx * (2.0f * jitter)) - jitter;
+                jy = (jy * (2.0f * jitter)) - jitter;
+                run_x += jx;
+                run_y += jy;
+                stage_x[threadIdx.x * 17u + s] = run_x;
+                stage_y[threadIdx.x * 17u + s] = run_y;
+                run_y -= jy;
+                run_y += 0.25f;
+                run_x -= jx;
+            }
+            run_x += 0.25f;
         }
-        run_x += 0.25f;
+    }
+    __syncthreads();
+    const uint64_t block_first = (uint64_t)blockIdx.x * 4096u;
+    for (uint32_t j = 0; j < 16; j++) {
+        const uint32_t local = j * 256u + threadIdx.x;                  // sample within the block
+        const uint64_t id = block_first + local;
+        if (id < W.n_samples) W.coords[id] = make_float2(stage_x[(local >> 4) * 17u + (local & 15u)], stage_y[(local >> 4) * 17u + (local & 15u)]);
     }
 }
 
@@ -960,63 +976,87 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
 // raythread.cpp:353-366 (TraceRay without reflection), 275-327 (ComputeLighting with the
 // shadow decisions read from the mask), 482-498 (blend), color.h.
 // ------------------------------------------------------------------------------------
+// colour of one sample from its closest hit and its shadow flags
+template <bool SS>
+__device__ __forceinline__ uint32_t shade_sample(const FrameParams &P, const PipelineParams &W, uint64_t id, uint32_t xi, uint32_t yi) {
+    const uint2 h = W.hits[id];
+    if (__uint_as_float(h.x) == kNoHit) return kBackground;
+    const d3 eye = make_d3(P.cam[0], P.cam[1], P.cam[2]);
+    float cx, cy;
+    if (SS) { const float2 c = W.coords[id]; cx = c.x; cy = c.y; }
+    else { cx = (float)((int)xi - P.half); cy = (float)((int)yi - P.half); }
+    const d3 dir = primary_direction(P, cx, cy);
+    const uint32_t rec_slot = (h.y != kNoNode) ? h.y : P.slot_of_triangle0;
+    const float tclosest = (h.y != kNoNode) ? __uint_as_float(h.x) : kFarAway;
+    const TriRecord *rec = P.tris + rec_slot;
+    const Material m = P.materials[rec->triangle];
+    const d3 position = eye + scale((double)tclosest, dir);
+    d3 normal = cross(load_d3(rec->e1), load_d3(rec->e2));
+    if (!(dotf(normal, dir) < 0)) normal = -normal;
+    const d3 view = -dir;
+
+    float intensity = 0.0f;
+    uint32_t shadow_slot = 0;
+    for (uint32_t li = 0; li < P.n_lights; li++) {
+        const Light L = P.lights[li];
+        d3 to_light;
+        if (L.type == CTGPU_LIGHT_AMBIENT) { intensity += L.intensity; continue; }
+        else if (L.type == CTGPU_LIGHT_POINT) to_light = load_d3(L.position) - position;
+        else if (L.type == CTGPU_LIGHT_DIRECTIONAL) to_light = load_d3(L.direction);
+        else continue;
+        const bool in_shadow = W.shadow[(size_t)shadow_slot * W.n_samples + id] != 0;
+        shadow_slot += 1;
+        if (in_shadow) continue;
+        const float n_dot_l = dotf(normal, to_light);
+        if (n_dot_l > 0) intensity += L.intensity * n_dot_l / (lengthf(normal) * lengthf(to_light));
+        if (m.specular != -1) {
+            const double nl = (double)dotf(normal, to_light);
+            const d3 reflected = scale(nl, scale(2.0, normal)) - to_light;
+            const float r_dot_v = dotf(reflected, view);
+            if (r_dot_v > 0) {
+                const float base = r_dot_v / (lengthf(reflected) * lengthf(view));
+                intensity = (float)((double)intensity + (double)L.intensity * pow((double)base, (double)m.specular));
+            }
+        }
+    }
+    return shade_value(m.color, intensity);
+}
+
 template <bool SS>
 __global__ __launch_bounds__(256) void ct_shade(const FrameParams P, const PipelineParams W) {
-    const uint64_t slot = (uint64_t)blockIdx.x * 256u + threadIdx.x;     // pixel slot: id >> 4 (SS) or id
-    const uint64_t first = SS ? slot * 16u : slot;
+    if (!SS) {
+        const uint64_t id = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+        if (id >= W.n_samples) return;
+        const PixelOfSample px = pixel_of<false>(P, id);
+        uint32_t yi;
+        if (!pixel_in_frame(P, px.xi, px.local_row, yi)) return;
+        P.out[(size_t)px.local_row * P.square + px.xi] = shade_sample<false>(P, W, id, px.xi, yi);
+        return;
+    }
+    // Supersampled: first one lane per SAMPLE (consecutive lanes read consecutive hit / position /
+    // shadow entries -- whole cache lines), colours parked in LDS; then one lane per PIXEL folds its
+    // 16 colours in order with the reference's running blend.
+    __shared__ uint32_t colour[256 * 17];                               // row stride 17: conflict-free both ways
+    const uint64_t block_first = (uint64_t)blockIdx.x * 4096u;
+    for (uint32_t j = 0; j < 16; j++) {
+        const uint32_t local = j * 256u + threadIdx.x;
+        const uint64_t id = block_first + local;
+        uint32_t c = kBackground;
+        if (id < W.n_samples) {
+            const PixelOfSample px = pixel_of<true>(P, id);
+            uint32_t yi;
+            if (pixel_in_frame(P, px.xi, px.local_row, yi)) c = shade_sample<true>(P, W, id, px.xi, yi);
+        }
+        colour[(local >> 4) * 17u + (local & 15u)] = c;
+    }
+    __syncthreads();
+    const uint64_t first = block_first + (uint64_t)threadIdx.x * 16u;
     if (first >= W.n_samples) return;
-    const PixelOfSample px = pixel_of<SS>(P, first);
+    const PixelOfSample px = pixel_of<true>(P, first);
     uint32_t yi;
     if (!pixel_in_frame(P, px.xi, px.local_row, yi)) return;
-    const d3 eye = make_d3(P.cam[0], P.cam[1], P.cam[2]);
-
-    uint32_t pixel_color = 0;
-    for (uint32_t s = 0; s < (SS ? 16u : 1u); s++) {
-        const uint64_t id = first + s;
-        const uint2 h = W.hits[id];
-        uint32_t color = kBackground;
-        if (__uint_as_float(h.x) != kNoHit) {
-            float cx, cy;
-            if (SS) { const float2 c = W.coords[id]; cx = c.x; cy = c.y; }
-            else { cx = (float)((int)px.xi - P.half); cy = (float)((int)yi - P.half); }
-            const d3 dir = primary_direction(P, cx, cy);
-            const uint32_t rec_slot = (h.y != kNoNode) ? h.y : P.slot_of_triangle0;
-            const float tclosest = (h.y != kNoNode) ? __uint_as_float(h.x) : kFarAway;
-            const TriRecord *rec = P.tris + rec_slot;
-            const Material m = P.materials[rec->triangle];
-            const d3 position = eye + scale((double)tclosest, dir);
-            d3 normal = cross(load_d3(rec->e1), load_d3(rec->e2));
-            if (!(dotf(normal, dir) < 0)) normal = -normal;
-            const d3 view = -dir;
-
-            float intensity = 0.0f;
-            uint32_t shadow_slot = 0;
-            for (uint32_t li = 0; li < P.n_lights; li++) {
-                const Light L = P.lights[li];
-                d3 to_light;
-                if (L.type == CTGPU_LIGHT_AMBIENT) { intensity += L.intensity; continue; }
-                else if (L.type == CTGPU_LIGHT_POINT) to_light = load_d3(L.position) - position;
-                else if (L.type == CTGPU_LIGHT_DIRECTIONAL) to_light = load_d3(L.direction);
-                else continue;
-                const bool in_shadow = W.shadow[(size_t)shadow_slot * W.n_samples + id] != 0;
-                shadow_slot += 1;
-                if (in_shadow) continue;
-                const float n_dot_l = dotf(normal, to_light);
-                if (n_dot_l > 0) intensity += L.intensity * n_dot_l / (lengthf(normal) * lengthf(to_light));
-                if (m.specular != -1) {
-                    const double nl = (double)dotf(normal, to_light);
-                    const d3 reflected = scale(nl, scale(2.0, normal)) - to_light;
-                    const float r_dot_v = dotf(reflected, view);
-                    if (r_dot_v > 0) {
-                        const float base = r_dot_v / (lengthf(reflected) * lengthf(view));
-                        intensity = (float)((double)intensity + (double)L.intensity * pow((double)base, (double)m.specular));
-                    }
-                }
-            }
-            color = shade_value(m.color, intensity);
-        }
-        pixel_color = (s == 0) ? color : blend_sample(pixel_color, color);
-    }
+    uint32_t pixel_color = colour[threadIdx.x * 17u];
+    for (uint32_t s = 1; s < 16; s++) pixel_color = blend_sample(pixel_color, colour[threadIdx.x * 17u + s]);
     P.out[(size_t)px.local_row * P.square + px.xi] = pixel_color;
 }
 
