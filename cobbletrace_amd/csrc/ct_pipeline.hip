@@ -681,7 +681,7 @@ struct PacketStack {
     }
 };
 
-template <int KIND>
+template <int KIND, bool SS>
 __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const FrameParams P, const PipelineParams W) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const uint32_t depth = W.packet_depth;                      // most entries the folded tree leaves pending
@@ -767,7 +767,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
             if (take) {
                 const uint64_t sample = id - light_base;
                 float px, py;
-                bool live = sample_position<true>(P, W, sample, px, py);
+                bool live = sample_position<SS>(P, W, sample, px, py);
                 if (KIND == 0) {
                     if (live) d = primary_direction(P, px, py);
                     else W.hits[id] = make_uint2(__float_as_uint(kNoHit), kInvalidSample);
@@ -1083,38 +1083,39 @@ int pipeline_walk_occupancy(size_t lds_bytes) {
 
 int pipeline_packet_occupancy(uint32_t depth, uint32_t lds_levels) {
     int a = 0, b = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, ct_walk_packet<0>, kWave, PacketStack::bytes(depth, lds_levels));
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, ct_walk_packet<1>, kWave, PacketStack::bytes(depth, lds_levels));
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, ct_walk_packet<0, true>, kWave, PacketStack::bytes(depth, lds_levels));
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, ct_walk_packet<1, true>, kWave, PacketStack::bytes(depth, lds_levels));
     return a < b ? a : b;
 }
 
 void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hipStream_t stream) {
-    if (W.packet && ss) {
-        const uint32_t slots = (uint32_t)(W.n_samples / 16u);
-        const uint32_t blocks = (slots + 255u) / 256u;
-        const uint32_t depth_p = W.packet_depth;
-        const size_t lds_p = PacketStack::bytes(depth_p, W.packet_lds_levels < depth_p ? W.packet_lds_levels : depth_p);
-        if (W.n_samples == 0) return;
-        hipLaunchKernelGGL(ct_sample_grid, dim3(blocks), dim3(256), 0, stream, P, W);
-        hipLaunchKernelGGL((ct_walk_packet<0>), dim3(W.walk_blocks), dim3(kWave), lds_p, stream, P, W);
-        if (W.n_shadow_lights) hipLaunchKernelGGL((ct_walk_packet<1>), dim3(W.walk_blocks), dim3(kWave), lds_p, stream, P, W);
-        hipLaunchKernelGGL((ct_shade<true>), dim3(blocks), dim3(256), 0, stream, P, W);
-        return;
-    }
-    const size_t lds = (size_t)W.lds_depth * kWave * 12u;      // entries + parent words
+    if (W.n_samples == 0) return;
     const uint32_t pixel_slots = (uint32_t)(ss ? W.n_samples / 16u : W.n_samples);
     const uint32_t pixel_blocks = (pixel_slots + 255u) / 256u;
-    if (W.n_samples == 0) return;
-    if (ss) {
-        hipLaunchKernelGGL(ct_sample_grid, dim3(pixel_blocks), dim3(256), 0, stream, P, W);
-        hipLaunchKernelGGL((ct_walk<0, true>), dim3(W.walk_blocks), dim3(kWave), lds, stream, P, W);
-        if (W.n_shadow_lights) hipLaunchKernelGGL((ct_walk<1, true>), dim3(W.walk_blocks), dim3(kWave), lds, stream, P, W);
-        hipLaunchKernelGGL((ct_shade<true>), dim3(pixel_blocks), dim3(256), 0, stream, P, W);
+    if (ss) hipLaunchKernelGGL(ct_sample_grid, dim3(pixel_blocks), dim3(256), 0, stream, P, W);
+    if (W.packet) {
+        // shared walk: a wave holds 2x2 pixels x 16 samples (supersampled) or an 8x8 pixel tile
+        const uint32_t depth_p = W.packet_depth;
+        const size_t lds_p = PacketStack::bytes(depth_p, W.packet_lds_levels < depth_p ? W.packet_lds_levels : depth_p);
+        if (ss) {
+            hipLaunchKernelGGL((ct_walk_packet<0, true>), dim3(W.walk_blocks), dim3(kWave), lds_p, stream, P, W);
+            if (W.n_shadow_lights) hipLaunchKernelGGL((ct_walk_packet<1, true>), dim3(W.walk_blocks), dim3(kWave), lds_p, stream, P, W);
+        } else {
+            hipLaunchKernelGGL((ct_walk_packet<0, false>), dim3(W.walk_blocks), dim3(kWave), lds_p, stream, P, W);
+            if (W.n_shadow_lights) hipLaunchKernelGGL((ct_walk_packet<1, false>), dim3(W.walk_blocks), dim3(kWave), lds_p, stream, P, W);
+        }
     } else {
-        hipLaunchKernelGGL((ct_walk<0, false>), dim3(W.walk_blocks), dim3(kWave), lds, stream, P, W);
-        if (W.n_shadow_lights) hipLaunchKernelGGL((ct_walk<1, false>), dim3(W.walk_blocks), dim3(kWave), lds, stream, P, W);
-        hipLaunchKernelGGL((ct_shade<false>), dim3(pixel_blocks), dim3(256), 0, stream, P, W);
+        const size_t lds = (size_t)W.lds_depth * kWave * 12u;      // entries + parent words
+        if (ss) {
+            hipLaunchKernelGGL((ct_walk<0, true>), dim3(W.walk_blocks), dim3(kWave), lds, stream, P, W);
+            if (W.n_shadow_lights) hipLaunchKernelGGL((ct_walk<1, true>), dim3(W.walk_blocks), dim3(kWave), lds, stream, P, W);
+        } else {
+            hipLaunchKernelGGL((ct_walk<0, false>), dim3(W.walk_blocks), dim3(kWave), lds, stream, P, W);
+            if (W.n_shadow_lights) hipLaunchKernelGGL((ct_walk<1, false>), dim3(W.walk_blocks), dim3(kWave), lds, stream, P, W);
+        }
     }
+    if (ss) hipLaunchKernelGGL((ct_shade<true>), dim3(pixel_blocks), dim3(256), 0, stream, P, W);
+    else hipLaunchKernelGGL((ct_shade<false>), dim3(pixel_blocks), dim3(256), 0, stream, P, W);
 }
 
 }  // namespace ctd

@@ -577,7 +577,7 @@ int launch_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, FrameParams &P, hipS
     W.lds_depth = std::min<uint32_t>((uint32_t)ctx->lds_depth, std::max<uint32_t>(ctx->tree_depth, 1));
     W.spill_depth = std::max<uint32_t>(ctx->tree_depth, 1) - W.lds_depth;
     const size_t lds_bytes = (size_t)W.lds_depth * 64 * 12;
-    W.packet = (ctx->packet_walk && ss && ctx->quad_pending <= 64u) ? 1u : 0u;     // stack levels are lanes of a register
+    W.packet = (ctx->packet_walk && ctx->quad_pending <= 64u) ? 1u : 0u;           // stack levels are lanes of a register
     W.packet_depth = ctx->quad_pending;
     W.packet_lds_levels = std::min<uint32_t>((uint32_t)ctx->packet_lds_levels, W.packet_depth);
     int per_cu = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu
