@@ -212,7 +212,7 @@ def main():
 
     out = None
     if rank == 0:
-        # ---- roofline of the dominant kernel (ct_trace_tiles): algorithmic bytes of ONE launch
+        # ---- roofline of the frame trace (ct_walk_packet dominates): algorithmic bytes of ONE frame
         work = renderer.ctx.count_work(frame)           # whole frame, instrumented variant
         pixels = int(work.rays_primary // (16 if is_ss else 1))
         frame_bytes = algorithmic_bytes(work, pixels)
@@ -229,8 +229,8 @@ def main():
                 traffic, traffic_src = rec["hbm_bytes_per_frame"], os.path.relpath(found[-1], ROOT)
         roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                    "kernel": "frame trace = ct_sample_grid + ct_walk<primary> + ct_walk<shadow> per light + ct_shade "
-                              "(ct_walk is >95 % of it; rocprof per-kernel split in profiles/)",
+                    "kernel": "frame trace = ct_sample_grid + ct_walk_packet<primary> + ct_walk_packet<shadow> + ct_shade "
+                              "(the two ct_walk_packet launches are ~95 % of it; rocprof per-kernel split in profiles/)",
                     "kernel_ms": round(kernel_ms, 4),
                     "bytes_per_launch": int(launch_bytes), "bytes_per_ray": round(frame_bytes / max(work.rays, 1), 1),
                     "node_visits_per_ray": round(work.node_visits / max(work.rays, 1), 2),

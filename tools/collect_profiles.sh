@@ -10,4 +10,5 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/$
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/${tag}_write -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --inflight 1 > $R/gpurun_out/${tag}_write.log 2>&1
 rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum --output-format csv -d $R/gpurun_out/${tag}_cache -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --inflight 1 > $R/gpurun_out/${tag}_cache.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY --output-format csv -d $R/gpurun_out/${tag}_sq -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --inflight 1 > $R/gpurun_out/${tag}_sq.log 2>&1
+rocprofv3 --kernel-trace --pmc SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES SQC_TC_REQ --output-format csv -d $R/gpurun_out/${tag}_sqc -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --inflight 1 > $R/gpurun_out/${tag}_sqc.log 2>&1
 cd $R && python3 tools/summarise_profiles.py $tag

@@ -6,7 +6,7 @@ import collections, csv, glob, json, os, sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
 out = "gpurun_out"
-FRAME_KERNELS = ("ct_sample_grid", "ct_walk<0", "ct_walk<1", "ct_shade", "ct_assemble")
+FRAME_KERNELS = ("ct_sample_grid", "ct_walk_packet<0", "ct_walk_packet<1", "ct_walk<0", "ct_walk<1", "ct_shade", "ct_assemble")
 
 
 def short(name):
@@ -31,7 +31,7 @@ for f in newest("%s/%s_stats/*/*kernel_stats.csv" % (out, tag)):
             stats[k] = (int(r["Calls"]), float(r["AverageNs"]) / 1e6)
 
 counters = collections.defaultdict(lambda: collections.defaultdict(list))
-for part in ("fetch", "write", "cache", "sq"):
+for part in ("fetch", "write", "cache", "sq", "sqc"):
     for f in newest("%s/%s_%s/*/*counter_collection.csv" % (out, tag, part)):
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
@@ -39,12 +39,13 @@ for part in ("fetch", "write", "cache", "sq"):
                 counters[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 mean = lambda v: sum(v) / len(v) if v else 0.0
 
-launches = {"ct_sample_grid": 1, "ct_walk<0>": 1, "ct_walk<1>": 1, "ct_shade": 1, "ct_assemble": 1}
+ORDER = ("ct_sample_grid", "ct_walk_packet<0>", "ct_walk_packet<1>", "ct_walk<0>", "ct_walk<1>", "ct_shade", "ct_assemble")
+launches = {k: 1 for k in ORDER}
 lines = ["# rocprofv3 summary %s -- `python bench.py` (dragon stand-in 1920x1080, 16 spp, 1 MI355X)" % tag, "",
-         "| kernel | launches/frame | avg ms | FETCH_SIZE KB | WRITE_SIZE KB | L2 hit % | L1 (TCP) hit % | VALU lane util % |",
-         "|---|---|---|---|---|---|---|---|"]
+         "| kernel | launches/frame | avg ms | FETCH_SIZE KB | WRITE_SIZE KB | L2 hit % | scalar cache hit % | VALU busy % | VALU lane util % | wave wait % |",
+         "|---|---|---|---|---|---|---|---|---|---|"]
 frame_ms = fetch_kb = write_kb = 0.0
-for k in ("ct_sample_grid", "ct_walk<0>", "ct_walk<1>", "ct_shade", "ct_assemble"):
+for k in ORDER:
     if k not in stats:
         continue
     c = counters[k]
@@ -52,9 +53,13 @@ for k in ("ct_sample_grid", "ct_walk<0>", "ct_walk<1>", "ct_shade", "ct_assemble
     hit, miss = mean(c["TCC_HIT_sum"]), mean(c["TCC_MISS_sum"])
     tcp_total, tcp_miss = mean(c["TCP_TOTAL_CACHE_ACCESSES_sum"]), mean(c["TCP_TCC_READ_REQ_sum"])
     util = 100.0 * mean(c["SQ_THREAD_CYCLES_VALU"]) / (mean(c["SQ_ACTIVE_INST_VALU"]) * 64) if c["SQ_ACTIVE_INST_VALU"] else 0
-    lines.append("| %s | %d | %.3f | %.0f | %.0f | %.1f | %.1f | %.0f |" % (
+    sq_hit, sq_req = mean(c["SQC_DCACHE_HITS"]), mean(c["SQC_DCACHE_REQ"])
+    # SQ_ACTIVE_INST_VALU counts 4-cycle issue slots summed over the 1024 SIMDs (256 CUs x 4); clock from the stats pass
+    valu_busy = 100.0 * mean(c["SQ_ACTIVE_INST_VALU"]) * 4 / (1024 * stats[k][1] * 1e-3 * 2.4e9) if c["SQ_ACTIVE_INST_VALU"] else 0
+    wait = 100.0 * mean(c["SQ_WAIT_ANY"]) / mean(c["SQ_WAVE_CYCLES"]) if c["SQ_WAVE_CYCLES"] else 0
+    lines.append("| %s | %d | %.3f | %.0f | %.0f | %.1f | %.1f | %.0f | %.0f | %.0f |" % (
         k, n, stats[k][1], mean(c["FETCH_SIZE"]), mean(c["WRITE_SIZE"]), 100 * hit / max(hit + miss, 1),
-        100 * (1 - tcp_miss / max(tcp_total, 1)), util))
+        100 * sq_hit / max(sq_req, 1), valu_busy, util, wait))
     frame_ms += n * stats[k][1]
     fetch_kb += n * mean(c["FETCH_SIZE"])
     write_kb += n * mean(c["WRITE_SIZE"])
