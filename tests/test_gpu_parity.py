@@ -370,8 +370,8 @@ def test_single_leaf_tree_on_every_path(monkeypatch):
 
 
 def test_packet_walk_variant(scenes, gpu_ctx, monkeypatch):
-    """ct_walk_packet (the wave's 64 rays share one walk, default for supersampled frames) and the
-    per-lane ct_walk render the identical supersampled frame."""
+    """ct_walk_packet (the wave's 64 rays share one walk over the four-wide folded tree, the default)
+    and the per-lane ct_walk over the reference's binary tree render identical frames."""
     monkeypatch.setenv("CTGPU_PACKET", "0")
     ctxs = {}
     try:
@@ -381,12 +381,90 @@ def test_packet_walk_variant(scenes, gpu_ctx, monkeypatch):
         monkeypatch.delenv("CTGPU_PACKET")
         for name, w, h, t in (("bunny", 640, 360, 32), ("import", 480, 270, 8), ("bunny", 200, 160, 1)):
             scene = scenes(name)
-            for sub in (False, True):
-                frame = scene.frame(w, h, threads=t, supersampling=True, subsampling=sub, rng_seed=5)
+            for ss, sub in ((True, False), (True, True), (False, False), (False, True)):
+                frame = scene.frame(w, h, threads=t, supersampling=ss, subsampling=sub, rng_seed=5)
                 want, sw = gpu_ctx(name).render(frame)
                 got, sg = ctxs[name].render(frame)
-                assert (got == want).all(), (name, w, h, sub)
+                assert (got == want).all(), (name, w, h, ss, sub)
                 assert sg.rays == sw.rays
     finally:
         for c in ctxs.values():
             c.close()
+
+
+def _tree_with_boxes_edited(scene, edit):
+    """A copy of the scene description whose node boxes went through edit(nodes) -- the caller of
+    the C ABI may hand over any tree, not only one built by BuildBVH."""
+    d = scene.desc
+    nodes = (ca.Node * d.n_nodes)()
+    C.memmove(nodes, d.nodes, C.sizeof(ca.Node) * d.n_nodes)
+    edit(nodes, d.n_nodes)
+    copy = ca.SceneDesc(d.n_triangles, d.n_nodes, d.n_lights, 0, d.vertices, d.materials, nodes, d.indexes, d.lights)
+    copy._keep = nodes
+    return copy
+
+
+def test_folded_tree_when_boxes_do_not_nest(scenes):
+    """The packet walk folds every second level of the tree away, which is exact only where a
+    node's children's boxes lie inside its own; the upload checks that per node.  Here some inner
+    nodes are shrunk below their children and some children are inflated beyond their parent: those
+    nodes must stay unfolded, and every path still takes exactly the reference's decisions for the
+    tree AS GIVEN (the oracle walks the same edited tree)."""
+    scene = scenes("import")
+
+    def shrink_and_inflate(nodes, n):
+        rng = np.random.default_rng(11)
+        inner = [i for i in range(1, n) if nodes[i].count == 0]
+        for i in rng.choice(inner, size=max(len(inner) // 5, 1), replace=False):
+            for a in range(3):
+                lo, hi = nodes[i].bmin[a], nodes[i].bmax[a]
+                if rng.random() < 0.5:                       # shrink: children now stick out
+                    nodes[i].bmin[a] = lo + 0.25 * (hi - lo)
+                    nodes[i].bmax[a] = hi - 0.25 * (hi - lo)
+                else:                                        # inflate a child beyond this node
+                    c = nodes[i].left + int(rng.integers(2))
+                    nodes[c].bmax[a] = nodes[c].bmax[a] + 0.5 * (hi - lo) + 0.01
+
+    desc = _tree_with_boxes_edited(scene, shrink_and_inflate)
+    ctx = ca.GpuContext(0)
+    ctx.upload(desc)
+    try:
+        for ss, w, h in ((False, 480, 270), (True, 240, 136)):
+            frame = scene.frame(w, h, threads=8, supersampling=ss, rng_seed=3)
+            got, st = ctx.render(frame)
+            want, cst = _oracle().render(desc, frame, os_threads=2)
+            _compare(got, want, "edited tree ss=%d" % ss)
+            # the edit changes what the reference itself renders: make sure it bit
+            plain, _ = _oracle().render(scene.desc, frame, os_threads=2)
+            assert (plain != want).any()
+        rays = _random_rays(scene, 20000, 5)
+        hits, ref = ctx.trace_rays(rays), _oracle().trace_rays(desc, rays)
+        assert (hits["triangle"] == ref["triangle"]).all() and (hits["t"].view(np.uint32) == ref["t"].view(np.uint32)).all()
+    finally:
+        ctx.close()
+
+
+def test_filter_switches_off_for_huge_coordinates(scenes):
+    """The binary32 plane filter needs a finite bound on the planes of the tree; with a box plane at
+    1e35 there is none (and that plane overflows binary32): every box verdict then comes from the
+    binary64 / exact levels, and the frame is still the reference's."""
+    scene = scenes("import")
+
+    def blow_up(nodes, n):
+        nodes[0].bmax[1] = 1e35
+        leaf = next(i for i in range(n - 1, 0, -1) if nodes[i].count)
+        nodes[leaf].bmax[1] = 1e35
+        nodes[leaf].bmin[0] = -1e35
+
+    desc = _tree_with_boxes_edited(scene, blow_up)
+    ctx = ca.GpuContext(0)
+    ctx.upload(desc)
+    try:
+        for ss, w, h in ((False, 320, 180), (True, 160, 90)):
+            frame = scene.frame(w, h, threads=4, supersampling=ss, rng_seed=2)
+            got, _ = ctx.render(frame)
+            want, _ = _oracle().render(desc, frame, os_threads=2)
+            _compare(got, want, "huge plane ss=%d" % ss)
+            assert (got != 0x333333).any()
+    finally:
+        ctx.close()
