@@ -109,7 +109,9 @@ __device__ __forceinline__ void slab(const d3 &o, const d3 &d, const double *bmi
 
 // The same arithmetic for the rare fallback inside a register-tight kernel: the scheduler may not
 // overlap the six divisions (each needs about ten temporaries), so they run one after another.
-__device__ __forceinline__ void slab_in_sequence(const d3 &o, const d3 &d, const double *bmin, const double *bmax,
+// Returns true when one of the six parameters is a NaN (0/0: a zero direction component and the
+// origin exactly on that plane) -- the one situation in which a folded tree may not be used (DESIGN B2).
+__device__ __forceinline__ bool slab_in_sequence(const d3 &o, const d3 &d, const double *bmin, const double *bmax,
                                                  float &tmin, float &tmax) {
     const float tx1 = (float)((bmin[0] - o.x) / d.x);
     __builtin_amdgcn_sched_barrier(0);
@@ -129,6 +131,7 @@ __device__ __forceinline__ void slab_in_sequence(const d3 &o, const d3 &d, const
     __builtin_amdgcn_sched_barrier(0);
     tmin = greater(tmin, lesser(tz1, tz2));
     tmax = lesser(tmax, greater(tz1, tz2));
+    return (tx1 != tx1) | (tx2 != tx2) | (ty1 != ty1) | (ty2 != ty2) | (tz1 != tz1) | (tz2 != tz2);
 }
 
 // ---------------------------------------------------------------- slab test, division-free

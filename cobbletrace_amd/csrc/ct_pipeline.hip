@@ -710,6 +710,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
     float t = kNoHit;
     uint32_t slot = kNoNode;
     bool has_ray = false, root_pass = false;
+    bool redo = false;            // this lane's ray met a NaN box parameter: walked again alone, unfolded (below)
     uint64_t ray_id = 0;          // shadow packets: per lane; primary packets: packet_base + lane
     uint64_t packet_base = 0;
     uint64_t chunk_next = 0, chunk_end = 0;
@@ -731,6 +732,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
         // ---------------- fetch a packet: every lane gets a ray (or stays empty at the end)
         has_ray = false;
         root_pass = false;
+        redo = false;
         for (;;) {
             const unsigned long long m_i = __ballot(!has_ray);
             if (m_i == 0ull || wave_drained) break;
@@ -808,9 +810,23 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
 
         // lanes still tracing (a shadow ray stops at its first hit, raythread.cpp:303-307); every
         // lane mask below is wave-uniform and stays inside it
-        unsigned long long tracing = __ballot(has_ray);
-        uint32_t cur = P.quad_root;
-        unsigned long long mask = __ballot(root_pass);
+        // Pass 0 walks the folded tree.  A ray that meets a NaN box parameter there (0/0: a zero
+        // direction component and the origin exactly on a box plane -- the one case folding is not
+        // proven for, DESIGN B2) leaves the packet, and pass 1 walks those rays again from the root
+        // over the same tree UNFOLDED (two entries per node, the reference's own structure).
+        for (int pass = 0; pass < 2; pass++) {
+        const QuadNode *quads = pass == 0 ? P.quads : P.quads_flat;
+        const uint32_t *quad_source = pass == 0 ? P.quad_source : P.quad_source_flat;
+        if (pass == 1) {
+            const unsigned long long again = __ballot(redo);
+            if (again == 0ull) break;
+            if (lane == 0) atomicAdd(&P.counters[15], (unsigned long long)__popcll(again));    // diagnostic
+            if (redo) { t = kNoHit; slot = kNoNode; }
+        }
+        unsigned long long tracing = pass == 0 ? __ballot(has_ray) : __ballot(redo);
+        uint32_t cur = pass == 0 ? P.quad_root : P.quad_root_flat;
+        unsigned long long mask = pass == 0 ? __ballot(root_pass) : tracing;
+        if (pass == 1) redo = false;
         uint32_t sp = 0;
         // the wave-uniform part of the stack lives in three vector registers, entry i in lane i
         // (read back with v_readlane, the level as lane select): no LDS round trip on a pop
@@ -843,7 +859,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                         if (hit && t != kNoHit && t < tclosest) slot = first + k;
                     }
                 }
-                if (KIND == 1) tracing = __ballot(has_ray && t == kNoHit);
+                if (KIND == 1) tracing &= __ballot(t == kNoHit);
                 mask = 0ull;               // on to the pop below
                 PK_T1(1);
             } else {
@@ -851,7 +867,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                 PK_COUNT(0, 1);
                 PK_COUNT(1, __popcll(mask));
                 const uint32_t node_id = cur;
-                const ScalarQuad sq = scalar_load_quad(P.quads + node_id);
+                const ScalarQuad sq = scalar_load_quad(quads + node_id);
                 // level 0: binary32 planes, verdicts with an error bound.  Every lane computes (the
                 // masked-out ones on stale rays, harmlessly) and the verdicts leave the vector unit
                 // as wave masks: no per-lane flag crosses a branch.
@@ -883,21 +899,26 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
 #pragma nounroll
                         for (uint32_t k = 0; k < n_entries; k++) {
                             if (((todo >> k) & 1u) == 0u) continue;
-                            const uint32_t source = P.quad_source[node_id * 4u + k];
+                            const uint32_t source = quad_source[node_id * 4u + k];
                             const double *bmin = P.nodes[source >> 1].lmin + (source & 1u) * 6u, *bmax = bmin + 3;
                             const d3 inv = make_d3(quick_reciprocal(d.x), quick_reciprocal(d.y), quick_reciprocal(d.z));
                             float tmin64, tmax64;
                             bool pass;
                             slab_approx(RAY_O, inv, bmin, bmax, tmin64, tmax64);
                             if (!(box_verdict_positive_t(tmin64, tmax64, t, pass) & fast)) {
-                                slab_in_sequence(RAY_O, d, bmin, bmax, tmin64, tmax64);
+                                redo |= slab_in_sequence(RAY_O, d, bmin, bmax, tmin64, tmax64) && pass == 0;
                                 pass = tmax64 >= tmin64 && tmin64 < t && tmax64 > 0;
                             }
                             passed |= pass ? (1u << k) : 0u;
                         }
                     }
+                    // a NaN parameter: folding is not proven for this ray (DESIGN B2) -- it leaves the
+                    // packet here and is walked again from the root, unfolded, after the packet
+                    const unsigned long long gone = __ballot(redo);
+                    tracing &= ~gone;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) enter[k] = (enter[k] & ~unsure_of[k]) | __ballot(((passed >> k) & 1u) != 0u);
+                    for (int k = 0; k < 4; k++)
+                        enter[k] = ((enter[k] & ~unsure_of[k]) | __ballot(((passed >> k) & 1u) != 0u)) & ~gone;
                 }
                 PK_T1(0);
                 // the first entry some lane enters comes next; later ones wait on the stack (last
@@ -940,10 +961,10 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                     if (!deferred_verdict_f32(tmin, rf.noi_z_e.y, t, keep)) {
                         // too close to ray.t to trust: the whole test, exactly
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                        const uint32_t source = P.quad_source[st.parent[sp]];
+                        const uint32_t source = quad_source[st.parent[sp]];
                         const double *bmin = P.nodes[source >> 1].lmin + (source & 1u) * 6u;
                         float etmin, etmax;
-                        slab_in_sequence(RAY_O, d, bmin, bmin + 3, etmin, etmax);
+                        (void)slab_in_sequence(RAY_O, d, bmin, bmin + 3, etmin, etmax);      // (a NaN here was seen at push time)
                         keep = etmax >= etmin && etmin < t && etmax > 0;
                     }
                 }
@@ -952,6 +973,8 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                 PK_T1(2);
             }
         }
+
+        }   // passes
 
         // ---------------- retire the packet
         if (has_ray) {

@@ -67,9 +67,9 @@ struct ctgpu_ctx {
     double root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
 
     DeviceArray<WideNode> nodes;
-    DeviceArray<QuadNode> quads;
-    DeviceArray<uint32_t> quad_source;
-    uint32_t quad_root = 0, quad_pending = 1;
+    DeviceArray<QuadNode> quads, quads_flat;
+    DeviceArray<uint32_t> quad_source, quad_source_flat;
+    uint32_t quad_root = 0, quad_root_flat = 0, quad_pending = 1;
     float plane_bound[3] = {0, 0, 0};
     DeviceArray<TriRecord> tris;
     DeviceArray<Material> materials;
@@ -195,7 +195,7 @@ extern "C" void ctgpu_destroy(ctgpu_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    ctx->nodes.release(); ctx->quads.release(); ctx->quad_source.release(); ctx->tris.release(); ctx->materials.release(); ctx->lights.release();
+    ctx->nodes.release(); ctx->quads.release(); ctx->quad_source.release(); ctx->quads_flat.release(); ctx->quad_source_flat.release(); ctx->tris.release(); ctx->materials.release(); ctx->lights.release();
     ctx->tiles.release(); ctx->fb.release(); ctx->gathered.release(); ctx->counters.release(); ctx->overflow.release();
     ctx->rand_table.release(); ctx->row_ordinal.release();
     ctx->coords.release(); ctx->hits.release(); ctx->shadow.release(); ctx->queue.release(); ctx->spill.release();
@@ -277,55 +277,59 @@ extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
         }
         return true;
     };
-    std::vector<QuadNode> quads;
-    std::vector<uint32_t> quad_source;
-    std::vector<uint32_t> quad_of(M, kNoNode), quad_head;          // reference node heading each QuadNode
-    auto quad_for = [&](uint32_t id) {
-        if (quad_of[id] == kNoNode) {
-            quad_of[id] = (uint32_t)quad_head.size();
-            quad_head.push_back(id);
-        }
-        return quad_of[id];
-    };
-    uint32_t quad_root = kLeafBit | 0u;
-    if (s->nodes[0].count == 0) quad_root = quad_for(0);
-    for (size_t q = 0; q < quad_head.size(); q++) {                 // quad_head grows while we go
-        const uint32_t head = quad_head[q];
-        QuadNode node;
-        std::memset(&node, 0, sizeof node);
-        uint32_t source[4] = {0, 0, 0, 0};
-        auto add = [&](uint32_t id, uint32_t parent, uint32_t side) {
-            const ctgpu_node &e = s->nodes[id];
-            const uint32_t k = node.count++;
-            for (int a = 0; a < 3; a++) { node.plane[k][a][0] = (float)e.bmin[a]; node.plane[k][a][1] = (float)e.bmax[a]; }
-            node.ref[k] = e.count ? (kLeafBit | e.first) : quad_for(id);
-            source[k] = wide_of[parent] * 2u + side;
+    struct Folded { std::vector<QuadNode> quads; std::vector<uint32_t> source; uint32_t root = kLeafBit | 0u, pending = 1; };
+    // fold = true: the tree the packet walk uses; fold = false: the same structure with nothing folded
+    // (two entries per node), walked a second time by rays folding is not proven for (DESIGN B2)
+    auto build_quads = [&](bool fold, Folded &out) -> bool {
+        std::vector<uint32_t> quad_of(M, kNoNode), quad_head;       // reference node heading each QuadNode
+        auto quad_for = [&](uint32_t id) {
+            if (quad_of[id] == kNoNode) {
+                quad_of[id] = (uint32_t)quad_head.size();
+                quad_head.push_back(id);
+            }
+            return quad_of[id];
         };
-        for (uint32_t side = 0; side < 2; side++) {
-            const uint32_t c = s->nodes[head].left + side;
-            if (folds(c)) { add(s->nodes[c].left, c, 0); add(s->nodes[c].left + 1, c, 1); }
-            else add(c, head, side);
+        if (s->nodes[0].count == 0) out.root = quad_for(0);
+        for (size_t q = 0; q < quad_head.size(); q++) {             // quad_head grows while we go
+            const uint32_t head = quad_head[q];
+            QuadNode node;
+            std::memset(&node, 0, sizeof node);
+            uint32_t source[4] = {0, 0, 0, 0};
+            auto add = [&](uint32_t id, uint32_t parent, uint32_t side) {
+                const ctgpu_node &e = s->nodes[id];
+                const uint32_t k = node.count++;
+                for (int a = 0; a < 3; a++) { node.plane[k][a][0] = (float)e.bmin[a]; node.plane[k][a][1] = (float)e.bmax[a]; }
+                node.ref[k] = e.count ? (kLeafBit | e.first) : quad_for(id);
+                source[k] = wide_of[parent] * 2u + side;
+            };
+            for (uint32_t side = 0; side < 2; side++) {
+                const uint32_t c = s->nodes[head].left + side;
+                if (fold && folds(c)) { add(s->nodes[c].left, c, 0); add(s->nodes[c].left + 1, c, 1); }
+                else add(c, head, side);
+            }
+            out.quads.push_back(node);
+            out.source.insert(out.source.end(), source, source + 4);
         }
-        quads.push_back(node);
-        quad_source.insert(quad_source.end(), source, source + 4);
-    }
-    // most entries ever waiting on the packet walk's stack: along a path, every QuadNode leaves count-1 behind
-    uint32_t quad_pending = 1;
-    if (!quads.empty()) {
-        std::vector<std::pair<uint32_t, uint32_t>> todo;
-        todo.push_back({quad_root, 0u});
-        size_t steps = 0;
-        while (!todo.empty()) {
-            const auto [q, before] = todo.back();
-            todo.pop_back();
-            if (++steps > quads.size()) return fail(CTGPU_ERR_ARG, "node links form a cycle");
-            const QuadNode &node = quads[q];
-            quad_pending = std::max(quad_pending, before + node.count - 1u);
-            for (uint32_t k = 0; k < node.count; k++)
-                if (!(node.ref[k] & kLeafBit)) todo.push_back({node.ref[k], before + node.count - 1u - k});
+        // most entries ever waiting on the packet walk's stack: along a path, every QuadNode leaves count-1 behind
+        if (!out.quads.empty()) {
+            std::vector<std::pair<uint32_t, uint32_t>> todo;
+            todo.push_back({out.root, 0u});
+            size_t steps = 0;
+            while (!todo.empty()) {
+                const auto [q, before] = todo.back();
+                todo.pop_back();
+                if (++steps > out.quads.size()) return false;
+                const QuadNode &node = out.quads[q];
+                out.pending = std::max(out.pending, before + node.count - 1u);
+                for (uint32_t k = 0; k < node.count; k++)
+                    if (!(node.ref[k] & kLeafBit)) todo.push_back({node.ref[k], before + node.count - 1u - k});
+            }
         }
-    }
-    if (quads.empty()) { quads.emplace_back(); std::memset(&quads[0], 0, sizeof(QuadNode)); quad_source.assign(4, 0u); }
+        if (out.quads.empty()) { out.quads.emplace_back(); std::memset(&out.quads[0], 0, sizeof(QuadNode)); out.source.assign(4, 0u); }
+        return true;
+    };
+    Folded folded, flat;
+    if (!build_quads(true, folded) || !build_quads(false, flat)) return fail(CTGPU_ERR_ARG, "node links form a cycle");
 
     // leaf-ordered triangle records; a tree walk gives depth and the leaf extents
     std::vector<TriRecord> recs(N);
@@ -374,12 +378,17 @@ extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
     HIP_TRY(ctx->materials.resize(N));
     HIP_TRY(ctx->lights.resize(std::max<uint32_t>(s->n_lights, 1)));
     HIP_TRY(hipMemcpy(ctx->nodes.ptr, wide.data(), wide.size() * sizeof(WideNode), hipMemcpyHostToDevice));
-    HIP_TRY(ctx->quads.resize(quads.size()));
-    HIP_TRY(hipMemcpy(ctx->quads.ptr, quads.data(), quads.size() * sizeof(QuadNode), hipMemcpyHostToDevice));
-    HIP_TRY(ctx->quad_source.resize(quad_source.size()));
-    HIP_TRY(hipMemcpy(ctx->quad_source.ptr, quad_source.data(), quad_source.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    ctx->quad_root = quad_root;
-    ctx->quad_pending = quad_pending;
+    HIP_TRY(ctx->quads.resize(folded.quads.size()));
+    HIP_TRY(hipMemcpy(ctx->quads.ptr, folded.quads.data(), folded.quads.size() * sizeof(QuadNode), hipMemcpyHostToDevice));
+    HIP_TRY(ctx->quad_source.resize(folded.source.size()));
+    HIP_TRY(hipMemcpy(ctx->quad_source.ptr, folded.source.data(), folded.source.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(ctx->quads_flat.resize(flat.quads.size()));
+    HIP_TRY(hipMemcpy(ctx->quads_flat.ptr, flat.quads.data(), flat.quads.size() * sizeof(QuadNode), hipMemcpyHostToDevice));
+    HIP_TRY(ctx->quad_source_flat.resize(flat.source.size()));
+    HIP_TRY(hipMemcpy(ctx->quad_source_flat.ptr, flat.source.data(), flat.source.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    ctx->quad_root = folded.root;
+    ctx->quad_root_flat = flat.root;
+    ctx->quad_pending = std::max(folded.pending, flat.pending);
     HIP_TRY(hipMemcpy(ctx->tris.ptr, recs.data(), (size_t)N * sizeof(TriRecord), hipMemcpyHostToDevice));
     static_assert(sizeof(Material) == sizeof(ctgpu_material), "material layout");
     static_assert(sizeof(Light) == sizeof(ctgpu_light), "light layout");
@@ -465,7 +474,8 @@ int fill_params(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, const ctgpu_partition
                 FrameParams &P) {
     const Geometry g = geometry(f);
     std::memset(&P, 0, sizeof P);
-    P.nodes = ctx->nodes.ptr; P.quads = ctx->quads.ptr; P.quad_source = ctx->quad_source.ptr; P.quad_root = ctx->quad_root; P.tris = ctx->tris.ptr; P.materials = ctx->materials.ptr; P.lights = ctx->lights.ptr;
+    P.nodes = ctx->nodes.ptr; P.quads = ctx->quads.ptr; P.quad_source = ctx->quad_source.ptr; P.quad_root = ctx->quad_root;
+    P.quads_flat = ctx->quads_flat.ptr; P.quad_source_flat = ctx->quad_source_flat.ptr; P.quad_root_flat = ctx->quad_root_flat; P.tris = ctx->tris.ptr; P.materials = ctx->materials.ptr; P.lights = ctx->lights.ptr;
     P.n_lights = ctx->n_lights;
     P.root_ref = ctx->root_ref;
     P.slot_of_triangle0 = ctx->slot_of_triangle0;
@@ -532,6 +542,8 @@ int read_counters(ctgpu_ctx *ctx, ctgpu_stats *st) {
         std::fprintf(stderr, "phases: A %llu x %.1f lanes (%.0f cyc each), B %llu x %.1f lanes (%.0f cyc), C %llu x %.1f lanes (%.0f cyc)\n", c[5],
                      (double)c[6] / c[5], (double)c[11] / c[5], c[7], c[7] ? (double)c[8] / c[7] : 0.0, c[7] ? (double)c[12] / c[7] : 0.0,
                      c[9], c[9] ? (double)c[10] / c[9] : 0.0, c[9] ? (double)c[13] / c[9] : 0.0);
+    if (std::getenv("CTGPU_DEBUG_REDO"))
+        std::fprintf(stderr, "packet walk: %llu rays walked again unfolded (NaN box parameter)\n", c[15]);
     if (std::getenv("CTGPU_DEBUG_PACKET") && c[14])
         std::fprintf(stderr, "packet walk: inner %llu (%.1f lanes, %.0f cyc each; level 1 on %.3f%%), leaf triangles %llu (%.1f lanes; %.0f cyc each), "
                      "pops %llu (%.0f cyc each); wave cycles %llu: inner %.1f%% leaf %.1f%% pop %.1f%% other %.1f%%\n",

@@ -2,6 +2,7 @@
 inputs.  Bar: <= 1 LSB per 8-bit channel (BASELINE.json); index / t of individual hits exact
 (the only non-exact operation on the path is pow(), SURVEY.md 7 "hard parts")."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -468,3 +469,48 @@ def test_filter_switches_off_for_huge_coordinates(scenes):
             assert (got != 0x333333).any()
     finally:
         ctx.close()
+
+
+def test_rays_with_nan_box_parameters(tmp_path):
+    """Camera exactly on the plane of flat, axis-aligned geometry, looking along it: the centre row of
+    a frame without supersampling has d.y == 0 and o.y == a box plane, so box parameters are 0/0 = NaN
+    and the reference's min / max macros do whatever they do with them.  The folded tree is not
+    proven for such rays: the packet walk must notice and walk them again unfolded.  Every path has
+    to reproduce the reference's (odd) picture, ray for ray."""
+    floor, extra = [], []
+    for i in range(8):                       # a tiled floor in the plane y = -1 (flat boxes all the way down the tree)
+        for j in range(8):
+            x, z = -2 + 0.5 * i, 1 + 0.5 * j
+            floor.append(([x, -1, z], [x + 0.5, -1, z], [x + 0.5, -1, z + 0.5], (255, 255, 255), 100))
+            floor.append(([x, -1, z], [x + 0.5, -1, z + 0.5], [x, -1, z + 0.5], (230, 230, 230), 100))
+    for i in range(6):                       # and things standing on it
+        x = -1.75 + 0.6 * i
+        extra.append(([x, -1, 3], [x + 0.4, -1, 3], [x + 0.2, 0.5, 3], (255, 80, 80), 10))
+        extra.append(([x, -1, 4.5], [x + 0.4, -1, 4.5], [x + 0.2, 1.0, 4.5], (80, 80, 255), 10))
+    lights = [{"type": "ambient", "intensity": 0.3}, {"type": "point", "intensity": 0.6, "position": [0, 3, 3]},
+              {"type": "directional", "intensity": 0.2, "direction": [0, 1, 0]}]
+    path = _write_scene(tmp_path, "on_the_floor.json", floor + extra, lights, camera=(0, -1, -3))
+    scene = ca.HostScene(path)
+    assert scene.desc.n_nodes > 30
+    rays = np.zeros(4000, dtype=ca.bindings.RAY_DTYPE)
+    rng = np.random.default_rng(9)
+    rays["origin"] = [0, -1, -3]
+    rays["direction"] = np.c_[rng.normal(size=4000) * 0.5, np.zeros(4000), np.ones(4000)]
+    rays["t"] = np.float32(1e30)
+    for packet in ("1", "0"):
+        os.environ["CTGPU_PACKET"] = packet
+        try:
+            ctx = ca.GpuContext(0)
+        finally:
+            del os.environ["CTGPU_PACKET"]
+        ctx.upload(scene.desc)
+        try:
+            for ss, sub in ((False, False), (True, False), (False, True)):
+                frame = scene.frame(200, 160, threads=4, supersampling=ss, subsampling=sub, rng_seed=1)
+                got, st = ctx.render(frame)
+                want, cst = _oracle().render(scene.desc, frame, os_threads=2)
+                _compare(got, want, "camera on the floor plane, packet=%s ss=%d sub=%d" % (packet, ss, sub))
+            hits, ref = ctx.trace_rays(rays), _oracle().trace_rays(scene.desc, rays)
+            assert (hits["triangle"] == ref["triangle"]).all() and (hits["t"].view(np.uint32) == ref["t"].view(np.uint32)).all()
+        finally:
+            ctx.close()
