@@ -300,6 +300,31 @@ __device__ __forceinline__ void box_verdict_f32(float tmin, float tmax, float tw
     margin = __builtin_fmaf(__builtin_fmaxf(__builtin_fabsf(tmin), __builtin_fabsf(tmax)), 0x1p-20f, two_e);
     least = __builtin_fminf(__builtin_fminf(tmax - tmin, ray_t - tmin), tmax);
 }
+// slab_pairs_f32 + box_verdict_f32 for one box, instruction for instruction (17 VALU): written out
+// because min / max on values the compiler did not produce itself get a canonicalising
+// `v_max x, x` in front of each operand (6 per box), and because the scalar unit is the scarcer
+// resource here -- everything per-lane stays in the vector unit until the two compares.
+__device__ __forceinline__ void box_filter_f32(const RayFilter &f, f32x2 px, f32x2 py, f32x2 pz, float ray_t,
+                                               float &tmin, float &least, float &margin) {
+    f32x2 tx, ty, tz;
+    float nx, ny, nz, fx, fy, fz, tmax, big, gap, room;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(tx) : "s"(px), "v"(f.inv_xy), "v"(f.noi_xy));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[1,1,1]" : "=v"(ty) : "s"(py), "v"(f.inv_xy), "v"(f.noi_xy));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(tz) : "s"(pz), "v"(f.inv_z_e2), "v"(f.noi_z_e));
+    asm("v_min_f32 %0, %1, %2" : "=v"(nx) : "v"(tx.x), "v"(tx.y));
+    asm("v_min_f32 %0, %1, %2" : "=v"(ny) : "v"(ty.x), "v"(ty.y));
+    asm("v_min_f32 %0, %1, %2" : "=v"(nz) : "v"(tz.x), "v"(tz.y));
+    asm("v_max_f32 %0, %1, %2" : "=v"(fx) : "v"(tx.x), "v"(tx.y));
+    asm("v_max_f32 %0, %1, %2" : "=v"(fy) : "v"(ty.x), "v"(ty.y));
+    asm("v_max_f32 %0, %1, %2" : "=v"(fz) : "v"(tz.x), "v"(tz.y));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmin) : "v"(nx), "v"(ny), "v"(nz));
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tmax) : "v"(fx), "v"(fy), "v"(fz));
+    asm("v_max_f32 %0, |%1|, |%2|" : "=v"(big) : "v"(tmin), "v"(tmax));
+    asm("v_fma_f32 %0, %1, %2, %3" : "=v"(margin) : "v"(big), "s"(0x1p-20f), "v"(f.inv_z_e2.y));
+    asm("v_sub_f32 %0, %1, %2" : "=v"(gap) : "v"(tmax), "v"(tmin));
+    asm("v_sub_f32 %0, %1, %2" : "=v"(room) : "v"(ray_t), "v"(tmin));
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(least) : "v"(gap), "v"(room), "v"(tmax));
+}
 // the deferred  tmin < ray.t  of a pushed child (ray.t may have dropped since): decided -> keep
 __device__ __forceinline__ bool deferred_verdict_f32(float tmin, float e, float ray_t, bool &keep) {
     const float m = filter_margin(tmin, e);

@@ -872,19 +872,19 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                 // masked-out ones on stale rays, harmlessly) and the verdicts leave the vector unit
                 // as wave masks: no per-lane flag crosses a branch.
                 float tmin[4];
-                unsigned long long enter[4], unsure_of[4], unsure = 0ull;
+                unsigned long long enter[4], unsure_of[4];
                 const uint32_t n_entries = sq.count();
+                // entries 0 and 1 always exist; 2 and 3 take part through their lane mask
+                const unsigned long long live[4] = {mask, mask, n_entries > 2u ? mask : 0ull, n_entries > 3u ? mask : 0ull};
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    float tmax, least, margin;
-                    slab_pairs_f32(rf, sq.planes(k, 0), sq.planes(k, 1), sq.planes(k, 2), tmin[k], tmax);
-                    box_verdict_f32(tmin[k], tmax, rf.inv_z_e2.y, t, least, margin);
+                    float least, margin;
+                    box_filter_f32(rf, sq.planes(k, 0), sq.planes(k, 1), sq.planes(k, 2), t, tmin[k], least, margin);
                     const unsigned long long yes = __ballot(least > margin), no = __ballot(least < -margin);
-                    const bool used = (uint32_t)k < n_entries;
-                    enter[k] = used ? (yes & mask) : 0ull;
-                    unsure_of[k] = used ? (mask & ~(yes | no)) : 0ull;
-                    unsure |= unsure_of[k];
+                    enter[k] = yes & live[k];
+                    unsure_of[k] = live[k] & ~(yes | no);
                 }
+                const unsigned long long unsure = (unsure_of[0] | unsure_of[1]) | (unsure_of[2] | unsure_of[3]);
                 if (unsure != 0ull) {
                     PK_COUNT(4, 1);
                     // level 1 (some lane sits inside the bound): binary64 planes, one-step margins;
@@ -921,30 +921,35 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                         enter[k] = ((enter[k] & ~unsure_of[k]) | __ballot(((passed >> k) & 1u) != 0u)) & ~gone;
                 }
                 PK_T1(0);
-                // the first entry some lane enters comes next; later ones wait on the stack (last
-                // first), each lane's `tmin < ray.t` re-evaluated when the entry is popped
-                const uint32_t first_entry = enter[0] ? 0u : enter[1] ? 1u : enter[2] ? 2u : enter[3] ? 3u : 4u;
-                bool overflow = false;
+                // the first entry some lane enters comes next; later ones wait on the stack (pushed last
+                // first), each lane's `tmin < ray.t` re-evaluated when the entry is popped.  Going down
+                // from entry 3: whenever a lower entry turns up, the one found before it is pushed.
+                // (the stack cannot overflow: packet_depth is the exact maximum over the tree, set at upload)
+                uint32_t next_ref = 0;
+                unsigned long long next_mask = 0ull;
+                float next_tmin = 0.0f;
+                uint32_t next_entry = 0;
 #pragma unroll
-                for (int k = 3; k >= 1; k--) {
-                    if ((uint32_t)k > first_entry && enter[k] != 0ull) {
-                        if (sp >= depth) { overflow = true; break; }
-                        const bool level = lane == sp;       // (v_writelane cannot take value and lane select from two scalar registers)
-                        stack_ref = level ? (int)sq.ref(k) : stack_ref;
-                        stack_mask_lo = level ? (int)(uint32_t)enter[k] : stack_mask_lo;
-                        stack_mask_hi = level ? (int)(uint32_t)(enter[k] >> 32) : stack_mask_hi;
-                        if (lane == 0) st.parent[sp] = node_id * 4u + (uint32_t)k;       // read on the exact path only
-                        st.put_tmin(sp, lane, tmin[k]);
-                        sp += 1;
+                for (int k = 3; k >= 0; k--) {
+                    if (enter[k] != 0ull) {
+                        if (next_mask != 0ull) {
+                            const bool level = lane == sp;       // (v_writelane cannot take value and lane select from two scalar registers)
+                            stack_ref = level ? (int)next_ref : stack_ref;
+                            stack_mask_lo = level ? (int)(uint32_t)next_mask : stack_mask_lo;
+                            stack_mask_hi = level ? (int)(uint32_t)(next_mask >> 32) : stack_mask_hi;
+                            st.parent[sp] = node_id * 4u + next_entry;                // every lane, same word: read on the exact path only
+                            st.put_tmin(sp, lane, next_tmin);
+                            sp += 1;
+                        }
+                        next_ref = sq.ref(k);
+                        next_mask = enter[k];
+                        next_tmin = tmin[k];
+                        next_entry = (uint32_t)k;
                     }
                 }
-                if (overflow) { atomicOr(P.overflow, 1u); break; }
-                if (first_entry < 4u) {
-                    cur = first_entry == 0u ? sq.ref(0) : first_entry == 1u ? sq.ref(1) : first_entry == 2u ? sq.ref(2) : sq.ref(3);
-                    mask = first_entry == 0u ? enter[0] : first_entry == 1u ? enter[1] : first_entry == 2u ? enter[2] : enter[3];
-                    continue;
-                }
-                mask = 0ull;
+                cur = next_ref;
+                mask = next_mask;
+                if (mask != 0ull) continue;
             }
             // ---------------- pop: next pending entry some lane still wants
             while (mask == 0ull && sp > 0) {
