@@ -880,9 +880,9 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                 for (int k = 0; k < 4; k++) {
                     float least, margin;
                     box_filter_f32(rf, sq.planes(k, 0), sq.planes(k, 1), sq.planes(k, 2), t, tmin[k], least, margin);
-                    const unsigned long long yes = __ballot(least > margin), no = __ballot(least < -margin);
-                    enter[k] = yes & live[k];
-                    unsure_of[k] = live[k] & ~(yes | no);
+                    // decided = |least| > margin (a NaN is undecided); passes = least > margin
+                    enter[k] = __ballot(least > margin) & live[k];
+                    unsure_of[k] = __ballot(!(__builtin_fabsf(least) > margin)) & live[k];
                 }
                 const unsigned long long unsure = (unsure_of[0] | unsure_of[1]) | (unsure_of[2] | unsure_of[3]);
                 if (unsure != 0ull) {
