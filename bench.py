@@ -123,6 +123,13 @@ def main():
     # while frame i's kernels drain their tail and its tiles are gathered and assembled, the way a
     # renderer producing a stream of frames runs.  Each context owns its scene copy and scratch arrays.
     inflight = max(1, args.inflight)
+    # Throughput tuning through the library's documented knobs (read at context creation): with several
+    # frames in flight and only a slice of the frame per rank, a smaller persistent grid per context
+    # and 128-ray-id chunks beat the defaults, which are tuned for one frame's latency
+    # (tools/overlap.py: 8-way share 0.57 -> 0.50 ms).
+    if inflight > 1 and world >= 4:
+        os.environ.setdefault("CTGPU_BLOCKS_PER_CU", "12")
+        os.environ.setdefault("CTGPU_CHUNK", "128")
     renderers = [ShardedRenderer(scene.desc, rank, world, local_rank) for _ in range(inflight)]
     streams = [torch.cuda.Stream() for _ in range(inflight)]
     renderer = renderers[0]

@@ -9,8 +9,10 @@ A = os.path.join(os.path.dirname(__file__), "..", "assets")
 name = sys.argv[1] if len(sys.argv) > 1 else "dragon"
 scene = ca.HostScene(os.path.join(A, "scene_import_%s.json" % name))
 full = scene.frame(1920, 1080, supersampling=True)
-for world in (1, 2, 4, 8):
-    for inflight in (1, 2, 3):
+worlds = [int(w) for w in os.environ.get("OVERLAP_WORLDS", "1,2,4,8").split(",")]
+flights = [int(w) for w in os.environ.get("OVERLAP_INFLIGHT", "1,2,3").split(",")]
+for world in worlds:
+    for inflight in flights:
         # rank 0's share of the real frame: partition (8-row tiles, rank 0 of `world`)
         rs = [ShardedRenderer(scene.desc, 0, world, 0) for _ in range(inflight)]
         ss = [torch.cuda.Stream() for _ in range(inflight)]
