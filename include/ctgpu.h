@@ -136,6 +136,14 @@ int  ctgpu_abi_version(void);
 const char *ctgpu_last_error(void);
 int  ctgpu_device_count(int *count);
 
+/* A context is bound to one GPU.  Tuning knobs are read from the environment here, once (none
+ * changes a pixel -- tests/test_gpu_parity.py::test_pipeline_knobs_do_not_change_pixels):
+ *   CTGPU_BLOCKS_PER_CU  persistent waves per CU of the traversal launches (0 = what fits; fewer
+ *                        is better when several contexts keep frames in flight on one GPU)
+ *   CTGPU_CHUNK          ray ids a wave reserves per queue atomic (multiple of 64; 0 = by frame size)
+ *   CTGPU_PACKET         0: per-lane walk over the binary tree instead of the shared (packet) walk
+ *   CTGPU_PACKET_LDS_LEVELS, CTGPU_LDS_DEPTH   stack levels kept in LDS (deeper ones go to HBM)
+ *   CTGPU_FORCE_MEGAKERNEL   1: the general path (one kernel, reflection capable) for every frame */
 int  ctgpu_create(int device, ctgpu_ctx **out);
 void ctgpu_destroy(ctgpu_ctx *ctx);
 
