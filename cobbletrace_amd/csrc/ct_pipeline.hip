@@ -6,19 +6,23 @@
 // chain of kernels over flat per-sample arrays in HBM (a few hundred MB at 1080p x 16 spp,
 // a rounding error against 288 GB and 8 TB/s):
 //
-//   ct_sample_grid   lane = pixel   jittered sample positions (the float residue of
-//                                   raythread.cpp:462-504 is sequential per pixel)
-//   ct_walk<PRIMARY> lane = ray     closest-hit traversal            -> hits[sample]
-//   ct_walk<SHADOW>  lane = ray     any-hit traversal per non-ambient light of every hit
-//                                   sample                           -> shadow bit mask
-//   ct_shade         lane = pixel   lighting + HSV + ordered supersample blend -> tile
+//   ct_sample_grid           lane = pixel   jittered sample positions (the float residue of
+//                                           raythread.cpp:462-504 is sequential per pixel)
+//   ct_walk_packet<PRIMARY>  lane = ray     closest-hit traversal, the wave's 64 rays sharing ONE
+//                                           walk over the four-wide folded tree   -> hits[sample]
+//   ct_walk_packet<SHADOW>   lane = ray     any-hit traversal per non-ambient light of every hit
+//                                           sample                                -> shadow bytes
+//   ct_shade                 lane = sample, then pixel   lighting + HSV, ordered supersample blend
 //
-// ct_walk is a PERSISTENT kernel: one wave per workgroup, as many workgroups as fit on the
-// chip, every lane pulls the next ray index from a global counter as soon as its ray is
-// done (wave-aggregated atomic), so lanes never wait for the slowest ray of "their" tile.
-// Only traversal state lives in registers (ray, inverse direction, t, closest slot, cursor),
-// which is what lets 6-8 waves share a SIMD.  The traversal stack is per lane: the first
-// P.lds_depth entries in LDS, deeper ones (rare) in a per-wave spill area in HBM.
+// The walk kernels are PERSISTENT: one wave per workgroup, as many workgroups as fit on the chip,
+// ray ids handed out in chunks from sharded queue heads (one shard per XCD).  In ct_walk_packet
+// everything that does not differ between the rays of a wave is scalar: the node comes through the
+// scalar cache into SGPRs, the stack holds one {entry, lane mask} per level, and since a CU has
+// four vector units but ONE scalar unit, that scalar control flow is what had to be made lean
+// (DESIGN.md section 4).  ct_walk<KIND,SS> below is the earlier per-lane design (every lane its own
+// stack and cursor over the binary tree); it stays as CTGPU_PACKET=0, as the fallback for trees
+// whose folded form could leave more than 64 entries pending, and as an independent
+// implementation the tests compare against.
 //
 // Scope: scenes without reflective materials and with at most 32 non-ambient lights.
 // Everything else takes the megakernel.  Semantics and citations: ct_device.h,
