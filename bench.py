@@ -239,6 +239,7 @@ def main():
                     "kernel": "frame trace = ct_sample_grid + ct_walk_packet<primary> + ct_walk_packet<shadow> + ct_shade "
                               "(the two ct_walk_packet launches are ~95 % of it; rocprof per-kernel split in profiles/)",
                     "kernel_ms": round(kernel_ms, 4),
+                    "traffic_rate": (round(traffic / (kernel_ms * 1e-3) / 1e9, 1) if traffic else None),   # measured HBM GB/s
                     "bytes_per_launch": int(launch_bytes), "bytes_per_ray": round(frame_bytes / max(work.rays, 1), 1),
                     "node_visits_per_ray": round(work.node_visits / max(work.rays, 1), 2),
                     "triangle_tests_per_ray": round(work.triangle_tests / max(work.rays, 1), 2)}
