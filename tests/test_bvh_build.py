@@ -69,3 +69,24 @@ def test_builder_is_deterministic(scenes, assets):
     assert a.lib.cth_node_hash(a.handle) == b.lib.cth_node_hash(b.handle)
     assert a.lib.cth_index_hash(a.handle) == b.lib.cth_index_hash(b.handle)
     assert a.lib.cth_triangle_hash(a.handle) == b.lib.cth_triangle_hash(b.handle)
+
+
+@pytest.mark.parametrize("name", ["bunny", "dragon"])
+def test_threaded_build_returns_the_same_tree(name, monkeypatch):
+    """Meshes of 50,000 triangles and more are built on several threads (top of the tree on one,
+    subtrees in parallel, slots numbered afterwards in the reference's allocation order): node for
+    node and index for index the result is the plain recursion's."""
+    import os
+    import __graft_entry__ as entry
+    entry.prepare_assets(need_dragon=(name == "dragon"))
+    path = os.path.join(os.path.dirname(__file__), "..", "assets", "scene_import_%s.json" % name)
+    built = {}
+    for threads in ("1", "3", "8"):
+        monkeypatch.setenv("CT_BVH_THREADS", threads)
+        scene = ca.HostScene(path)
+        built[threads] = (scene.nodes().copy(), scene.indexes().copy())
+        scene.close()
+    assert built["1"][0].shape[0] > 80000
+    for threads in ("3", "8"):
+        assert built[threads][0].tobytes() == built["1"][0].tobytes()
+        assert (built[threads][1] == built["1"][1]).all()
