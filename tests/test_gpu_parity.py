@@ -514,3 +514,23 @@ def test_rays_with_nan_box_parameters(tmp_path):
             assert (hits["triangle"] == ref["triangle"]).all() and (hits["t"].view(np.uint32) == ref["t"].view(np.uint32)).all()
         finally:
             ctx.close()
+
+
+@pytest.mark.parametrize("name,w,h", [("bunny", 320, 180), ("import", 256, 144)])
+def test_random_views(name, w, h, scenes, gpu_ctx):
+    """Many camera orientations and positions (every direction component non-zero, so the binary32
+    filter of the packet walk decides nearly everything): each frame equals the oracle's."""
+    scene, ctx = scenes(name), gpu_ctx(name)
+    rng = np.random.default_rng(2026)
+    base = np.array(scene.camera, dtype=np.float64)
+    for view in range(6):
+        angles = [np.float32(a) for a in rng.uniform(-0.35, 0.35, 3)]
+        rot = _oracle().camera_rotation(*angles)
+        for ss in (False, True):
+            frame = scene.frame(w, h, threads=4, supersampling=ss, rotation=rot, rng_seed=view)
+            jitter = rng.uniform(-0.05, 0.05, 3) * max(1.0, np.abs(base).max())
+            frame.cam_pos = (C.c_double * 3)(*(base + jitter))
+            gpu_fb, st = ctx.render(frame)
+            cpu_fb, cst = _oracle().render(scene.desc, frame, os_threads=4)
+            _compare(gpu_fb, cpu_fb, "%s view %d ss=%d" % (name, view, ss))
+            assert 0 < st.rays_shadow <= cst.rays_shadow          # (the oracle also traces the row the bitmap drops)
