@@ -876,21 +876,34 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                 // masked-out ones on stale rays, harmlessly) and the verdicts leave the vector unit
                 // as wave masks: no per-lane flag crosses a branch.
                 float tmin[4];
-                unsigned long long enter[4], unsure_of[4];
-                const uint32_t n_entries = sq.count();
-                // entries 0 and 1 always exist; 2 and 3 take part through their lane mask
-                const unsigned long long live[4] = {mask, mask, n_entries > 2u ? mask : 0ull, n_entries > 3u ? mask : 0ull};
+                unsigned long long enter[4];
+                // An absent entry (a QuadNode has 2..4) holds a one-point box at a corner of the scene's
+                // bound: its tmax - tmin is never positive, so it is never entered, and no scalar
+                // instruction is spent on "is entry k there".  Whether ANY lane is undecided on ANY
+                // entry comes from one compare: the least of |least_k| - margin_k must be positive
+                // (a NaN, or the rare ray that grazes that corner point, sends the wave to the exact
+                // levels, which look at the entries one by one).
+                float worst = 0.0f;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     float least, margin;
                     box_filter_f32(rf, sq.planes(k, 0), sq.planes(k, 1), sq.planes(k, 2), t, tmin[k], least, margin);
-                    // decided = |least| > margin (a NaN is undecided); passes = least > margin
-                    enter[k] = __ballot(least > margin) & live[k];
-                    unsure_of[k] = __ballot(!(__builtin_fabsf(least) > margin)) & live[k];
+                    enter[k] = __ballot(least > margin) & mask;
+                    const float slack = __builtin_fabsf(least) - margin;           // > 0: decided
+                    worst = (k == 0) ? slack : __builtin_fminf(worst, slack);
                 }
-                const unsigned long long unsure = (unsure_of[0] | unsure_of[1]) | (unsure_of[2] | unsure_of[3]);
+                const unsigned long long unsure = __ballot(!(worst > 0.0f)) & mask;
                 if (unsure != 0ull) {
                     PK_COUNT(4, 1);
+                    // which entries, which lanes: the filter once more, entry by entry
+                    const uint32_t n_entries = sq.count();
+                    unsigned long long unsure_of[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        float tmin_again, least, margin;
+                        box_filter_f32(rf, sq.planes(k, 0), sq.planes(k, 1), sq.planes(k, 2), t, tmin_again, least, margin);
+                        unsure_of[k] = ((uint32_t)k < n_entries) ? (__ballot(!(__builtin_fabsf(least) > margin)) & mask) : 0ull;
+                    }
                     // level 1 (some lane sits inside the bound): binary64 planes, one-step margins;
                     // level 2 (rarer still): the reference's divisions.  One box at a time, planes by
                     // vector load: this path is rare and must stay light on registers (it would

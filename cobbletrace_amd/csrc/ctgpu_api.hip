@@ -307,6 +307,9 @@ extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
                 if (fold && folds(c)) { add(s->nodes[c].left, c, 0); add(s->nodes[c].left + 1, c, 1); }
                 else add(c, head, side);
             }
+            // absent entries: a one-point box at the corner of the plane bound (never entered, see ct_walk_packet)
+            for (uint32_t k = node.count; k < 4; k++)
+                for (int a = 0; a < 3; a++) node.plane[k][a][0] = node.plane[k][a][1] = ctx->plane_bound[a];
             out.quads.push_back(node);
             out.source.insert(out.source.end(), source, source + 4);
         }
