@@ -534,3 +534,36 @@ def test_random_views(name, w, h, scenes, gpu_ctx):
             cpu_fb, cst = _oracle().render(scene.desc, frame, os_threads=4)
             _compare(gpu_fb, cpu_fb, "%s view %d ss=%d" % (name, view, ss))
             assert 0 < st.rays_shadow <= cst.rays_shadow          # (the oracle also traces the row the bitmap drops)
+
+
+def test_deep_chain_tree(monkeypatch):
+    """Triangles spaced geometrically along x make the midpoint builder peel one off per level: a
+    tree about as deep as it is large.  The packet walk then has dozens of entries pending (more
+    than its LDS levels: the rest spill to HBM), the per-lane walk a deep stack of its own."""
+    n = 56
+    xs = 2.2 ** np.arange(n) * 0.02
+    verts = np.array([[x, -1.0, 4.0 + 0.01 * i, x + 0.6 * x + 0.01, -1.0, 4.0 + 0.01 * i, x + 0.3 * x, 1.0, 4.0 + 0.01 * i]
+                      for i, x in enumerate(xs)])
+    scene = ca.HostScene(vertices=verts)
+    depth = scene.lib.cth_tree_depth(scene.handle)
+    assert depth >= 40
+    frame = scene.frame(256, 128, threads=4, supersampling=False)
+    frame.cam_pos = (C.c_double * 3)(1.0, 0.0, -6.0)
+    want, _ = _oracle().render(scene.desc, frame, os_threads=2)
+    assert (want != 0x333333).any()
+    for env in ({}, {"CTGPU_PACKET_LDS_LEVELS": "2"}, {"CTGPU_PACKET": "0", "CTGPU_LDS_DEPTH": "2"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        ctx = ca.GpuContext(0)
+        for k in env:
+            monkeypatch.delenv(k)
+        ctx.upload(scene.desc)
+        try:
+            for ss in (False, True):
+                f = scene.frame(256, 128, threads=4, supersampling=ss, rng_seed=4)
+                f.cam_pos = (C.c_double * 3)(1.0, 0.0, -6.0)
+                got, _ = ctx.render(f)
+                ref, _ = _oracle().render(scene.desc, f, os_threads=2)
+                _compare(got, ref, "chain tree %s ss=%d" % (env, ss))
+        finally:
+            ctx.close()
