@@ -567,3 +567,33 @@ def test_deep_chain_tree(monkeypatch):
                 _compare(got, ref, "chain tree %s ss=%d" % (env, ss))
         finally:
             ctx.close()
+
+
+def test_degenerate_inputs(tmp_path):
+    """Zero-area triangles, a directional light with the zero vector as direction (every shadow
+    ray is all-NaN arithmetic), an axis-parallel light direction (a zero component in every shadow
+    ray: exact level only), a point light sitting on a surface: whatever the reference does with
+    these, every GPU path does the same."""
+    tris = [([-2, -1, 1], [2, -1, 1], [2, -1, 6], (255, 255, 255), 100), ([-2, -1, 1], [2, -1, 6], [-2, -1, 6], (240, 240, 240), 100)]
+    for i in range(5):
+        for j in range(4):
+            x, z = -1.6 + 0.7 * i, 2.0 + 0.9 * j
+            tris.append(([x, -1, z], [x + 0.4, -1, z], [x + 0.2, 0.2 + 0.1 * j, z], (200, 60 + 30 * i, 60), 20))
+    tris.append(([0, 0, 3], [0, 0, 3], [0, 0, 3], (1, 2, 3), 5))                     # a point
+    tris.append(([-1, 0.5, 4], [1, 0.5, 4], [0, 0.5, 4], (3, 2, 1), 5))              # a segment
+    cases = {
+        "zero_direction": [{"type": "ambient", "intensity": 0.3}, {"type": "directional", "intensity": 0.5, "direction": [0, 0, 0]}],
+        "axis_direction": [{"type": "ambient", "intensity": 0.2}, {"type": "directional", "intensity": 0.6, "direction": [0, 1, 0]},
+                           {"type": "directional", "intensity": 0.2, "direction": [1, 0, 0]}],
+        "light_on_floor": [{"type": "ambient", "intensity": 0.2}, {"type": "point", "intensity": 0.7, "position": [0.25, -1, 3.5]}],
+    }
+    for name, lights in cases.items():
+        path = _write_scene(tmp_path, name + ".json", tris, lights, camera=(0, 0.4, -3))
+        for packet in ("1", "0"):
+            os.environ["CTGPU_PACKET"] = packet
+            try:
+                for ss in (False, True):
+                    gpu_fb, cpu_fb, st, cst = _render_both(path, 192, 144, threads=4, supersampling=ss, rng_seed=3)
+                    _compare(gpu_fb, cpu_fb, "%s packet=%s ss=%d" % (name, packet, ss))
+            finally:
+                del os.environ["CTGPU_PACKET"]
