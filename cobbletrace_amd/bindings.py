@@ -100,6 +100,7 @@ _GPU_SYMBOLS = {
     "ctgpu_assemble": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.POINTER(Partition), C.c_void_p, C.c_void_p, C.c_void_p]),
     "ctgpu_read_counters": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "ctgpu_trace_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
+    "ctgpu_trace_rays_packet": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
     "ctgpu_count_work": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.POINTER(Stats)]),
     "ctgpu_rand_stream": (C.c_int, [C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p]),
 }
@@ -296,6 +297,14 @@ class GpuContext:
         rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
         hits = np.zeros(rays.shape[0], dtype=HIT_DTYPE)
         self._check(self.lib.ctgpu_trace_rays(self.handle, rays.ctypes.data, rays.shape[0], hits.ctypes.data))
+        return hits
+
+    def trace_rays_packet(self, rays, any_hit=False):
+        """The per-ray hook through ct_walk_packet, the kernel the frames are traced with."""
+        rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
+        hits = np.zeros(rays.shape[0], dtype=HIT_DTYPE)
+        self._check(self.lib.ctgpu_trace_rays_packet(self.handle, rays.ctypes.data, rays.shape[0], 1 if any_hit else 0,
+                                                     hits.ctypes.data))
         return hits
 
     def partition_pixels(self, frame, part):

@@ -73,12 +73,15 @@ struct PipelineParams {
     uint32_t packet_lds_levels;  // stack levels whose per-lane tmin lives in LDS (deeper ones in HBM)
     uint32_t packet_depth;       // most entries the folded tree can have pending at once
     int32_t  thresh_r, thresh_a, thresh_b;
+    const ctgpu_ray *ray_list;   // ctgpu_trace_rays_packet: the caller's rays (n_samples of them) ...
+    ctgpu_hit *ray_hits;         // ... and where their results go
 };
 
 uint64_t pipeline_sample_count(const FrameParams &P, bool ss);
 int  pipeline_walk_occupancy(size_t lds_bytes);
 int  pipeline_packet_occupancy(uint32_t depth, uint32_t lds_levels);
 void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hipStream_t stream);
+void launch_packet_ray_list(const FrameParams &P, const PipelineParams &W, bool any_hit, hipStream_t stream);
 
 void launch_trace_tiles(const FrameParams &P, uint32_t n_tiles, bool ss, bool reflect, bool count, hipStream_t stream);
 void launch_trace_ray_list(const FrameParams &P, const ctgpu_ray *rays, uint64_t n, ctgpu_hit *hits, hipStream_t stream);

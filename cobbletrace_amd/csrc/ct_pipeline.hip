@@ -685,8 +685,14 @@ struct PacketStack {
     }
 };
 
+// KIND 0  primary rays of the frame            (closest hit -> hits[])
+// KIND 1  shadow rays of the frame             (any hit     -> shadow bytes)
+// KIND 2  caller's ray list, closest hit       (-> ctgpu_hit; the per-ray test hook ctgpu_trace_rays_packet:
+// KIND 3  caller's ray list, any hit               64 consecutive list entries are one packet, same walk code)
 template <int KIND, bool SS>
 __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const FrameParams P, const PipelineParams W) {
+    constexpr bool LIST = KIND >= 2;                 // rays come from W.ray_list instead of the frame's samples
+    constexpr bool ANY_HIT = KIND == 1 || KIND == 3; // a ray leaves the walk at its first ray.t update
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const uint32_t depth = W.packet_depth;                      // most entries the folded tree leaves pending
     PacketStack st;
@@ -699,8 +705,8 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
     const uint32_t lane = threadIdx.x;
     // (a wave mask becomes a lane predicate with inverse_ballot: the mask goes straight into EXEC)
     const uint64_t n_samples = W.n_samples;
-    const uint32_t n_shards = (KIND == 0) ? kShards : kShards * W.n_shadow_lights;
-    unsigned long long *heads = W.queue + (size_t)(KIND == 0 ? 0u : kShards) * 16u;
+    const uint32_t n_shards = (KIND != 1) ? kShards : kShards * W.n_shadow_lights;
+    unsigned long long *heads = W.queue + (size_t)(KIND != 1 ? 0u : kShards) * 16u;
     const uint64_t shard_span = ((n_samples + kShards - 1) / kShards + W.chunk - 1) / W.chunk * W.chunk;
     uint32_t shard = blockIdx.x % n_shards, shards_done = 0;
     uint64_t light_base = 0;
@@ -772,9 +778,15 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
             chunk_next += (wanted < avail) ? wanted : avail;
             if (take) {
                 const uint64_t sample = id - light_base;
-                float px, py;
-                bool live = sample_position<SS>(P, W, sample, px, py);
-                if (KIND == 0) {
+                float px = 0.0f, py = 0.0f;
+                float t_start = kNoHit;
+                bool live = LIST ? true : sample_position<SS>(P, W, sample, px, py);
+                if (LIST) {
+                    const ctgpu_ray *ray = W.ray_list + id;
+                    shadow_o = load_d3(ray->origin);
+                    d = load_d3(ray->direction);
+                    if (!ANY_HIT) t_start = ray->t;            // (an any-hit ray starts at 1e30f, raythread.cpp:303)
+                } else if (KIND == 0) {
                     if (live) d = primary_direction(P, px, py);
                     else W.hits[id] = make_uint2(__float_as_uint(kNoHit), kInvalidSample);
                 } else if (live) {
@@ -789,22 +801,27 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                     }
                 }
                 if (live) {
-                    t = kNoHit;
+                    t = t_start;
                     slot = kNoNode;
                     const d3 inv = make_d3(quick_reciprocal(d.x), quick_reciprocal(d.y), quick_reciprocal(d.z));
                     rf = ray_filter(RAY_O, d, inv, P.plane_bound);
-                    if (KIND == 1) ray_id = id;
+                    // every frame ray starts at ray.t = 1e30f and only drops to hits > 0.0001f, which the
+                    // approximate levels rely on; a caller's ray with another start (the reference's
+                    // reflected rays start at 0, raythread.cpp:373) takes the exact level throughout
+                    const bool positive_t = !LIST || t > 0.0f;
+                    if (!positive_t) { rf.inv_z_e2.y = __builtin_inff(); rf.noi_z_e.y = __builtin_inff(); }
+                    if (KIND != 0) ray_id = id;
                     has_ray = true;
                     // root box (bvh.cpp:205 at rootNodeIdx)
                     float tmin, tmax;
                     slab_approx(RAY_O, inv, P.root_min, P.root_max, tmin, tmax);
-                    if (!(box_verdict_positive_t(tmin, tmax, t, root_pass) & direction_allows_fast_slab(d))) {
+                    if (!(box_verdict_positive_t(tmin, tmax, t, root_pass) & direction_allows_fast_slab(d) & positive_t)) {
                         slab(RAY_O, d, P.root_min, P.root_max, tmin, tmax);
                         root_pass = tmax >= tmin && tmin < t && tmax > 0;
                     }
                 }
             }
-            if (KIND == 0) break;          // primary packets: one aligned run of 64 samples, no top-up
+            if (KIND != 1) break;          // primary / list packets: one aligned run of 64 ids, no top-up
         }
         n_traced += (uint32_t)__popcll(__ballot(has_ray));
         if (__ballot(has_ray) == 0ull) {
@@ -818,19 +835,19 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
         // direction component and the origin exactly on a box plane -- the one case folding is not
         // proven for, DESIGN B2) leaves the packet, and pass 1 walks those rays again from the root
         // over the same tree UNFOLDED (two entries per node, the reference's own structure).
-        for (int pass = 0; pass < 2; pass++) {
-        const QuadNode *quads = pass == 0 ? P.quads : P.quads_flat;
-        const uint32_t *quad_source = pass == 0 ? P.quad_source : P.quad_source_flat;
-        if (pass == 1) {
+        for (int walk_pass = 0; walk_pass < 2; walk_pass++) {
+        const QuadNode *quads = walk_pass == 0 ? P.quads : P.quads_flat;
+        const uint32_t *quad_source = walk_pass == 0 ? P.quad_source : P.quad_source_flat;
+        if (walk_pass == 1) {
             const unsigned long long again = __ballot(redo);
             if (again == 0ull) break;
             if (lane == 0) atomicAdd(&P.counters[15], (unsigned long long)__popcll(again));    // diagnostic
             if (redo) { t = kNoHit; slot = kNoNode; }
         }
-        unsigned long long tracing = pass == 0 ? __ballot(has_ray) : __ballot(redo);
-        uint32_t cur = pass == 0 ? P.quad_root : P.quad_root_flat;
-        unsigned long long mask = pass == 0 ? __ballot(root_pass) : tracing;
-        if (pass == 1) redo = false;
+        unsigned long long tracing = walk_pass == 0 ? __ballot(has_ray) : __ballot(redo);
+        uint32_t cur = walk_pass == 0 ? P.quad_root : P.quad_root_flat;
+        unsigned long long mask = walk_pass == 0 ? __ballot(root_pass) : tracing;
+        if (walk_pass == 1) redo = false;             // nothing below sets it again: pass 1 is the last word
         uint32_t sp = 0;
         // the wave-uniform part of the stack lives in three vector registers, entry i in lane i
         // (read back with v_readlane, the level as lane select): no LDS round trip on a pop
@@ -854,7 +871,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                         PK_COUNT(2, count);
                         PK_COUNT(3, (uint64_t)count * __popcll(mask));
                     }
-                    if (mine && (KIND == 0 || t == kNoHit)) {
+                    if (mine && (!ANY_HIT || t == kNoHit)) {
                         const d3 p1 = make_d3(tr.f64(0), tr.f64(1), tr.f64(2)), e1 = make_d3(tr.f64(3), tr.f64(4), tr.f64(5)),
                                  e2 = make_d3(tr.f64(6), tr.f64(7), tr.f64(8));
                         const float before = t;
@@ -863,7 +880,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                         if (hit && t != kNoHit && t < tclosest) slot = first + k;
                     }
                 }
-                if (KIND == 1) tracing &= __ballot(t == kNoHit);
+                if (ANY_HIT) tracing &= __ballot(t == kNoHit);
                 mask = 0ull;               // on to the pop below
                 PK_T1(1);
             } else {
@@ -912,7 +929,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
 #pragma unroll
                     for (int k = 0; k < 4; k++) todo |= __builtin_amdgcn_inverse_ballot_w64(unsure_of[k]) ? (1u << k) : 0u;
                     if (todo != 0u) {
-                        const bool fast = direction_allows_fast_slab(d);
+                        const bool fast = direction_allows_fast_slab(d) && (!LIST || t > 0.0f);
 #pragma nounroll
                         for (uint32_t k = 0; k < n_entries; k++) {
                             if (((todo >> k) & 1u) == 0u) continue;
@@ -920,13 +937,14 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                             const double *bmin = P.nodes[source >> 1].lmin + (source & 1u) * 6u, *bmax = bmin + 3;
                             const d3 inv = make_d3(quick_reciprocal(d.x), quick_reciprocal(d.y), quick_reciprocal(d.z));
                             float tmin64, tmax64;
-                            bool pass;
+                            bool verdict;
                             slab_approx(RAY_O, inv, bmin, bmax, tmin64, tmax64);
-                            if (!(box_verdict_positive_t(tmin64, tmax64, t, pass) & fast)) {
-                                redo |= slab_in_sequence(RAY_O, d, bmin, bmax, tmin64, tmax64) && pass == 0;
-                                pass = tmax64 >= tmin64 && tmin64 < t && tmax64 > 0;
+                            if (!(box_verdict_positive_t(tmin64, tmax64, t, verdict) & fast)) {
+                                const bool nan_parameter = slab_in_sequence(RAY_O, d, bmin, bmax, tmin64, tmax64);
+                                if (walk_pass == 0) redo |= nan_parameter;      // only the folded walk gives rays up
+                                verdict = tmax64 >= tmin64 && tmin64 < t && tmax64 > 0;
                             }
-                            passed |= pass ? (1u << k) : 0u;
+                            passed |= verdict ? (1u << k) : 0u;
                         }
                     }
                     // a NaN parameter: folding is not proven for this ray (DESIGN B2) -- it leaves the
@@ -1000,7 +1018,15 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
 
         // ---------------- retire the packet
         if (has_ray) {
-            if (KIND == 0) W.hits[packet_base + lane] = make_uint2(__float_as_uint(t), slot);
+            if (LIST) {
+                ctgpu_hit h;
+                h.t = t;
+                h.tclosest = (slot != kNoNode) ? t : kFarAway;         // *tclosest == ray.t once a triangle is recorded
+                h.triangle = (slot != kNoNode) ? P.tris[slot].triangle : 0u;
+                h.found = (t != kNoHit) ? 1u : 0u;
+                W.ray_hits[ray_id] = h;
+            }
+            else if (KIND == 0) W.hits[packet_base + lane] = make_uint2(__float_as_uint(t), slot);
             else if (t != kNoHit) W.shadow[ray_id] = 1;
         }
     }
@@ -1012,7 +1038,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
         atomicAdd(&P.counters[14], __builtin_amdgcn_s_memtime() - pk_begin);
     }
 #endif
-    if (lane == 0) atomicAdd(&P.counters[KIND == 0 ? 0 : 1], (unsigned long long)n_traced);
+    if (lane == 0 && !LIST) atomicAdd(&P.counters[KIND == 0 ? 0 : 1], (unsigned long long)n_traced);
 }
 #undef RAY_O
 
@@ -1161,6 +1187,15 @@ void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hip
     }
     if (ss) hipLaunchKernelGGL((ct_shade<true>), dim3(pixel_blocks), dim3(256), 0, stream, P, W);
     else hipLaunchKernelGGL((ct_shade<false>), dim3(pixel_blocks), dim3(256), 0, stream, P, W);
+}
+
+// the per-ray hook of the shared walk: W.ray_list[0 .. n_samples) -> W.ray_hits, 64 consecutive rays a packet
+void launch_packet_ray_list(const FrameParams &P, const PipelineParams &W, bool any_hit, hipStream_t stream) {
+    if (W.n_samples == 0) return;
+    const uint32_t depth_p = W.packet_depth;
+    const size_t lds_p = PacketStack::bytes(depth_p, W.packet_lds_levels < depth_p ? W.packet_lds_levels : depth_p);
+    if (any_hit) hipLaunchKernelGGL((ct_walk_packet<3, false>), dim3(W.walk_blocks), dim3(kWave), lds_p, stream, P, W);
+    else hipLaunchKernelGGL((ct_walk_packet<2, false>), dim3(W.walk_blocks), dim3(kWave), lds_p, stream, P, W);
 }
 
 }  // namespace ctd

@@ -578,6 +578,8 @@ bool pipeline_eligible(const ctgpu_ctx *ctx, const ctgpu_frame_desc *f) {
     return ctx->n_shadow_lights <= 32;
 }
 
+int fill_pipeline(ctgpu_ctx *ctx, uint64_t n_samples, PipelineParams &W);
+
 int launch_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, FrameParams &P, hipStream_t stream) {
     const bool ss = (f->flags & CTGPU_F_SUPERSAMPLE) != 0;
     if (!pipeline_eligible(ctx, f)) {
@@ -586,8 +588,23 @@ int launch_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, FrameParams &P, hipS
         return CTGPU_OK;
     }
     PipelineParams W;
+    int rc = fill_pipeline(ctx, pipeline_sample_count(P, ss), W); if (rc) return rc;
+
+    if (ss) HIP_TRY(ctx->coords.resize(W.n_samples));
+    HIP_TRY(ctx->hits.resize(W.n_samples));
+    HIP_TRY(ctx->shadow.resize(W.n_samples * std::max<uint32_t>(W.n_shadow_lights, 1)));
+    W.coords = ctx->coords.ptr; W.hits = ctx->hits.ptr; W.shadow = ctx->shadow.ptr;
+    HIP_TRY(hipMemsetAsync(ctx->queue.ptr, 0, 33 * 8 * 16 * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(ctx->shadow.ptr, 0, W.n_samples * std::max<uint32_t>(W.n_shadow_lights, 1), stream));
+    launch_pipeline(P, W, ss, stream);
+    HIP_TRY(hipGetLastError());
+    return CTGPU_OK;
+}
+
+// grid, queue chunk and stack buffers of the walk kernels for n_samples ray ids
+int fill_pipeline(ctgpu_ctx *ctx, uint64_t n_samples, PipelineParams &W) {
     std::memset(&W, 0, sizeof W);
-    W.n_samples = pipeline_sample_count(P, ss);
+    W.n_samples = n_samples;
     W.n_shadow_lights = ctx->n_shadow_lights;
     W.lds_depth = std::min<uint32_t>((uint32_t)ctx->lds_depth, std::max<uint32_t>(ctx->tree_depth, 1));
     W.spill_depth = std::max<uint32_t>(ctx->tree_depth, 1) - W.lds_depth;
@@ -608,18 +625,9 @@ int launch_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, FrameParams &P, hipS
     chunk = std::min<uint64_t>(std::max<uint64_t>((chunk + 63) / 64 * 64, 64), 4096);
     W.chunk = (uint32_t)chunk;
     W.thresh_r = ctx->walk_thresh[0]; W.thresh_a = ctx->walk_thresh[1]; W.thresh_b = ctx->walk_thresh[2];
-
-    if (ss) HIP_TRY(ctx->coords.resize(W.n_samples));
-    HIP_TRY(ctx->hits.resize(W.n_samples));
-    HIP_TRY(ctx->shadow.resize(W.n_samples * std::max<uint32_t>(W.n_shadow_lights, 1)));
     if (W.n_samples >= 0xfffffff0ull) return fail(CTGPU_ERR_ARG, "frame too large: %llu samples", (unsigned long long)W.n_samples);
     HIP_TRY(ctx->spill.resize((size_t)W.walk_blocks * (size_t)std::max(W.lds_depth + W.spill_depth, W.packet_depth) * 64 * 12 / 8 + 64));
-    W.coords = ctx->coords.ptr; W.hits = ctx->hits.ptr; W.shadow = ctx->shadow.ptr;
     W.queue = ctx->queue.ptr; W.spill = ctx->spill.ptr; W.shadow_lights = ctx->shadow_lights.ptr;
-    HIP_TRY(hipMemsetAsync(ctx->queue.ptr, 0, 33 * 8 * 16 * sizeof(unsigned long long), stream));
-    HIP_TRY(hipMemsetAsync(ctx->shadow.ptr, 0, W.n_samples * std::max<uint32_t>(W.n_shadow_lights, 1), stream));
-    launch_pipeline(P, W, ss, stream);
-    HIP_TRY(hipGetLastError());
     return CTGPU_OK;
 }
 
@@ -859,5 +867,46 @@ extern "C" int ctgpu_trace_rays(ctgpu_ctx *ctx, const ctgpu_ray *rays, uint64_t 
     (void)hipFree(d_rays);
     (void)hipFree(d_hits);
     if (e != hipSuccess) return fail(CTGPU_ERR_HIP, "ctgpu_trace_rays: %s", hipGetErrorString(e));
+    return check_overflow(ctx);
+}
+
+// The same hook through the kernel the frames are traced with: the caller's rays, 64 consecutive
+// ones a packet, walked by ct_walk_packet (folded tree, binary32 filter, exact levels, unfolded
+// second pass) exactly as the samples of a frame are.
+extern "C" int ctgpu_trace_rays_packet(ctgpu_ctx *ctx, const ctgpu_ray *rays, uint64_t n, uint32_t flags, ctgpu_hit *hits) {
+    if (!ctx || (n && (!rays || !hits))) return fail(CTGPU_ERR_ARG, "ctgpu_trace_rays_packet: null argument");
+    if (flags & ~(uint32_t)CTGPU_TRACE_ANY_HIT) return fail(CTGPU_ERR_ARG, "ctgpu_trace_rays_packet: unknown flags %u", flags);
+    if (!ctx->has_scene) return fail(CTGPU_ERR_NO_SCENE, "no scene uploaded");
+    if (ctx->quad_pending > 64u) return fail(CTGPU_ERR_STACK, "the packet walk does not serve this tree (%u entries pending)", ctx->quad_pending);
+    if (n == 0) return CTGPU_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    ctgpu_frame_desc f;
+    std::memset(&f, 0, sizeof f);
+    f.width = 8; f.height = 8; f.num_threads = 1; f.max_depth = 0;
+    f.cam_rot[0] = f.cam_rot[4] = f.cam_rot[8] = 1.0;
+    const ctgpu_partition whole = {8, 0, 1};
+    FrameParams P;
+    int rc = fill_params(ctx, &f, &whole, false, P); if (rc) return rc;
+    PipelineParams W;
+    rc = fill_pipeline(ctx, n, W); if (rc) return rc;
+    W.packet = 1;
+    ctgpu_ray *d_rays = nullptr;
+    ctgpu_hit *d_hits = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_rays, n * sizeof(ctgpu_ray)));
+    hipError_t e = hipMalloc((void **)&d_hits, n * sizeof(ctgpu_hit));
+    if (e != hipSuccess) { (void)hipFree(d_rays); return fail(CTGPU_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
+    e = hipMemcpy(d_rays, rays, n * sizeof(ctgpu_ray), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemsetAsync(ctx->queue.ptr, 0, 33 * 8 * 16 * sizeof(unsigned long long), ctx->stream);
+    if (e == hipSuccess) {
+        W.ray_list = d_rays;
+        W.ray_hits = d_hits;
+        launch_packet_ray_list(P, W, (flags & CTGPU_TRACE_ANY_HIT) != 0, ctx->stream);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(hits, d_hits, n * sizeof(ctgpu_hit), hipMemcpyDeviceToHost);
+    (void)hipFree(d_rays);
+    (void)hipFree(d_hits);
+    if (e != hipSuccess) return fail(CTGPU_ERR_HIP, "ctgpu_trace_rays_packet: %s", hipGetErrorString(e));
     return check_overflow(ctx);
 }

@@ -19,8 +19,9 @@
  *   ctgpu_render_partition /    the row-band split of HandleUpdates (raythread.cpp:574-588)
  *   ctgpu_assemble              re-cut into interleaved row tiles for N GPUs, and the merge of
  *                               the per-GPU tiles into the caller's framebuffer
- *   ctgpu_trace_rays            ClosestIntersection on caller-supplied rays (test / KAT hook)
- *                               raythread.cpp:197-228
+ *   ctgpu_trace_rays /          ClosestIntersection on caller-supplied rays (test / KAT hook),
+ *   ctgpu_trace_rays_packet     through the general kernel / through the frame kernel
+ *                               raythread.cpp:197-228, 303-307
  *   ctgpu_count_work            instrumented run returning node-visit / triangle-test counts
  *                               (the reference has gprof only)
  *
@@ -177,6 +178,15 @@ int  ctgpu_assemble(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, const ctgpu_p
 int  ctgpu_read_counters(ctgpu_ctx *ctx, ctgpu_stats *stats);
 
 int  ctgpu_trace_rays(ctgpu_ctx *ctx, const ctgpu_ray *rays, uint64_t n, ctgpu_hit *hits);
+
+/* The same per-ray hook through the kernel that traces the frames (the shared "packet" walk,
+ * ct_walk_packet): 64 consecutive rays of the list form one packet.  flags = 0: closest hit,
+ * results as ctgpu_trace_rays gives them (IntersectBVHClosest, bvh.cpp:198-222, under
+ * ClosestIntersection, raythread.cpp:197-228).  CTGPU_TRACE_ANY_HIT: the shadow query of
+ * ComputeLighting (raythread.cpp:303-307) -- every ray starts at t = 1e30f whatever `t` says and
+ * leaves at its first ray.t update; only `found` is comparable with a full traversal. */
+#define CTGPU_TRACE_ANY_HIT 1u
+int  ctgpu_trace_rays_packet(ctgpu_ctx *ctx, const ctgpu_ray *rays, uint64_t n, uint32_t flags, ctgpu_hit *hits);
 
 /* Instrumented render of the same frame (slower; no framebuffer): fills node_visits and
  * triangle_tests besides the ray counts.  These are the V_r / Q_r sums of the roofline model. */

@@ -516,6 +516,114 @@ def test_rays_with_nan_box_parameters(tmp_path):
             ctx.close()
 
 
+def _tables_scene(tmp_path):
+    """Flat-topped tables whose tops lie in the plane y = 0.5 and whose walls end there (box MAX planes
+    at y = 0.5 all the way down the tree), rows of tall triangles that cross that plane between and
+    behind the rows of tables (inner nodes hold both, deeper ones only tables), some walls ending
+    exactly at x = 0."""
+    tris = []
+    for j in range(4):
+        z0 = 1.0 + 1.3 * j
+        for i in range(7):
+            x0 = round((i - 3) * 0.4 - 0.4, 6)
+            x1, z1 = round(x0 + 0.3 + 0.1 * (i == 2), 6), z0 + 0.3
+            wall, top = (200, 200, 60 + 40 * j), (90, 160, 220)
+            tris.append(([x0, -1, z0], [x1, -1, z0], [x1, 0.5, z0], wall, 30))            # front wall, ends at y = 0.5
+            tris.append(([x0, -1, z0], [x1, 0.5, z0], [x0, 0.5, z0], wall, 30))
+            tris.append(([x0, 0.5, z0], [x1, 0.5, z0], [x1, 0.5, z1], top, 100))           # flat top in y = 0.5
+            tris.append(([x0, 0.5, z0], [x1, 0.5, z1], [x0, 0.5, z1], top, 100))
+        if j % 2:                                                                          # a row of tall ones behind
+            for i in range(9):
+                x = -1.9 + 0.42 * i
+                tris.append(([x, -1, z0 + 0.8], [x + 0.4, -1, z0 + 0.8], [x + 0.2, 2.0 - 0.1 * i, z0 + 0.8],
+                             (255, 70 + 20 * i, 70), 10))                                  # crosses y = 0.5
+    lights = [{"type": "ambient", "intensity": 0.3}, {"type": "point", "intensity": 0.6, "position": [0.3, 3, 0]},
+              {"type": "directional", "intensity": 0.2, "direction": [0.2, 1, -0.3]}]
+    return _write_scene(tmp_path, "tables.json", tris, lights, camera=(0, 0.5, -3))
+
+
+def test_nan_parameter_rays_that_hit(tmp_path):
+    """Camera height exactly on the MAX plane of many boxes: for the centre row (d.y == 0) that plane's
+    parameter is 0/0.  The reference's min / max macros (mymath.h:11-17) then DROP the x and y
+    constraints of such a box (bvh.cpp:165-179 evaluated in order), the ray enters it on its z range
+    alone and goes on to hit the tall triangles behind.  The packet walk must hand such rays to its
+    unfolded second pass and walk them there to the END (round 1 truncated that walk: a shadowed
+    variable let pass 1 give rays up again).  Frames and single rays, every path, against the oracle."""
+    scene = ca.HostScene(_tables_scene(tmp_path))
+    assert scene.desc.n_nodes > 30
+    w, h = 240, 160
+    rays = np.zeros(6400, dtype=ca.bindings.RAY_DTYPE)
+    rng = np.random.default_rng(4)
+    rays["origin"] = [0, 0.5, -3]
+    rays["direction"] = np.c_[rng.normal(size=6400) * 0.45, np.zeros(6400), np.ones(6400)]
+    rays["direction"][:640, 0] = 0.0                  # ... and a zero x component with walls ending at x = 0
+    rays["direction"][320:640, 1] = rng.normal(size=320) * 0.2
+    rays["t"] = np.float32(1e30)
+    ref = _oracle().trace_rays(scene.desc, rays)
+    assert ref["found"][640:].sum() > 1500            # the in-plane rays really hit (the tall triangles)
+    for packet in ("1", "0"):
+        os.environ["CTGPU_PACKET"] = packet
+        try:
+            ctx = ca.GpuContext(0)
+        finally:
+            del os.environ["CTGPU_PACKET"]
+        ctx.upload(scene.desc)
+        try:
+            for ss, sub in ((False, False), (True, False), (False, True)):
+                frame = scene.frame(w, h, threads=4, supersampling=ss, subsampling=sub, rng_seed=2)
+                got, st = ctx.render(frame)
+                want, cst = _oracle().render(scene.desc, frame, os_threads=2)
+                if not ss:
+                    centre = want[h // 2, w // 2 - h // 2: w // 2 + h // 2]
+                    assert ((centre != 0x333333) & (centre != 0)).sum() > h // 4       # the d.y == 0 row shows geometry
+                _compare(got, want, "camera on box max planes, packet=%s ss=%d sub=%d" % (packet, ss, sub))
+                assert (got == want).all()
+            for hits in (ctx.trace_rays(rays), ctx.trace_rays_packet(rays)):
+                assert (hits["found"] == ref["found"]).all()
+                assert (hits["triangle"] == ref["triangle"]).all()
+                assert (hits["t"].view(np.uint32) == ref["t"].view(np.uint32)).all()
+            assert (ctx.trace_rays_packet(rays, any_hit=True)["found"] == ref["found"]).all()
+        finally:
+            ctx.close()
+
+
+@pytest.mark.parametrize("name", ["cube", "import", "bunny"])
+def test_closest_hit_exact_through_the_packet_walk(name, scenes, gpu_ctx):
+    """north_star: intermediate float hits within 1e-4 rel, exact index -- here bit-exact t, tclosest and
+    index, on the kernel that renders the frames (ct_walk_packet), 64 list entries per packet: random
+    incoherent rays (every lane its own way through the shared walk), rays with zero direction
+    components (exact level, NaN / inf slabs), reflected-ray starts (t = 0, raythread.cpp:373), and
+    coherent camera-like bundles (where the binary32 filter decides nearly everything)."""
+    scene, ctx = scenes(name), gpu_ctx(name)
+    n = 200_000 if name != "cube" else 50_000
+    rays = _random_rays(scene, n, seed=12)
+    v = scene.vertices().reshape(-1, 3)
+    centre, span = (v.min(0) + v.max(0)) / 2, (v.max(0) - v.min(0)).max()
+    rng = np.random.default_rng(5)
+    bundle = np.zeros(n // 2, dtype=ca.bindings.RAY_DTYPE)
+    eye = centre + np.array([0.1, 0.2, -2.5]) * span
+    bundle["origin"] = eye
+    side = int(np.sqrt(len(bundle)))
+    gx, gy = np.meshgrid(np.linspace(-0.4, 0.4, side), np.linspace(-0.4, 0.4, side))
+    k = side * side
+    bundle["direction"][:k] = np.c_[gx.ravel(), gy.ravel(), np.ones(k)] * 0.7 + (centre - eye) / span * 0.3
+    bundle["direction"][k:] = rng.normal(size=(len(bundle) - k, 3))
+    bundle["t"] = np.float32(1e30)
+    for what, batch in (("random", rays), ("bundle", bundle), ("odd length", rays[:1000 + 37])):
+        got = ctx.trace_rays_packet(batch)
+        want = _oracle().trace_rays(scene.desc, batch)
+        assert (got["found"] == want["found"]).all(), what
+        assert (got["triangle"] == want["triangle"]).all(), what
+        assert (got["t"].view(np.uint32) == want["t"].view(np.uint32)).all(), what
+        assert (got["tclosest"].view(np.uint32) == want["tclosest"].view(np.uint32)).all(), what
+        assert want["found"].sum() > len(batch) // 20, what
+        # the shadow query of the same rays: hit or not is all ComputeLighting asks (raythread.cpp:303-307)
+        fresh = batch.copy()
+        fresh["t"] = np.float32(1e30)
+        shadowed = ctx.trace_rays_packet(fresh, any_hit=True)
+        assert (shadowed["found"] == _oracle().trace_rays(scene.desc, fresh)["found"]).all(), what
+
+
 @pytest.mark.parametrize("name,w,h", [("bunny", 320, 180), ("import", 256, 144)])
 def test_random_views(name, w, h, scenes, gpu_ctx):
     """Many camera orientations and positions (every direction component non-zero, so the binary32
