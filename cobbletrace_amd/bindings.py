@@ -56,7 +56,7 @@ class FrameDesc(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("rays_primary", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_reflect", C.c_uint64),
                 ("pixels_written", C.c_uint64), ("node_visits", C.c_uint64), ("triangle_tests", C.c_uint64),
-                ("kernel_ms", C.c_double), ("total_ms", C.c_double)]
+                ("kernel_ms", C.c_double), ("total_ms", C.c_double), ("rays_shadow_elided", C.c_uint64)]
 
     @property
     def rays(self):

@@ -10,6 +10,11 @@
 
 namespace ctd {
 
+// words of FrameParams::counters: 0 primary rays, 1 shadow rays, 2 reflected rays, 3 node visits, 4 triangle
+// tests, 5..14 diagnostic builds, 15 rays the packet walk walked again unfolded, 16 shadow rays not needed
+constexpr int kCounterWords = 24;
+constexpr int kCounterElided = 16;
+
 struct FrameParams {
     // scene (device pointers)
     const WideNode  *nodes;
@@ -53,7 +58,7 @@ struct FrameParams {
 
     // outputs
     uint32_t *out;                         // [local_rows][square]
-    unsigned long long *counters;          // primary, shadow, reflect, visits, tests
+    unsigned long long *counters;          // [kCounterWords] primary, shadow, reflect, visits, tests, diagnostics ...
     uint32_t *overflow;                    // set to 1 on traversal-stack overflow
 };
 
@@ -69,10 +74,12 @@ struct PipelineParams {
     uint32_t n_shadow_lights;
     uint32_t lds_depth, spill_depth, walk_blocks;
     uint32_t chunk;              // ray ids a wave reserves per queue atomic (multiple of 64)
+    uint32_t chunk_shadow;       // the same for the shadow walk (its candidates are only partly rays)
     uint32_t packet;             // 1: supersampled frames use ct_walk_packet (shared walk per wave)
     uint32_t packet_lds_levels;  // stack levels whose per-lane tmin lives in LDS (deeper ones in HBM)
     uint32_t packet_depth;       // most entries the folded tree can have pending at once
     int32_t  thresh_r, thresh_a, thresh_b;
+    uint32_t keep_every_shadow_ray;   // 1: ct_light_gate passes every hit sample's shadow rays (CTGPU_KEEP_SHADOW_RAYS)
     const ctgpu_ray *ray_list;   // ctgpu_trace_rays_packet: the caller's rays (n_samples of them) ...
     ctgpu_hit *ray_hits;         // ... and where their results go
 };

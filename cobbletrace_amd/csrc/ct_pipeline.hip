@@ -30,6 +30,8 @@
 #include "ct_params.h"
 #include "ct_raygen.h"
 
+#include <algorithm>
+
 using namespace ctd;
 
 namespace {
@@ -405,6 +407,7 @@ __device__ __forceinline__ void step_leaf(Walker &w, const TriRecord *__restrict
 
 template <int KIND, bool SS>
 __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk(const FrameParams P, const PipelineParams W) {
+    const uint32_t q_chunk = (KIND == 1) ? W.chunk_shadow : W.chunk;      // ray ids per queue atomic
     extern __shared__ __align__(16) unsigned char lds_raw[];
     WalkStack st;
     st.lds = (LdsEntry *)lds_raw;
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk(const FrameParam
     const uint64_t n_samples = W.n_samples;
     const uint32_t n_shards = (KIND == 0) ? kShards : kShards * W.n_shadow_lights;
     unsigned long long *heads = W.queue + (size_t)(KIND == 0 ? 0u : kShards) * 16u;
-    const uint64_t shard_span = ((n_samples + kShards - 1) / kShards + W.chunk - 1) / W.chunk * W.chunk;
+    const uint64_t shard_span = ((n_samples + kShards - 1) / kShards + q_chunk - 1) / q_chunk * q_chunk;
     uint32_t shard = blockIdx.x % n_shards, shards_done = 0;
     uint64_t light_base = 0;                 // first ray id of the light the current chunk belongs to
     Light shadow_light = Light{};
@@ -491,7 +494,7 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk(const FrameParam
                     // (reserving one chunk ahead to hide the atomic's round trip was tried: the chunk a
                     // busy wave sits on at the end of the launch costs more than the latency it hides)
                     unsigned long long offset = 0;
-                    if (lane == 0) offset = atomicAdd(heads + (size_t)shard * 16u, (unsigned long long)W.chunk);
+                    if (lane == 0) offset = atomicAdd(heads + (size_t)shard * 16u, (unsigned long long)q_chunk);
                     offset = __shfl(offset, 0);
                     const uint32_t light = shard / kShards, part = shard % kShards;
                     const uint64_t lo = (uint64_t)part * shard_span + offset;       // sample id within the light
@@ -501,7 +504,7 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk(const FrameParam
                         if (shards_done >= n_shards) { wave_drained = true; break; }
                         continue;
                     }
-                    uint64_t hi = lo + W.chunk;
+                    uint64_t hi = lo + q_chunk;
                     if (hi > ((uint64_t)part + 1u) * shard_span) hi = ((uint64_t)part + 1u) * shard_span;
                     if (hi > n_samples) hi = n_samples;
                     light_base = (uint64_t)light * n_samples;
@@ -527,9 +530,9 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk(const FrameParam
                             W.hits[id] = make_uint2(__float_as_uint(kNoHit), kInvalidSample);
                         }
                     } else if (live) {
-                        const uint2 h = W.hits[sample];
-                        live = __uint_as_float(h.x) != kNoHit;           // ClosestIntersection found something
+                        live = W.shadow[id] == 0;                        // ct_light_gate: a hit sample whose light can contribute
                         if (live) {
+                            const uint2 h = W.hits[sample];
                             // P = origin + tclosest * dir (raythread.cpp:360); tclosest = ray.t when a
                             // triangle was recorded, else 2^32
                             const float tclosest = (h.y != kNoNode) ? __uint_as_float(h.x) : kFarAway;
@@ -691,6 +694,7 @@ struct PacketStack {
 // KIND 3  caller's ray list, any hit               64 consecutive list entries are one packet, same walk code)
 template <int KIND, bool SS>
 __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const FrameParams P, const PipelineParams W) {
+    const uint32_t q_chunk = (KIND == 1) ? W.chunk_shadow : W.chunk;      // ray ids per queue atomic
     constexpr bool LIST = KIND >= 2;                 // rays come from W.ray_list instead of the frame's samples
     constexpr bool ANY_HIT = KIND == 1 || KIND == 3; // a ray leaves the walk at its first ray.t update
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -707,10 +711,10 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
     const uint64_t n_samples = W.n_samples;
     const uint32_t n_shards = (KIND != 1) ? kShards : kShards * W.n_shadow_lights;
     unsigned long long *heads = W.queue + (size_t)(KIND != 1 ? 0u : kShards) * 16u;
-    const uint64_t shard_span = ((n_samples + kShards - 1) / kShards + W.chunk - 1) / W.chunk * W.chunk;
+    const uint64_t shard_span = ((n_samples + kShards - 1) / kShards + q_chunk - 1) / q_chunk * q_chunk;
     uint32_t shard = blockIdx.x % n_shards, shards_done = 0;
-    uint64_t light_base = 0;
-    uint32_t light_index = 0;                // lights[] entry of the shadow rays in the current chunk
+    uint64_t light_base = 0, chunk_light_base = 0;       // first ray id of the packet's / the current chunk's light
+    uint32_t light_index = 0, chunk_light_index = 0;     // lights[] entry of the shadow rays in the packet / chunk
     const d3 eye = make_d3(P.cam[0], P.cam[1], P.cam[2]);
 
     // ray origin: the eye for every primary ray (kept in scalar registers), per lane for shadow rays
@@ -743,12 +747,13 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
         has_ray = false;
         root_pass = false;
         redo = false;
+        float px = 0.0f, py = 0.0f;
         for (;;) {
             const unsigned long long m_i = __ballot(!has_ray);
             if (m_i == 0ull || wave_drained) break;
             if (chunk_next >= chunk_end) {
                 unsigned long long offset = 0;
-                if (lane == 0) offset = atomicAdd(heads + (size_t)shard * 16u, (unsigned long long)W.chunk);
+                if (lane == 0) offset = atomicAdd(heads + (size_t)shard * 16u, (unsigned long long)q_chunk);
                 offset = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)offset) |
                          ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(offset >> 32)) << 32);
                 const uint32_t light = shard / kShards, part = shard % kShards;
@@ -759,14 +764,16 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                     if (shards_done >= n_shards) wave_drained = true;
                     continue;
                 }
-                uint64_t hi = lo + W.chunk;
+                uint64_t hi = lo + q_chunk;
                 if (hi > ((uint64_t)part + 1u) * shard_span) hi = ((uint64_t)part + 1u) * shard_span;
                 if (hi > n_samples) hi = n_samples;
-                light_base = (uint64_t)light * n_samples;
-                chunk_next = light_base + lo;
-                chunk_end = light_base + hi;
-                if (KIND == 1) light_index = (uint32_t)__builtin_amdgcn_readfirstlane((int)W.shadow_lights[light]);
-                // a packet never mixes lights (its rays should point the same way): start a new one
+                chunk_light_base = (uint64_t)light * n_samples;
+                chunk_next = chunk_light_base + lo;
+                chunk_end = chunk_light_base + hi;
+                if (KIND == 1) chunk_light_index = (uint32_t)__builtin_amdgcn_readfirstlane((int)W.shadow_lights[light]);
+                // a packet never mixes lights (its rays should point the same way) nor chunks (the next chunk
+                // this wave gets lies elsewhere in the image: topping up from it was measured, 5 % slower --
+                // it splits that chunk's rays over two packets, i.e. two walks through that region)
                 if (KIND == 1 && m_i != ~0ull) break;
             }
             const uint64_t avail = chunk_end - chunk_next;
@@ -774,51 +781,23 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
             const bool take = !has_ray && rank < avail;
             const uint64_t id = chunk_next + rank;
             if (KIND == 0) packet_base = chunk_next;      // every lane is free here: rank == lane
+            light_base = chunk_light_base;                // (the packet's light: it only ever takes from chunks of one)
+            light_index = chunk_light_index;
             const uint64_t wanted = (uint64_t)__popcll(m_i);
             chunk_next += (wanted < avail) ? wanted : avail;
+            // phase 1 (may run several times for a shadow packet): which ids become rays.  A shadow ray
+            // exists where ct_light_gate left a 0 -- a hit sample whose light could contribute.
             if (take) {
-                const uint64_t sample = id - light_base;
-                float px = 0.0f, py = 0.0f;
-                float t_start = kNoHit;
-                bool live = LIST ? true : sample_position<SS>(P, W, sample, px, py);
-                if (LIST) {
-                    const ctgpu_ray *ray = W.ray_list + id;
-                    shadow_o = load_d3(ray->origin);
-                    d = load_d3(ray->direction);
-                    if (!ANY_HIT) t_start = ray->t;            // (an any-hit ray starts at 1e30f, raythread.cpp:303)
-                } else if (KIND == 0) {
-                    if (live) d = primary_direction(P, px, py);
-                    else W.hits[id] = make_uint2(__float_as_uint(kNoHit), kInvalidSample);
-                } else if (live) {
-                    const uint2 h = W.hits[sample];
-                    live = __uint_as_float(h.x) != kNoHit;
-                    if (live) {
-                        const float tclosest = (h.y != kNoNode) ? __uint_as_float(h.x) : kFarAway;
-                        shadow_o = eye + scale((double)tclosest, primary_direction(P, px, py));
-                        const Light &shadow_light = P.lights[light_index];
-                        d = (shadow_light.type == CTGPU_LIGHT_POINT) ? load_d3(shadow_light.position) - shadow_o
-                                                                     : load_d3(shadow_light.direction);
-                    }
+                bool live = true;
+                if (KIND == 0) {
+                    live = sample_position<SS>(P, W, id, px, py);
+                    if (!live) W.hits[id] = make_uint2(__float_as_uint(kNoHit), kInvalidSample);
+                } else if (KIND == 1) {
+                    live = W.shadow[id] == 0;
                 }
                 if (live) {
-                    t = t_start;
-                    slot = kNoNode;
-                    const d3 inv = make_d3(quick_reciprocal(d.x), quick_reciprocal(d.y), quick_reciprocal(d.z));
-                    rf = ray_filter(RAY_O, d, inv, P.plane_bound);
-                    // every frame ray starts at ray.t = 1e30f and only drops to hits > 0.0001f, which the
-                    // approximate levels rely on; a caller's ray with another start (the reference's
-                    // reflected rays start at 0, raythread.cpp:373) takes the exact level throughout
-                    const bool positive_t = !LIST || t > 0.0f;
-                    if (!positive_t) { rf.inv_z_e2.y = __builtin_inff(); rf.noi_z_e.y = __builtin_inff(); }
                     if (KIND != 0) ray_id = id;
                     has_ray = true;
-                    // root box (bvh.cpp:205 at rootNodeIdx)
-                    float tmin, tmax;
-                    slab_approx(RAY_O, inv, P.root_min, P.root_max, tmin, tmax);
-                    if (!(box_verdict_positive_t(tmin, tmax, t, root_pass) & direction_allows_fast_slab(d) & positive_t)) {
-                        slab(RAY_O, d, P.root_min, P.root_max, tmin, tmax);
-                        root_pass = tmax >= tmin && tmin < t && tmax > 0;
-                    }
                 }
             }
             if (KIND != 1) break;          // primary / list packets: one aligned run of 64 ids, no top-up
@@ -827,6 +806,45 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
         if (__ballot(has_ray) == 0ull) {
             if (wave_drained) break;
             continue;
+        }
+        // phase 2 (once per packet, all its lanes together): the rays themselves
+        if (has_ray) {
+            float t_start = kNoHit;
+            if (LIST) {
+                const ctgpu_ray *ray = W.ray_list + ray_id;
+                shadow_o = load_d3(ray->origin);
+                d = load_d3(ray->direction);
+                if (!ANY_HIT) t_start = ray->t;            // (an any-hit ray starts at 1e30f, raythread.cpp:303)
+            } else if (KIND == 0) {
+                d = primary_direction(P, px, py);
+            } else {
+                // P = origin + tclosest * dir (raythread.cpp:360); tclosest = ray.t when a triangle was
+                // recorded, else 2^32
+                const uint64_t sample = ray_id - light_base;
+                (void)sample_position<SS>(P, W, sample, px, py);
+                const uint2 h = W.hits[sample];
+                const float tclosest = (h.y != kNoNode) ? __uint_as_float(h.x) : kFarAway;
+                shadow_o = eye + scale((double)tclosest, primary_direction(P, px, py));
+                const Light &shadow_light = P.lights[light_index];
+                d = (shadow_light.type == CTGPU_LIGHT_POINT) ? load_d3(shadow_light.position) - shadow_o
+                                                             : load_d3(shadow_light.direction);
+            }
+            t = t_start;
+            slot = kNoNode;
+            const d3 inv = make_d3(quick_reciprocal(d.x), quick_reciprocal(d.y), quick_reciprocal(d.z));
+            rf = ray_filter(RAY_O, d, inv, P.plane_bound);
+            // every frame ray starts at ray.t = 1e30f and only drops to hits > 0.0001f, which the
+            // approximate levels rely on; a caller's ray with another start (the reference's
+            // reflected rays start at 0, raythread.cpp:373) takes the exact level throughout
+            const bool positive_t = !LIST || t > 0.0f;
+            if (!positive_t) { rf.inv_z_e2.y = __builtin_inff(); rf.noi_z_e.y = __builtin_inff(); }
+            // root box (bvh.cpp:205 at rootNodeIdx)
+            float tmin, tmax;
+            slab_approx(RAY_O, inv, P.root_min, P.root_max, tmin, tmax);
+            if (!(box_verdict_positive_t(tmin, tmax, t, root_pass) & direction_allows_fast_slab(d) & positive_t)) {
+                slab(RAY_O, d, P.root_min, P.root_max, tmin, tmax);
+                root_pass = tmax >= tmin && tmin < t && tmax > 0;
+            }
         }
 
         // lanes still tracing (a shadow ray stops at its first hit, raythread.cpp:303-307); every
@@ -889,6 +907,22 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                 PK_COUNT(1, __popcll(mask));
                 const uint32_t node_id = cur;
                 const ScalarQuad sq = scalar_load_quad(quads + node_id);
+#ifdef CT_DUMMY_VALU                       // diagnostic builds: what N more vector / scalar instructions per visit cost
+                {
+                    float dummy = t;
+#pragma unroll
+                    for (int i = 0; i < CT_DUMMY_VALU; i++) asm volatile("v_add_f32 %0, %0, %0" : "+v"(dummy));
+                    asm volatile("" :: "v"(dummy));
+                }
+#endif
+#ifdef CT_DUMMY_SALU
+                {
+                    uint32_t dummy = node_id;
+#pragma unroll
+                    for (int i = 0; i < CT_DUMMY_SALU; i++) asm volatile("s_add_u32 %0, %0, %0" : "+s"(dummy) :: "scc");
+                    asm volatile("" :: "s"(dummy));
+                }
+#endif
                 // level 0: binary32 planes, verdicts with an error bound.  Every lane computes (the
                 // masked-out ones on stale rays, harmlessly) and the verdicts leave the vector unit
                 // as wave masks: no per-lane flag crosses a branch.
@@ -1047,11 +1081,14 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
 // raythread.cpp:353-366 (TraceRay without reflection), 275-327 (ComputeLighting with the
 // shadow decisions read from the mask), 482-498 (blend), color.h.
 // ------------------------------------------------------------------------------------
-// colour of one sample from its closest hit and its shadow flags
+// The shaded point of a sample: what TraceRay derives from the closest hit (raythread.cpp:357-366, 329-350).
+struct ShadedPoint {
+    d3 position, normal, view;
+    Material material;
+};
 template <bool SS>
-__device__ __forceinline__ uint32_t shade_sample(const FrameParams &P, const PipelineParams &W, uint64_t id, uint32_t xi, uint32_t yi) {
-    const uint2 h = W.hits[id];
-    if (__uint_as_float(h.x) == kNoHit) return kBackground;
+__device__ __forceinline__ ShadedPoint shaded_point(const FrameParams &P, const PipelineParams &W, uint64_t id, uint2 h,
+                                                    uint32_t xi, uint32_t yi) {
     const d3 eye = make_d3(P.cam[0], P.cam[1], P.cam[2]);
     float cx, cy;
     if (SS) { const float2 c = W.coords[id]; cx = c.x; cy = c.y; }
@@ -1060,37 +1097,108 @@ __device__ __forceinline__ uint32_t shade_sample(const FrameParams &P, const Pip
     const uint32_t rec_slot = (h.y != kNoNode) ? h.y : P.slot_of_triangle0;
     const float tclosest = (h.y != kNoNode) ? __uint_as_float(h.x) : kFarAway;
     const TriRecord *rec = P.tris + rec_slot;
-    const Material m = P.materials[rec->triangle];
-    const d3 position = eye + scale((double)tclosest, dir);
-    d3 normal = cross(load_d3(rec->e1), load_d3(rec->e2));
-    if (!(dotf(normal, dir) < 0)) normal = -normal;
-    const d3 view = -dir;
+    ShadedPoint s;
+    s.material = P.materials[rec->triangle];
+    s.position = eye + scale((double)tclosest, dir);
+    s.normal = cross(load_d3(rec->e1), load_d3(rec->e2));
+    if (!(dotf(s.normal, dir) < 0)) s.normal = -s.normal;
+    s.view = -dir;
+    return s;
+}
+// vector towards a non-ambient light (raythread.cpp:289-296)
+__device__ __forceinline__ d3 towards_light(const Light &L, const d3 &position) {
+    return (L.type == CTGPU_LIGHT_POINT) ? load_d3(L.position) - position : load_d3(L.direction);
+}
+// the two quantities ComputeLighting gates a light's contribution on (raythread.cpp:309-325): the light
+// adds something only if n.l > 0, or (with a specular exponent) r.v > 0 -- whatever the shadow ray says
+__device__ __forceinline__ float diffuse_reach(const ShadedPoint &s, const d3 &to_light) { return dotf(s.normal, to_light); }
+__device__ __forceinline__ float specular_reach(const ShadedPoint &s, const d3 &to_light, d3 &reflected) {
+    const double nl = (double)dotf(s.normal, to_light);
+    reflected = scale(nl, scale(2.0, s.normal)) - to_light;
+    return dotf(reflected, s.view);
+}
+
+// colour of one sample from its closest hit and its shadow flags
+template <bool SS>
+__device__ __forceinline__ uint32_t shade_sample(const FrameParams &P, const PipelineParams &W, uint64_t id, uint32_t xi, uint32_t yi) {
+    const uint2 h = W.hits[id];
+    if (__uint_as_float(h.x) == kNoHit) return kBackground;
+    const ShadedPoint s = shaded_point<SS>(P, W, id, h, xi, yi);
 
     float intensity = 0.0f;
     uint32_t shadow_slot = 0;
     for (uint32_t li = 0; li < P.n_lights; li++) {
         const Light L = P.lights[li];
-        d3 to_light;
         if (L.type == CTGPU_LIGHT_AMBIENT) { intensity += L.intensity; continue; }
-        else if (L.type == CTGPU_LIGHT_POINT) to_light = load_d3(L.position) - position;
-        else if (L.type == CTGPU_LIGHT_DIRECTIONAL) to_light = load_d3(L.direction);
-        else continue;
-        const bool in_shadow = W.shadow[(size_t)shadow_slot * W.n_samples + id] != 0;
+        else if (L.type != CTGPU_LIGHT_POINT && L.type != CTGPU_LIGHT_DIRECTIONAL) continue;
+        const d3 to_light = towards_light(L, s.position);
+        // 1: the shadow ray found something; 2: ct_light_gate saw that this light adds nothing here
+        const bool skip = W.shadow[(size_t)shadow_slot * W.n_samples + id] != 0;
         shadow_slot += 1;
-        if (in_shadow) continue;
-        const float n_dot_l = dotf(normal, to_light);
-        if (n_dot_l > 0) intensity += L.intensity * n_dot_l / (lengthf(normal) * lengthf(to_light));
-        if (m.specular != -1) {
-            const double nl = (double)dotf(normal, to_light);
-            const d3 reflected = scale(nl, scale(2.0, normal)) - to_light;
-            const float r_dot_v = dotf(reflected, view);
+        if (skip) continue;
+        const float n_dot_l = diffuse_reach(s, to_light);
+        if (n_dot_l > 0) intensity += L.intensity * n_dot_l / (lengthf(s.normal) * lengthf(to_light));
+        if (s.material.specular != -1) {
+            d3 reflected;
+            const float r_dot_v = specular_reach(s, to_light, reflected);
             if (r_dot_v > 0) {
-                const float base = r_dot_v / (lengthf(reflected) * lengthf(view));
-                intensity = (float)((double)intensity + (double)L.intensity * pow((double)base, (double)m.specular));
+                const float base = r_dot_v / (lengthf(reflected) * lengthf(s.view));
+                intensity = (float)((double)intensity + (double)L.intensity * pow((double)base, (double)s.material.specular));
             }
         }
     }
-    return shade_value(m.color, intensity);
+    return shade_value(s.material.color, intensity);
+}
+
+// ------------------------------------------------------------------------------------
+// ct_light_gate: which shadow rays the frame needs.  ComputeLighting (raythread.cpp:275-327) sends a
+// shadow ray to every non-ambient light from every hit and only then looks at n.l and r.v; when
+// neither is positive the light adds nothing whether it is blocked or not, so that ray's answer is
+// never used.  One lane per sample, between the primary and the shadow walk: shadow[light][sample]
+// = 0 where the shadow walk has to find out, 2 where there is nothing to find out (no hit, or a
+// light that cannot contribute -- the same float comparisons ct_shade makes afterwards, on the same
+// operands).  The shadow walk writes 1 where a light is blocked; ct_shade skips a light on 1 and 2.
+// ------------------------------------------------------------------------------------
+template <bool SS>
+__global__ __launch_bounds__(256) void ct_light_gate(const FrameParams P, const PipelineParams W) {
+    // (a fixed grid that strides over the samples, one counter atomic per block at the end: one atomic
+    // per wave on a single word would take longer than the whole kernel, ~11 ns each)
+    __shared__ uint32_t block_elided[4];
+    uint32_t elided = 0;
+    for (uint64_t id = (uint64_t)blockIdx.x * 256u + threadIdx.x; id < W.n_samples; id += (uint64_t)gridDim.x * 256u) {
+        const uint2 h = W.hits[id];
+        const bool hit = __uint_as_float(h.x) != kNoHit;         // (samples outside the frame are stored as misses)
+        ShadedPoint s = ShadedPoint{};
+        if (hit) {
+            const PixelOfSample px = pixel_of<SS>(P, id);
+            uint32_t yi = 0;
+            (void)pixel_in_frame(P, px.xi, px.local_row, yi);
+            s = shaded_point<SS>(P, W, id, h, px.xi, yi);
+        }
+        for (uint32_t k = 0; k < W.n_shadow_lights; k++) {
+            uint8_t verdict = 2;
+            if (hit && W.keep_every_shadow_ray) verdict = 0;
+            else if (hit) {
+                const Light L = P.lights[W.shadow_lights[k]];
+                const d3 to_light = towards_light(L, s.position);
+                bool contributes = diffuse_reach(s, to_light) > 0;
+                if (!contributes && s.material.specular != -1) {
+                    d3 reflected;
+                    contributes = specular_reach(s, to_light, reflected) > 0;
+                }
+                verdict = contributes ? 0 : 2;
+                elided += contributes ? 0u : 1u;
+            }
+            W.shadow[(size_t)k * W.n_samples + id] = verdict;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) elided += __shfl_down(elided, off);
+    if ((threadIdx.x & 63u) == 0) block_elided[threadIdx.x >> 6] = elided;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = block_elided[0] + block_elided[1] + block_elided[2] + block_elided[3];
+        if (total) atomicAdd(&P.counters[kCounterElided], (unsigned long long)total);
+    }
 }
 
 template <bool SS>
@@ -1163,6 +1271,7 @@ void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hip
     if (W.n_samples == 0) return;
     const uint32_t pixel_slots = (uint32_t)(ss ? W.n_samples / 16u : W.n_samples);
     const uint32_t pixel_blocks = (pixel_slots + 255u) / 256u;
+    const uint32_t sample_blocks = (uint32_t)std::min<uint64_t>((W.n_samples + 255u) / 256u, 2048u);      // ct_light_gate strides
     if (ss) hipLaunchKernelGGL(ct_sample_grid, dim3(pixel_blocks), dim3(256), 0, stream, P, W);
     if (W.packet) {
         // shared walk: a wave holds 2x2 pixels x 16 samples (supersampled) or an 8x8 pixel tile
@@ -1170,19 +1279,31 @@ void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hip
         const size_t lds_p = PacketStack::bytes(depth_p, W.packet_lds_levels < depth_p ? W.packet_lds_levels : depth_p);
         if (ss) {
             hipLaunchKernelGGL((ct_walk_packet<0, true>), dim3(W.walk_blocks), dim3(kWave), lds_p, stream, P, W);
-            if (W.n_shadow_lights) hipLaunchKernelGGL((ct_walk_packet<1, true>), dim3(W.walk_blocks), dim3(kWave), lds_p, stream, P, W);
+            if (W.n_shadow_lights) {
+                hipLaunchKernelGGL((ct_light_gate<true>), dim3(sample_blocks), dim3(256), 0, stream, P, W);
+                hipLaunchKernelGGL((ct_walk_packet<1, true>), dim3(W.walk_blocks), dim3(kWave), lds_p, stream, P, W);
+            }
         } else {
             hipLaunchKernelGGL((ct_walk_packet<0, false>), dim3(W.walk_blocks), dim3(kWave), lds_p, stream, P, W);
-            if (W.n_shadow_lights) hipLaunchKernelGGL((ct_walk_packet<1, false>), dim3(W.walk_blocks), dim3(kWave), lds_p, stream, P, W);
+            if (W.n_shadow_lights) {
+                hipLaunchKernelGGL((ct_light_gate<false>), dim3(sample_blocks), dim3(256), 0, stream, P, W);
+                hipLaunchKernelGGL((ct_walk_packet<1, false>), dim3(W.walk_blocks), dim3(kWave), lds_p, stream, P, W);
+            }
         }
     } else {
         const size_t lds = (size_t)W.lds_depth * kWave * 12u;      // entries + parent words
         if (ss) {
             hipLaunchKernelGGL((ct_walk<0, true>), dim3(W.walk_blocks), dim3(kWave), lds, stream, P, W);
-            if (W.n_shadow_lights) hipLaunchKernelGGL((ct_walk<1, true>), dim3(W.walk_blocks), dim3(kWave), lds, stream, P, W);
+            if (W.n_shadow_lights) {
+                hipLaunchKernelGGL((ct_light_gate<true>), dim3(sample_blocks), dim3(256), 0, stream, P, W);
+                hipLaunchKernelGGL((ct_walk<1, true>), dim3(W.walk_blocks), dim3(kWave), lds, stream, P, W);
+            }
         } else {
             hipLaunchKernelGGL((ct_walk<0, false>), dim3(W.walk_blocks), dim3(kWave), lds, stream, P, W);
-            if (W.n_shadow_lights) hipLaunchKernelGGL((ct_walk<1, false>), dim3(W.walk_blocks), dim3(kWave), lds, stream, P, W);
+            if (W.n_shadow_lights) {
+                hipLaunchKernelGGL((ct_light_gate<false>), dim3(sample_blocks), dim3(256), 0, stream, P, W);
+                hipLaunchKernelGGL((ct_walk<1, false>), dim3(W.walk_blocks), dim3(kWave), lds, stream, P, W);
+            }
         }
     }
     if (ss) hipLaunchKernelGGL((ct_shade<true>), dim3(pixel_blocks), dim3(256), 0, stream, P, W);

@@ -20,7 +20,7 @@ using namespace ctd;
 
 // sizes the bindings (cobbletrace_amd/bindings.py) rely on
 static_assert(sizeof(ctgpu_node) == 64 && sizeof(ctgpu_light) == 56 && sizeof(ctgpu_material) == 12, "scene records");
-static_assert(sizeof(ctgpu_scene_desc) == 56 && sizeof(ctgpu_frame_desc) == 136 && sizeof(ctgpu_stats) == 64, "descriptors");
+static_assert(sizeof(ctgpu_scene_desc) == 56 && sizeof(ctgpu_frame_desc) == 136 && sizeof(ctgpu_stats) == 72, "descriptors");
 static_assert(sizeof(ctgpu_ray) == 56 && sizeof(ctgpu_hit) == 16 && sizeof(ctgpu_partition) == 12, "test-hook records");
 
 // ------------------------------------------------------------------ error plumbing
@@ -97,7 +97,9 @@ struct ctgpu_ctx {
     int lds_depth = 8;                          // 6 KB of LDS per wave; deeper entries spill to HBM
     int blocks_per_cu = 0;                      // 0 = occupancy query
     int chunk = 0;                              // 0 = sized from the frame
+    int chunk_shadow = 0;                       // 0 = same as chunk
     int packet_lds_levels = 14;                 // per-lane tmin levels kept in LDS by the packet walk
+    bool keep_shadow_rays = false;              // CTGPU_KEEP_SHADOW_RAYS=1: trace the shadow rays whose answer cannot matter, too
     bool packet_walk = true;                    // ct_walk_packet for supersampled frames (CTGPU_PACKET=0: per-lane walk)
     bool force_megakernel = false;
 
@@ -165,9 +167,9 @@ extern "C" int ctgpu_create(int device, ctgpu_ctx **out) {
     HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&ctx->ev0));
     HIP_TRY(hipEventCreate(&ctx->ev1));
-    HIP_TRY(ctx->counters.resize(16));
+    HIP_TRY(ctx->counters.resize(kCounterWords));
     HIP_TRY(ctx->overflow.resize(1));
-    HIP_TRY(hipMemset(ctx->counters.ptr, 0, 16 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(ctx->counters.ptr, 0, kCounterWords * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(ctx->overflow.ptr, 0, sizeof(uint32_t)));
     if (const char *t = std::getenv("CTGPU_THRESH")) {   // tuning knob: "a,b,c"
         int a, b, c;
@@ -181,7 +183,9 @@ extern "C" int ctgpu_create(int device, ctgpu_ctx **out) {
     if (const char *t = std::getenv("CTGPU_LDS_DEPTH")) ctx->lds_depth = std::max(1, std::atoi(t));
     if (const char *t = std::getenv("CTGPU_BLOCKS_PER_CU")) ctx->blocks_per_cu = std::max(0, std::atoi(t));
     if (const char *t = std::getenv("CTGPU_CHUNK")) ctx->chunk = std::max(0, std::atoi(t));
+    if (const char *t = std::getenv("CTGPU_CHUNK_SHADOW")) ctx->chunk_shadow = std::max(0, std::atoi(t));
     if (const char *t = std::getenv("CTGPU_PACKET")) ctx->packet_walk = std::atoi(t) != 0;
+    if (const char *t = std::getenv("CTGPU_KEEP_SHADOW_RAYS")) ctx->keep_shadow_rays = std::atoi(t) != 0;
     if (const char *t = std::getenv("CTGPU_PACKET_LDS_LEVELS")) ctx->packet_lds_levels = std::max(1, std::atoi(t));
     if (const char *t = std::getenv("CTGPU_FORCE_MEGAKERNEL")) ctx->force_megakernel = std::atoi(t) != 0;
     hipDeviceProp_t prop;
@@ -539,7 +543,7 @@ int check_overflow(ctgpu_ctx *ctx) {
 }
 
 int read_counters(ctgpu_ctx *ctx, ctgpu_stats *st) {
-    unsigned long long c[16];
+    unsigned long long c[kCounterWords];
     HIP_TRY(hipMemcpy(c, ctx->counters.ptr, sizeof c, hipMemcpyDeviceToHost));
     if (std::getenv("CTGPU_DEBUG_PHASES") && c[5])
         std::fprintf(stderr, "phases: A %llu x %.1f lanes (%.0f cyc each), B %llu x %.1f lanes (%.0f cyc), C %llu x %.1f lanes (%.0f cyc)\n", c[5],
@@ -561,6 +565,7 @@ int read_counters(ctgpu_ctx *ctx, ctgpu_stats *st) {
     if (st) {
         st->rays_primary = c[0]; st->rays_shadow = c[1]; st->rays_reflect = c[2];
         st->node_visits = c[3]; st->triangle_tests = c[4];
+        st->rays_shadow_elided = c[kCounterElided];
     }
     return CTGPU_OK;
 }
@@ -595,7 +600,6 @@ int launch_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, FrameParams &P, hipS
     HIP_TRY(ctx->shadow.resize(W.n_samples * std::max<uint32_t>(W.n_shadow_lights, 1)));
     W.coords = ctx->coords.ptr; W.hits = ctx->hits.ptr; W.shadow = ctx->shadow.ptr;
     HIP_TRY(hipMemsetAsync(ctx->queue.ptr, 0, 33 * 8 * 16 * sizeof(unsigned long long), stream));
-    HIP_TRY(hipMemsetAsync(ctx->shadow.ptr, 0, W.n_samples * std::max<uint32_t>(W.n_shadow_lights, 1), stream));
     launch_pipeline(P, W, ss, stream);
     HIP_TRY(hipGetLastError());
     return CTGPU_OK;
@@ -606,6 +610,7 @@ int fill_pipeline(ctgpu_ctx *ctx, uint64_t n_samples, PipelineParams &W) {
     std::memset(&W, 0, sizeof W);
     W.n_samples = n_samples;
     W.n_shadow_lights = ctx->n_shadow_lights;
+    W.keep_every_shadow_ray = ctx->keep_shadow_rays ? 1u : 0u;
     W.lds_depth = std::min<uint32_t>((uint32_t)ctx->lds_depth, std::max<uint32_t>(ctx->tree_depth, 1));
     W.spill_depth = std::max<uint32_t>(ctx->tree_depth, 1) - W.lds_depth;
     const size_t lds_bytes = (size_t)W.lds_depth * 64 * 12;
@@ -624,6 +629,8 @@ int fill_pipeline(ctgpu_ctx *ctx, uint64_t n_samples, PipelineParams &W) {
     uint64_t chunk = ctx->chunk > 0 ? (uint64_t)ctx->chunk : (W.n_samples >= (4u << 20) ? 128u : 64u);
     chunk = std::min<uint64_t>(std::max<uint64_t>((chunk + 63) / 64 * 64, 64), 4096);
     W.chunk = (uint32_t)chunk;
+    uint64_t chunk_shadow = ctx->chunk_shadow > 0 ? (uint64_t)ctx->chunk_shadow : chunk;
+    W.chunk_shadow = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((chunk_shadow + 63) / 64 * 64, 64), 4096);
     W.thresh_r = ctx->walk_thresh[0]; W.thresh_a = ctx->walk_thresh[1]; W.thresh_b = ctx->walk_thresh[2];
     if (W.n_samples >= 0xfffffff0ull) return fail(CTGPU_ERR_ARG, "frame too large: %llu samples", (unsigned long long)W.n_samples);
     HIP_TRY(ctx->spill.resize((size_t)W.walk_blocks * (size_t)std::max(W.lds_depth + W.spill_depth, W.packet_depth) * 64 * 12 / 8 + 64));
@@ -802,6 +809,7 @@ extern "C" int ctgpu_render_multi(ctgpu_ctx *const *ctxs, int n_ctx, const ctgpu
         rc = read_counters(c, &st); if (rc) return rc;
         rc = check_overflow(c); if (rc) return rc;
         total.rays_primary += st.rays_primary; total.rays_shadow += st.rays_shadow; total.rays_reflect += st.rays_reflect;
+        total.rays_shadow_elided += st.rays_shadow_elided;
     }
     HIP_TRY(hipSetDevice(root->device));
     float ms = 0.0f;
@@ -823,7 +831,7 @@ extern "C" int ctgpu_count_work(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, c
     rc = fill_params(ctx, frame, &whole, true, P); if (rc) return rc;
     HIP_TRY(ctx->tiles.resize((size_t)P.local_rows * P.square));
     P.out = ctx->tiles.ptr;
-    HIP_TRY(hipMemsetAsync(ctx->counters.ptr, 0, 16 * sizeof(unsigned long long), ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->counters.ptr, 0, kCounterWords * sizeof(unsigned long long), ctx->stream));
     const bool ss = (frame->flags & CTGPU_F_SUPERSAMPLE) != 0;
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
     launch_trace_tiles(P, tile_count(P), ss, ctx->has_reflection && frame->max_depth > 0, true, ctx->stream);

@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define CTGPU_ABI_VERSION 1
+#define CTGPU_ABI_VERSION 2
 
 typedef struct ctgpu_ctx ctgpu_ctx;
 
@@ -115,6 +115,9 @@ typedef struct ctgpu_stats {
     uint64_t node_visits, triangle_tests;               /* only from ctgpu_count_work */
     double   kernel_ms;                                 /* HIP-event time of the trace kernel(s) */
     double   total_ms;                                  /* dispatch -> pixels in the destination */
+    uint64_t rays_shadow_elided;     /* shadow rays ComputeLighting would start (raythread.cpp:303) whose answer
+                                        cannot change the pixel (n.l <= 0 and no specular reach) and which are
+                                        therefore not traced: rays_shadow + rays_shadow_elided is the reference's count */
 } ctgpu_stats;
 
 /* ---- partition of one frame over several GPUs ---- */

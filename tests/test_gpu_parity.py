@@ -197,7 +197,8 @@ def test_dragon_full_size_properties(scenes, gpu_ctx):
     b, sb = ctx.render(frame)
     assert (a == b).all() and sa.rays == sb.rays                  # idempotent
     hits = int(((a != 0x333333) & (a != 0)).sum())
-    assert sa.rays_shadow == 2 * hits                             # two non-ambient lights per hit
+    # two non-ambient lights per hit: traced, or left out because the light cannot contribute there
+    assert sa.rays_shadow + sa.rays_shadow_elided == 2 * hits and 0 < sa.rays_shadow_elided < hits * 2
     assert sa.rays_primary == 1080 * 1056 - 1080                  # rendered rows x square, minus the dropped row
     assert (a[1:25] == 0).all() and (a[0] == 0).all() and (a[:, :420] == 0).all() and (a[:, 1500:] == 0).all()
     # four bands (of 32) against the oracle, bit for bit
@@ -205,6 +206,70 @@ def test_dragon_full_size_properties(scenes, gpu_ctx):
     rows = cpu_fb.any(axis=1)
     assert rows.sum() == 4 * 33
     _compare(a[rows], cpu_fb[rows], "dragon stand-in 1920x1080 bands 14-17")
+
+
+def _oracle_bands(scene, frame, bands):
+    """Rows of the frame the oracle renders for the given row bands (worker partitions,
+    raythread.cpp:574-588), one band at a time so that any set of bands can be picked."""
+    rows = np.zeros(frame.height, dtype=bool)
+    fb = np.zeros((frame.height, frame.width), dtype=np.uint32)
+    for b in bands:
+        part, _ = _oracle().render(scene.desc, frame, os_threads=1, band_first=b, band_count=1)
+        band_rows = part.any(axis=1)
+        fb[band_rows] = part[band_rows]
+        rows |= band_rows
+    return fb, rows
+
+
+def _oracle_bands_parallel(scene, frame, bands):
+    """The same with the bands traced concurrently (one oracle worker thread per band)."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(len(bands), 8)) as pool:
+        parts = list(pool.map(lambda b: _oracle_bands(scene, frame, [b]), bands))
+    fb = np.zeros((frame.height, frame.width), dtype=np.uint32)
+    rows = np.zeros(frame.height, dtype=bool)
+    for part, r in parts:
+        fb[r] = part[r]
+        rows |= r
+    return fb, rows
+
+
+def test_dragon_headline_frame_supersampled(scenes, gpu_ctx):
+    """THE benchmarked instantiation (bench.py's default: BASELINE.json's metric configuration):
+    scene_import_dragon.json at 1920x1080, the scene file's own settings -- 32 bands, supersampling on
+    (16 jittered samples per pixel, hash jitter seed 0), three lights with shadow rays.  Six of the 32
+    row bands, spread over the image, against the oracle; plus whole-frame properties."""
+    scene, ctx = scenes("dragon"), gpu_ctx("dragon")
+    frame = scene.frame(1920, 1080, rng_mode=ca.RNG_HASH, rng_seed=0)          # T = 32, ss = on from the scene file
+    assert frame.flags & ca.F_SUPERSAMPLE and frame.num_threads == 32
+    a, sa = ctx.render(frame)
+    b, sb = ctx.render(frame)
+    assert (a == b).all() and sa.rays == sb.rays                               # idempotent
+    assert sa.rays_primary == (1080 * 1056 - 1080) * 16
+    assert (a[1:25] == 0).all() and (a[0] == 0).all() and (a[:, :420] == 0).all() and (a[:, 1500:] == 0).all()
+    bands = [3, 9, 14, 17, 22, 28]
+    cpu_fb, rows = _oracle_bands_parallel(scene, frame, bands)
+    assert rows.sum() == len(bands) * 33
+    n_diff = _compare(a[rows], cpu_fb[rows], "dragon stand-in 1920x1080 ss=on, bands %s" % bands)
+    assert n_diff == 0            # observed: bit-identical (the 1-LSB allowance is for pow(), which has not bitten yet)
+    assert ((a[rows] != 0x333333) & (a[rows] != 0)).sum() > 50_000             # the bands show the mesh
+
+
+def test_dragon_4k_supersampled_c5(scenes, gpu_ctx):
+    """BASELINE.json configs[4] (C5): dragon at 3840x2160, 16 samples per pixel and shadow rays --
+    74 M primary rays.  Four of the 32 bands against the oracle, whole-frame ray accounting."""
+    scene, ctx = scenes("dragon"), gpu_ctx("dragon")
+    frame = scene.frame(3840, 2160, rng_mode=ca.RNG_HASH, rng_seed=0)
+    assert frame.flags & ca.F_SUPERSAMPLE and frame.num_threads == 32
+    a, sa = ctx.render(frame)
+    assert sa.rays_primary == (2160 * 2144 - 2160) * 16                        # 2160 columns x 2144 rows, minus the dropped row
+    assert (a[:, :840] == 0).all() and (a[:, 3000:] == 0).all() and (a[0] == 0).all()
+    bands = [6, 13, 18, 25]
+    cpu_fb, rows = _oracle_bands_parallel(scene, frame, bands)
+    assert rows.sum() == len(bands) * 67
+    n_diff = _compare(a[rows], cpu_fb[rows], "dragon stand-in 3840x2160 ss=on (C5), bands %s" % bands)
+    assert n_diff == 0
+    assert ((a[rows] != 0x333333) & (a[rows] != 0)).sum() > 100_000
 
 
 def test_both_gpu_paths_agree(scenes, monkeypatch):
@@ -224,7 +289,9 @@ def test_both_gpu_paths_agree(scenes, monkeypatch):
             a, sa = mega.render(frame)
             b, sb = fast.render(frame)
             assert (a == b).all()
-            assert (sa.rays_primary, sa.rays_shadow) == (sb.rays_primary, sb.rays_shadow)
+            # (the megakernel traces every shadow ray the reference does; the pipeline leaves out those
+            # whose answer cannot matter and says how many)
+            assert (sa.rays_primary, sa.rays_shadow) == (sb.rays_primary, sb.rays_shadow + sb.rays_shadow_elided)
     finally:
         mega.close()
         fast.close()
@@ -232,7 +299,7 @@ def test_both_gpu_paths_agree(scenes, monkeypatch):
 
 @pytest.mark.parametrize("env", [{"CTGPU_LDS_DEPTH": "1"}, {"CTGPU_LDS_DEPTH": "3", "CTGPU_CHUNK": "64"},
                                  {"CTGPU_CHUNK": "4096"}, {"CTGPU_WALK_THRESH": "8,16,8"},
-                                 {"CTGPU_BLOCKS_PER_CU": "1"}],
+                                 {"CTGPU_BLOCKS_PER_CU": "1"}, {"CTGPU_KEEP_SHADOW_RAYS": "1"}],
                          ids=lambda e: ",".join("%s=%s" % kv for kv in e.items()))
 def test_pipeline_knobs_do_not_change_pixels(env, scenes, gpu_ctx, monkeypatch):
     """Stack spill to HBM (tiny LDS depth), chunk sizes, phase thresholds and the
@@ -252,6 +319,39 @@ def test_pipeline_knobs_do_not_change_pixels(env, scenes, gpu_ctx, monkeypatch):
             assert (got == w).all()
     finally:
         ctx.close()
+
+
+def test_elided_shadow_rays_are_accounted_for(scenes, gpu_ctx, monkeypatch):
+    """ct_light_gate leaves out the shadow rays whose answer ComputeLighting never uses (n.l <= 0 and
+    no specular reach, raythread.cpp:309-325).  With CTGPU_KEEP_SHADOW_RAYS=1 every one is traced:
+    same pixels, and traced + elided is the same number either way -- the reference's ray count."""
+    monkeypatch.setenv("CTGPU_KEEP_SHADOW_RAYS", "1")
+    ctxs = {}
+    try:
+        for name in ("bunny", "import"):
+            ctxs[name] = ca.GpuContext(0)
+            ctxs[name].upload(scenes(name).desc)
+        monkeypatch.delenv("CTGPU_KEEP_SHADOW_RAYS")
+        for name, w, h in (("bunny", 640, 360), ("import", 480, 270)):
+            scene = scenes(name)
+            for ss in (False, True):
+                frame = scene.frame(w, h, threads=8, supersampling=ss, rng_seed=6)
+                lean, sl = gpu_ctx(name).render(frame)
+                full, sf = ctxs[name].render(frame)
+                assert (lean == full).all()
+                assert sf.rays_shadow_elided == 0 and sl.rays_shadow_elided > 0
+                assert sl.rays_shadow + sl.rays_shadow_elided == sf.rays_shadow
+                if not ss:
+                    # ... which is what the oracle traces, less the row the bitmap drops (not traced here)
+                    _, cst = _oracle().render(scene.desc, frame, os_threads=4)
+                    import copy
+                    f1 = copy.copy(frame)
+                    f1.num_threads = frame.height
+                    _, dropped = _oracle().render(scene.desc, f1, os_threads=1, band_first=0, band_count=1)
+                    assert sf.rays_shadow == cst.rays_shadow - dropped.rays_shadow
+    finally:
+        for c in ctxs.values():
+            c.close()
 
 
 def _write_scene(tmp_path, name, triangles, lights, settings=None, camera=(0, 0, -3)):
