@@ -63,6 +63,15 @@ class Stats(C.Structure):
         return self.rays_primary + self.rays_shadow + self.rays_reflect
 
 
+class WalkWork(C.Structure):
+    _fields_ = [("packets", C.c_uint64 * 2), ("quad_nodes", C.c_uint64 * 2), ("triangle_records", C.c_uint64 * 2)]
+
+
+class KernelTimes(C.Structure):
+    NAMES = ("ct_sample_grid", "ct_walk_packet<primary>", "ct_light_gate", "ct_walk_packet<shadow>", "ct_shade")
+    _fields_ = [("launches", C.c_uint64 * 5), ("total_ms", C.c_double * 5)]
+
+
 class Partition(C.Structure):
     _fields_ = [("tile_rows", C.c_int32), ("part_index", C.c_int32), ("part_count", C.c_int32)]
 
@@ -98,9 +107,18 @@ _GPU_SYMBOLS = {
     "ctgpu_partition_pixels": (C.c_int, [C.POINTER(FrameDesc), C.POINTER(Partition), C.POINTER(C.c_uint64)]),
     "ctgpu_render_partition": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.POINTER(Partition), C.c_void_p, C.c_void_p]),
     "ctgpu_assemble": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.POINTER(Partition), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "ctgpu_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "ctgpu_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "ctgpu_comm_rank": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "ctgpu_comm_destroy": (C.c_int, [C.c_void_p]),
+    "ctgpu_gather_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p]),
+    "ctgpu_render_sharded": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.c_int, C.c_void_p, C.c_void_p]),
     "ctgpu_read_counters": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "ctgpu_trace_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "ctgpu_trace_rays_packet": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
+    "ctgpu_read_walk_work": (C.c_int, [C.c_void_p, C.POINTER(WalkWork)]),
+    "ctgpu_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "ctgpu_read_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(KernelTimes)]),
     "ctgpu_count_work": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.POINTER(Stats)]),
     "ctgpu_rand_stream": (C.c_int, [C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p]),
 }
@@ -121,6 +139,7 @@ _HOST_SYMBOLS = {
     "cth_node_hash": (C.c_uint64, [C.c_void_p]),
     "cth_index_hash": (C.c_uint64, [C.c_void_p]),
     "cth_fnv1a64": (C.c_uint64, [C.c_void_p, C.c_uint64]),
+    "cth_assemble_tiles": (C.c_int, [C.POINTER(FrameDesc), C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "cth_raythread_options": (None, [C.c_int, C.c_uint64, C.c_int, C.c_int]),
     "cth_raythread_reset": (None, []),
     "cth_raythread_frames": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_char_p]),
@@ -299,6 +318,19 @@ class GpuContext:
         self._check(self.lib.ctgpu_trace_rays(self.handle, rays.ctypes.data, rays.shape[0], hits.ctypes.data))
         return hits
 
+    def read_walk_work(self):
+        w = WalkWork()
+        self._check(self.lib.ctgpu_read_walk_work(self.handle, C.byref(w)))
+        return w
+
+    def kernel_timing(self, enable=True):
+        self._check(self.lib.ctgpu_kernel_timing(self.handle, 1 if enable else 0))
+
+    def read_kernel_times(self):
+        t = KernelTimes()
+        self._check(self.lib.ctgpu_read_kernel_times(self.handle, C.byref(t)))
+        return t
+
     def trace_rays_packet(self, rays, any_hit=False):
         """The per-ray hook through ct_walk_packet, the kernel the frames are traced with."""
         rays = np.ascontiguousarray(rays, dtype=RAY_DTYPE)
@@ -319,6 +351,28 @@ class GpuContext:
     def assemble(self, frame, part, d_all_tiles_ptr, d_fb_ptr, stream_ptr=None):
         self._check(self.lib.ctgpu_assemble(self.handle, C.byref(frame), C.byref(part), C.c_void_p(d_all_tiles_ptr),
                                             C.c_void_p(d_fb_ptr), C.c_void_p(stream_ptr or 0)))
+
+    # ---- one process per GPU: the native RCCL gather (ctgpu_comm.hip)
+    @staticmethod
+    def comm_unique_id():
+        lib = gpu_library()
+        buf = (C.c_uint8 * 128)()
+        rc = lib.ctgpu_comm_unique_id(buf)
+        if rc != 0:
+            raise RuntimeError("ctgpu error %d: %s" % (rc, lib.ctgpu_last_error().decode()))
+        return bytes(buf)
+
+    def comm_init(self, unique_id, rank, world):
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        self._check(self.lib.ctgpu_comm_init(self.handle, buf, rank, world))
+
+    def gather_tiles(self, d_tiles_ptr, n, d_all_ptr, root=0, stream_ptr=None):
+        self._check(self.lib.ctgpu_gather_tiles(self.handle, C.c_void_p(d_tiles_ptr), n, C.c_void_p(d_all_ptr or 0), root,
+                                                C.c_void_p(stream_ptr or 0)))
+
+    def render_sharded(self, frame, tile_rows, d_fb_ptr, stream_ptr=None):
+        self._check(self.lib.ctgpu_render_sharded(self.handle, C.byref(frame), tile_rows, C.c_void_p(d_fb_ptr or 0),
+                                                  C.c_void_p(stream_ptr or 0)))
 
     def read_counters(self):
         st = Stats()

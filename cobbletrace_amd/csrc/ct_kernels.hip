@@ -23,6 +23,7 @@
 // triangles in index order, strict '<' for the closest hit).
 #include "ct_device.h"
 #include "ct_params.h"
+#include "ct_tiles.h"
 #include "ct_raygen.h"
 
 using namespace ctd;
@@ -503,34 +504,13 @@ __global__ __launch_bounds__(256) void ct_assemble(const FrameParams P, const ui
     const uint32_t xi = blockIdx.x * 256u + threadIdx.x;
     const uint32_t yi = blockIdx.y;
     if (xi >= P.square || yi >= P.rendered_rows) return;
-
-    auto fetch = [&](uint32_t row) -> uint32_t {
-        const uint32_t tile = row / P.tile_rows;
-        const uint32_t owner = tile % P.part_count;
-        const uint32_t local_row = (tile / P.part_count) * P.tile_rows + row % P.tile_rows;
-        return all_tiles[((size_t)owner * P.local_rows + local_row) * P.square + xi];
-    };
-
-    uint32_t color;
-    if (!P.subsample) {
-        color = fetch(yi);
-    } else {
-        // Rows a band traces: even offsets and its last row (raythread.cpp:526-535).  Every
-        // traced row except the band's first also writes the row below it with the average
-        // of itself and the previously traced row (raythread.cpp:512-524); within a band
-        // that happens in row order, so the later write wins:
-        //   odd offset, not the last row -> never traced: average of its two neighbours
-        //   offset q-2 when q is even     -> traced, then overwritten by row q-1's average
-        // The in-between write of a band's FIRST row (into the neighbouring band) is the
-        // reference's one racy store; as in the oracle it is dropped.
-        const uint32_t q = P.rows_per_band, off = yi % q;
-        if ((off & 1u) && off != q - 1u) color = average_pair(fetch(yi - 1u), fetch(yi + 1u));
-        else if (!(q & 1u) && q >= 2u && off == q - 2u) color = average_pair(fetch(yi), fetch(yi + 1u));
-        else color = fetch(yi);
-    }
-    const int row = P.height / 2 - ((int)yi - P.half), col = (int)xi - P.half + P.width / 2;
-    if (row < 0 || row >= P.height || col < 0 || col >= P.width) return;
-    fb[(size_t)row * P.width + col] = color;
+    // the layout arithmetic is include/ct_tiles.h, shared with the host layer's cth_assemble_tiles
+    ct_tile_layout L;
+    L.width = P.width; L.height = P.height; L.half = P.half; L.square = P.square;
+    L.rendered_rows = P.rendered_rows; L.rows_per_band = P.rows_per_band; L.subsample = P.subsample;
+    L.tile_rows = P.tile_rows; L.part_count = P.part_count; L.local_rows = P.local_rows;
+    uint64_t slot;
+    if (ct_tiles_bitmap_slot(&L, xi, yi, &slot)) fb[slot] = ct_tiles_pixel(&L, all_tiles, xi, yi);
 }
 
 // ------------------------------------------------------------------------------------

@@ -80,6 +80,8 @@ struct PipelineParams {
     uint32_t packet_depth;       // most entries the folded tree can have pending at once
     int32_t  thresh_r, thresh_a, thresh_b;
     uint32_t keep_every_shadow_ray;   // 1: ct_light_gate passes every hit sample's shadow rays (CTGPU_KEEP_SHADOW_RAYS)
+    unsigned long long *walk_work;    // [64 slots][8]: {packets, QuadNodes fetched, triangle records fetched} of the primary
+                                      // walk in words 0..2, of the shadow walk in words 3..5 (packet walk only)
     const ctgpu_ray *ray_list;   // ctgpu_trace_rays_packet: the caller's rays (n_samples of them) ...
     ctgpu_hit *ray_hits;         // ... and where their results go
 };
@@ -87,7 +89,8 @@ struct PipelineParams {
 uint64_t pipeline_sample_count(const FrameParams &P, bool ss);
 int  pipeline_walk_occupancy(size_t lds_bytes);
 int  pipeline_packet_occupancy(uint32_t depth, uint32_t lds_levels);
-void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hipStream_t stream);
+constexpr int kPipelineKernels = 5;      // ct_sample_grid, primary walk, ct_light_gate, shadow walk, ct_shade
+void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hipStream_t stream, hipEvent_t *marks);
 void launch_packet_ray_list(const FrameParams &P, const PipelineParams &W, bool any_hit, hipStream_t stream);
 
 void launch_trace_tiles(const FrameParams &P, uint32_t n_tiles, bool ss, bool reflect, bool count, hipStream_t stream);

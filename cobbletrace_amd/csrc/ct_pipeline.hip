@@ -730,6 +730,9 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
     uint64_t chunk_next = 0, chunk_end = 0;
     bool wave_drained = false;
     uint32_t n_traced = 0;
+    // what this wave asked the memory system for: packets walked, QuadNodes (128 B each) and triangle
+    // records (80 B each) fetched -- the kernel's own bytes of the roofline (ctgpu_read_walk_work)
+    uint32_t n_packets = 0, n_quads = 0, n_records = 0;
 #ifdef CT_WALK_STATS
     unsigned long long pk_n[6] = {0, 0, 0, 0, 0, 0}, pk_cyc[3] = {0, 0, 0};
     const unsigned long long pk_begin = __builtin_amdgcn_s_memtime();
@@ -807,6 +810,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
             if (wave_drained) break;
             continue;
         }
+        n_packets += 1;
         // phase 2 (once per packet, all its lanes together): the rays themselves
         if (has_ray) {
             float t_start = kNoHit;
@@ -886,6 +890,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                     const ScalarTri tr = scalar_load_tri(P.tris + first + k);
                     if (k == 0) {
                         count = tr.remaining();
+                        n_records += count;
                         PK_COUNT(2, count);
                         PK_COUNT(3, (uint64_t)count * __popcll(mask));
                     }
@@ -904,6 +909,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
             } else {
                 PK_T0();
                 PK_COUNT(0, 1);
+                n_quads += 1;
                 PK_COUNT(1, __popcll(mask));
                 const uint32_t node_id = cur;
                 const ScalarQuad sq = scalar_load_quad(quads + node_id);
@@ -1072,7 +1078,14 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
         atomicAdd(&P.counters[14], __builtin_amdgcn_s_memtime() - pk_begin);
     }
 #endif
-    if (lane == 0 && !LIST) atomicAdd(&P.counters[KIND == 0 ? 0 : 1], (unsigned long long)n_traced);
+    if (lane == 0 && !LIST) {
+        atomicAdd(&P.counters[KIND == 0 ? 0 : 1], (unsigned long long)n_traced);
+        // (64 slots on separate cache lines: atomics on one word would queue up at ~11 ns each)
+        unsigned long long *work = W.walk_work + (size_t)(blockIdx.x & 63u) * 8u + (KIND == 0 ? 0u : 3u);
+        atomicAdd(work + 0, (unsigned long long)n_packets);
+        atomicAdd(work + 1, (unsigned long long)n_quads);
+        atomicAdd(work + 2, (unsigned long long)n_records);
+    }
 }
 #undef RAY_O
 
@@ -1267,47 +1280,46 @@ int pipeline_packet_occupancy(uint32_t depth, uint32_t lds_levels) {
     return a < b ? a : b;
 }
 
-void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hipStream_t stream) {
+void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hipStream_t stream, hipEvent_t *marks) {
     if (W.n_samples == 0) return;
+    // marks (optional, kPipelineKernels + 1 events): one before each kernel and one after the last, so that the
+    // time between marks k and k+1 is kernel k's (ctgpu_kernel_timing)
+    auto mark = [&](int k) { if (marks) (void)hipEventRecord(marks[k], stream); };
     const uint32_t pixel_slots = (uint32_t)(ss ? W.n_samples / 16u : W.n_samples);
     const uint32_t pixel_blocks = (pixel_slots + 255u) / 256u;
     const uint32_t sample_blocks = (uint32_t)std::min<uint64_t>((W.n_samples + 255u) / 256u, 2048u);      // ct_light_gate strides
+    const bool shadows = W.n_shadow_lights != 0;
+    mark(0);
     if (ss) hipLaunchKernelGGL(ct_sample_grid, dim3(pixel_blocks), dim3(256), 0, stream, P, W);
+    mark(1);
+    const dim3 grid(W.walk_blocks), wave(kWave);
     if (W.packet) {
         // shared walk: a wave holds 2x2 pixels x 16 samples (supersampled) or an 8x8 pixel tile
         const uint32_t depth_p = W.packet_depth;
         const size_t lds_p = PacketStack::bytes(depth_p, W.packet_lds_levels < depth_p ? W.packet_lds_levels : depth_p);
-        if (ss) {
-            hipLaunchKernelGGL((ct_walk_packet<0, true>), dim3(W.walk_blocks), dim3(kWave), lds_p, stream, P, W);
-            if (W.n_shadow_lights) {
-                hipLaunchKernelGGL((ct_light_gate<true>), dim3(sample_blocks), dim3(256), 0, stream, P, W);
-                hipLaunchKernelGGL((ct_walk_packet<1, true>), dim3(W.walk_blocks), dim3(kWave), lds_p, stream, P, W);
-            }
-        } else {
-            hipLaunchKernelGGL((ct_walk_packet<0, false>), dim3(W.walk_blocks), dim3(kWave), lds_p, stream, P, W);
-            if (W.n_shadow_lights) {
-                hipLaunchKernelGGL((ct_light_gate<false>), dim3(sample_blocks), dim3(256), 0, stream, P, W);
-                hipLaunchKernelGGL((ct_walk_packet<1, false>), dim3(W.walk_blocks), dim3(kWave), lds_p, stream, P, W);
-            }
-        }
+        if (ss) hipLaunchKernelGGL((ct_walk_packet<0, true>), grid, wave, lds_p, stream, P, W);
+        else hipLaunchKernelGGL((ct_walk_packet<0, false>), grid, wave, lds_p, stream, P, W);
+        mark(2);
+        if (shadows && ss) hipLaunchKernelGGL((ct_light_gate<true>), dim3(sample_blocks), dim3(256), 0, stream, P, W);
+        if (shadows && !ss) hipLaunchKernelGGL((ct_light_gate<false>), dim3(sample_blocks), dim3(256), 0, stream, P, W);
+        mark(3);
+        if (shadows && ss) hipLaunchKernelGGL((ct_walk_packet<1, true>), grid, wave, lds_p, stream, P, W);
+        if (shadows && !ss) hipLaunchKernelGGL((ct_walk_packet<1, false>), grid, wave, lds_p, stream, P, W);
     } else {
         const size_t lds = (size_t)W.lds_depth * kWave * 12u;      // entries + parent words
-        if (ss) {
-            hipLaunchKernelGGL((ct_walk<0, true>), dim3(W.walk_blocks), dim3(kWave), lds, stream, P, W);
-            if (W.n_shadow_lights) {
-                hipLaunchKernelGGL((ct_light_gate<true>), dim3(sample_blocks), dim3(256), 0, stream, P, W);
-                hipLaunchKernelGGL((ct_walk<1, true>), dim3(W.walk_blocks), dim3(kWave), lds, stream, P, W);
-            }
-        } else {
-            hipLaunchKernelGGL((ct_walk<0, false>), dim3(W.walk_blocks), dim3(kWave), lds, stream, P, W);
-            if (W.n_shadow_lights) {
-                hipLaunchKernelGGL((ct_light_gate<false>), dim3(sample_blocks), dim3(256), 0, stream, P, W);
-                hipLaunchKernelGGL((ct_walk<1, false>), dim3(W.walk_blocks), dim3(kWave), lds, stream, P, W);
-            }
-        }
+        if (ss) hipLaunchKernelGGL((ct_walk<0, true>), grid, wave, lds, stream, P, W);
+        else hipLaunchKernelGGL((ct_walk<0, false>), grid, wave, lds, stream, P, W);
+        mark(2);
+        if (shadows && ss) hipLaunchKernelGGL((ct_light_gate<true>), dim3(sample_blocks), dim3(256), 0, stream, P, W);
+        if (shadows && !ss) hipLaunchKernelGGL((ct_light_gate<false>), dim3(sample_blocks), dim3(256), 0, stream, P, W);
+        mark(3);
+        if (shadows && ss) hipLaunchKernelGGL((ct_walk<1, true>), grid, wave, lds, stream, P, W);
+        if (shadows && !ss) hipLaunchKernelGGL((ct_walk<1, false>), grid, wave, lds, stream, P, W);
     }
+    mark(4);
     if (ss) hipLaunchKernelGGL((ct_shade<true>), dim3(pixel_blocks), dim3(256), 0, stream, P, W);
     else hipLaunchKernelGGL((ct_shade<false>), dim3(pixel_blocks), dim3(256), 0, stream, P, W);
+    mark(5);
 }
 
 // the per-ray hook of the shared walk: W.ray_list[0 .. n_samples) -> W.ray_hits, 64 consecutive rays a packet

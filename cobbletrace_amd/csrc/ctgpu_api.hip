@@ -4,7 +4,8 @@
 // leaf-ordered triangle records, see ct_device.h), the per-frame scratch buffers, and the
 // launches of ct_kernels.hip.  No compute happens on the host: without a HIP device every
 // entry point that needs one returns an error.
-#include "ct_params.h"
+#include "ctgpu_internal.h"
+#include "ct_tiles.h"
 
 #include <algorithm>
 #include <chrono>
@@ -26,7 +27,7 @@ static_assert(sizeof(ctgpu_ray) == 56 && sizeof(ctgpu_hit) == 16 && sizeof(ctgpu
 // ------------------------------------------------------------------ error plumbing
 static thread_local std::string g_last_error;
 
-static int fail(int code, const char *fmt, ...) {
+int ctgpu_fail(int code, const char *fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
@@ -39,7 +40,7 @@ static int fail(int code, const char *fmt, ...) {
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
         hipError_t e_ = (expr);                                                                    \
-        if (e_ != hipSuccess) return fail(CTGPU_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));  \
+        if (e_ != hipSuccess) return ctgpu_fail(CTGPU_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));  \
     } while (0)
 
 // ------------------------------------------------------------------ context
@@ -91,7 +92,11 @@ struct ctgpu_ctx {
     DeviceArray<unsigned long long> queue;      // 1 + 32 ray counters, then the hit count
     DeviceArray<unsigned long long> spill;      // stack entries beyond the LDS part
     DeviceArray<uint32_t> shadow_lights;
+    DeviceArray<unsigned long long> walk_work;  // [64][8] fetch counters of the packet walks (ct_params.h)
     uint32_t n_shadow_lights = 0;
+    bool kernel_timing = false;                 // ctgpu_kernel_timing: events around every pipeline kernel
+    std::vector<hipEvent_t> marks;              // (kPipelineKernels + 1) per timed frame
+    size_t marks_used = 0;
     int cu_count = 256;
     int walk_thresh[3] = {64, 32, 24};          // retire/fetch, inner, leaf (measured best on MI355X)
     int lds_depth = 8;                          // 6 KB of LDS per wave; deeper entries spill to HBM
@@ -102,6 +107,10 @@ struct ctgpu_ctx {
     bool keep_shadow_rays = false;              // CTGPU_KEEP_SHADOW_RAYS=1: trace the shadow rays whose answer cannot matter, too
     bool packet_walk = true;                    // ct_walk_packet for supersampled frames (CTGPU_PACKET=0: per-lane walk)
     bool force_megakernel = false;
+
+    ctgpu_comm_state *comm = nullptr;           // ctgpu_comm_init: this rank's RCCL communicator
+    std::vector<void *> multi_comms;            // ctgpu_render_multi: one communicator per device, kept by the root context
+    std::vector<int> multi_devices;
 
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -114,7 +123,7 @@ struct ctgpu_ctx {
 // (glibc 2.35): state r[0..33] seeded by the Lehmer sequence 16807*x mod (2^31-1),
 // 310 outputs discarded, then o_k = (r[k-31] + r[k-3]) >> 1 on 32-bit words.
 extern "C" int ctgpu_rand_stream(uint32_t seed, uint64_t offset, uint64_t n, int32_t *out) {
-    if (!out && n) return fail(CTGPU_ERR_ARG, "ctgpu_rand_stream: null output");
+    if (!out && n) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_rand_stream: null output");
     if (seed == 0) seed = 1;
     uint32_t r[34];
     r[0] = seed;
@@ -147,23 +156,33 @@ extern "C" int ctgpu_abi_version(void) { return CTGPU_ABI_VERSION; }
 extern "C" const char *ctgpu_last_error(void) { return g_last_error.c_str(); }
 
 extern "C" int ctgpu_device_count(int *count) {
-    if (!count) return fail(CTGPU_ERR_ARG, "ctgpu_device_count: null argument");
+    if (!count) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_device_count: null argument");
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess) { *count = 0; return fail(CTGPU_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { *count = 0; return ctgpu_fail(CTGPU_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
     *count = n;
     return CTGPU_OK;
 }
 
+static int create_resources(ctgpu_ctx *ctx);
+
 extern "C" int ctgpu_create(int device, ctgpu_ctx **out) {
-    if (!out) return fail(CTGPU_ERR_ARG, "ctgpu_create: null argument");
+    if (!out) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_create: null argument");
     *out = nullptr;
     int n = 0;
-    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(CTGPU_ERR_NO_DEVICE, "no HIP device is visible");
-    if (device < 0 || device >= n) return fail(CTGPU_ERR_ARG, "device %d out of range (0..%d)", device, n - 1);
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return ctgpu_fail(CTGPU_ERR_NO_DEVICE, "no HIP device is visible");
+    if (device < 0 || device >= n) return ctgpu_fail(CTGPU_ERR_ARG, "device %d out of range (0..%d)", device, n - 1);
     HIP_TRY(hipSetDevice(device));
     ctgpu_ctx *ctx = new ctgpu_ctx();
     ctx->device = device;
+    const int rc = create_resources(ctx);
+    if (rc != CTGPU_OK) { ctgpu_destroy(ctx); return rc; }      // (the message of the failing call stands)
+    *out = ctx;
+    return CTGPU_OK;
+}
+
+static int create_resources(ctgpu_ctx *ctx) {
+    const int device = ctx->device;
     HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&ctx->ev0));
     HIP_TRY(hipEventCreate(&ctx->ev1));
@@ -191,7 +210,19 @@ extern "C" int ctgpu_create(int device, ctgpu_ctx **out) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->cu_count = prop.multiProcessorCount;
     HIP_TRY(ctx->queue.resize(33 * 8 * 16));
-    *out = ctx;
+    HIP_TRY(ctx->walk_work.resize(64 * 8));
+    HIP_TRY(hipMemset(ctx->walk_work.ptr, 0, 64 * 8 * sizeof(unsigned long long)));
+    return CTGPU_OK;
+}
+
+ctgpu_comm_state *&ctgpu_comm_slot(ctgpu_ctx *ctx) { return ctx->comm; }
+int ctgpu_device_of(const ctgpu_ctx *ctx) { return ctx->device; }
+int ctgpu_shard_buffers(ctgpu_ctx *ctx, uint64_t n_tiles, uint64_t n_all, void **tiles, void **all) {
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(ctx->tiles.resize(n_tiles));
+    if (n_all) HIP_TRY(ctx->gathered.resize(n_all));
+    *tiles = ctx->tiles.ptr;
+    *all = n_all ? ctx->gathered.ptr : nullptr;
     return CTGPU_OK;
 }
 
@@ -199,11 +230,14 @@ extern "C" void ctgpu_destroy(ctgpu_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)ctgpu_comm_destroy(ctx);
+    ctgpu_multi_comms_release(ctx->multi_comms);
     ctx->nodes.release(); ctx->quads.release(); ctx->quad_source.release(); ctx->quads_flat.release(); ctx->quad_source_flat.release(); ctx->tris.release(); ctx->materials.release(); ctx->lights.release();
     ctx->tiles.release(); ctx->fb.release(); ctx->gathered.release(); ctx->counters.release(); ctx->overflow.release();
     ctx->rand_table.release(); ctx->row_ordinal.release();
     ctx->coords.release(); ctx->hits.release(); ctx->shadow.release(); ctx->queue.release(); ctx->spill.release();
-    ctx->shadow_lights.release();
+    ctx->shadow_lights.release(); ctx->walk_work.release();
+    for (hipEvent_t e : ctx->marks) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -212,11 +246,11 @@ extern "C" void ctgpu_destroy(ctgpu_ctx *ctx) {
 
 // ------------------------------------------------------------------ scene upload
 extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
-    if (!ctx || !s) return fail(CTGPU_ERR_ARG, "ctgpu_upload_scene: null argument");
+    if (!ctx || !s) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_upload_scene: null argument");
     if (s->n_triangles == 0 || s->n_nodes == 0 || !s->vertices || !s->materials || !s->nodes || !s->indexes)
-        return fail(CTGPU_ERR_ARG, "ctgpu_upload_scene: empty scene or null array");
-    if (s->n_lights && !s->lights) return fail(CTGPU_ERR_ARG, "ctgpu_upload_scene: null light array");
-    if (s->n_nodes > 2u * s->n_triangles) return fail(CTGPU_ERR_ARG, "ctgpu_upload_scene: more nodes than 2N-1");
+        return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_upload_scene: empty scene or null array");
+    if (s->n_lights && !s->lights) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_upload_scene: null light array");
+    if (s->n_nodes > 2u * s->n_triangles) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_upload_scene: more nodes than 2N-1");
     HIP_TRY(hipSetDevice(ctx->device));
 
     const uint32_t N = s->n_triangles, M = s->n_nodes;
@@ -224,13 +258,13 @@ extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
     for (uint32_t i = 0; i < M; i++) {
         const ctgpu_node &n = s->nodes[i];
         if (n.count == 0) {
-            if (n.left == 0 || (uint64_t)n.left + 1 >= M) return fail(CTGPU_ERR_ARG, "node %u: child link out of range", i);
+            if (n.left == 0 || (uint64_t)n.left + 1 >= M) return ctgpu_fail(CTGPU_ERR_ARG, "node %u: child link out of range", i);
         } else if ((uint64_t)n.first + n.count > N) {
-            return fail(CTGPU_ERR_ARG, "node %u: leaf range out of range", i);
+            return ctgpu_fail(CTGPU_ERR_ARG, "node %u: leaf range out of range", i);
         }
     }
     for (uint32_t i = 0; i < N; i++)
-        if (s->indexes[i] >= N) return fail(CTGPU_ERR_ARG, "indexes[%u] out of range", i);
+        if (s->indexes[i] >= N) return ctgpu_fail(CTGPU_ERR_ARG, "indexes[%u] out of range", i);
 
     // inner nodes get consecutive WideNode slots in reference order
     std::vector<uint32_t> wide_of(M, kNoNode);
@@ -336,7 +370,7 @@ extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
         return true;
     };
     Folded folded, flat;
-    if (!build_quads(true, folded) || !build_quads(false, flat)) return fail(CTGPU_ERR_ARG, "node links form a cycle");
+    if (!build_quads(true, folded) || !build_quads(false, flat)) return ctgpu_fail(CTGPU_ERR_ARG, "node links form a cycle");
 
     // leaf-ordered triangle records; a tree walk gives depth and the leaf extents
     std::vector<TriRecord> recs(N);
@@ -349,7 +383,7 @@ extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
         while (!todo.empty()) {
             const auto [id, d] = todo.back();
             todo.pop_back();
-            if (++visited > M) return fail(CTGPU_ERR_ARG, "node links form a cycle");
+            if (++visited > M) return ctgpu_fail(CTGPU_ERR_ARG, "node links form a cycle");
             depth = std::max(depth, d);
             const ctgpu_node &n = s->nodes[id];
             if (n.count) {
@@ -360,7 +394,7 @@ extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
             }
         }
     }
-    if (depth > CTGPU_MAX_TREE_DEPTH) return fail(CTGPU_ERR_STACK, "tree depth %u exceeds %d", depth, CTGPU_MAX_TREE_DEPTH);
+    if (depth > CTGPU_MAX_TREE_DEPTH) return ctgpu_fail(CTGPU_ERR_STACK, "tree depth %u exceeds %d", depth, CTGPU_MAX_TREE_DEPTH);
 
     uint32_t slot0 = 0;
     for (uint32_t slot = 0; slot < N; slot++) {
@@ -433,13 +467,13 @@ struct Geometry {
 };
 
 int check_frame(const ctgpu_frame_desc *f) {
-    if (!f) return fail(CTGPU_ERR_ARG, "null frame descriptor");
+    if (!f) return ctgpu_fail(CTGPU_ERR_ARG, "null frame descriptor");
     if (f->width <= 0 || f->height <= 1 || f->width > 65536 || f->height > 65536)
-        return fail(CTGPU_ERR_ARG, "bitmap size %dx%d not supported", f->width, f->height);
+        return ctgpu_fail(CTGPU_ERR_ARG, "bitmap size %dx%d not supported", f->width, f->height);
     if (f->num_threads <= 0 || f->num_threads > f->height)
-        return fail(CTGPU_ERR_ARG, "num_threads %d must be in 1..height", f->num_threads);
-    if (f->rng_mode != CTGPU_RNG_HASH && f->rng_mode != CTGPU_RNG_LIBC) return fail(CTGPU_ERR_ARG, "unknown rng_mode");
-    if (f->max_depth < 0 || f->max_depth > 10) return fail(CTGPU_ERR_ARG, "max_depth must be 0..10");
+        return ctgpu_fail(CTGPU_ERR_ARG, "num_threads %d must be in 1..height", f->num_threads);
+    if (f->rng_mode != CTGPU_RNG_HASH && f->rng_mode != CTGPU_RNG_LIBC) return ctgpu_fail(CTGPU_ERR_ARG, "unknown rng_mode");
+    if (f->max_depth < 0 || f->max_depth > 10) return ctgpu_fail(CTGPU_ERR_ARG, "max_depth must be 0..10");
     return CTGPU_OK;
 }
 
@@ -453,16 +487,14 @@ Geometry geometry(const ctgpu_frame_desc *f) {
 }
 
 int check_partition(const ctgpu_partition *p) {
-    if (!p) return fail(CTGPU_ERR_ARG, "null partition");
+    if (!p) return ctgpu_fail(CTGPU_ERR_ARG, "null partition");
     if (p->tile_rows < 1 || p->part_count < 1 || p->part_index < 0 || p->part_index >= p->part_count)
-        return fail(CTGPU_ERR_ARG, "bad partition (tile_rows %d, part %d of %d)", p->tile_rows, p->part_index, p->part_count);
+        return ctgpu_fail(CTGPU_ERR_ARG, "bad partition (tile_rows %d, part %d of %d)", p->tile_rows, p->part_index, p->part_count);
     return CTGPU_OK;
 }
 
 uint32_t local_rows_of(const Geometry &g, const ctgpu_partition *p) {
-    const uint32_t tiles = (g.rendered_rows + (uint32_t)p->tile_rows - 1u) / (uint32_t)p->tile_rows;
-    const uint32_t per_part = (tiles + (uint32_t)p->part_count - 1u) / (uint32_t)p->part_count;
-    return per_part * (uint32_t)p->tile_rows;
+    return ct_tiles_local_rows(g.rendered_rows, (uint32_t)p->tile_rows, (uint32_t)p->part_count);      // include/ct_tiles.h
 }
 
 // rows a frame traces, in single-worker order (for the LIBC jitter stream)
@@ -537,7 +569,7 @@ int check_overflow(ctgpu_ctx *ctx) {
     HIP_TRY(hipMemcpy(&flag, ctx->overflow.ptr, sizeof flag, hipMemcpyDeviceToHost));
     if (flag) {
         HIP_TRY(hipMemset(ctx->overflow.ptr, 0, sizeof flag));
-        return fail(CTGPU_ERR_STACK, "traversal stack overflow (tree depth %u)", ctx->tree_depth);
+        return ctgpu_fail(CTGPU_ERR_STACK, "traversal stack overflow (tree depth %u)", ctx->tree_depth);
     }
     return CTGPU_OK;
 }
@@ -600,7 +632,18 @@ int launch_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, FrameParams &P, hipS
     HIP_TRY(ctx->shadow.resize(W.n_samples * std::max<uint32_t>(W.n_shadow_lights, 1)));
     W.coords = ctx->coords.ptr; W.hits = ctx->hits.ptr; W.shadow = ctx->shadow.ptr;
     HIP_TRY(hipMemsetAsync(ctx->queue.ptr, 0, 33 * 8 * 16 * sizeof(unsigned long long), stream));
-    launch_pipeline(P, W, ss, stream);
+    hipEvent_t *marks = nullptr;
+    if (ctx->kernel_timing) {
+        const size_t need = ctx->marks_used + kPipelineKernels + 1;
+        while (ctx->marks.size() < need) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            ctx->marks.push_back(e);
+        }
+        marks = ctx->marks.data() + ctx->marks_used;
+        ctx->marks_used = need;
+    }
+    launch_pipeline(P, W, ss, stream, marks);
     HIP_TRY(hipGetLastError());
     return CTGPU_OK;
 }
@@ -632,9 +675,10 @@ int fill_pipeline(ctgpu_ctx *ctx, uint64_t n_samples, PipelineParams &W) {
     uint64_t chunk_shadow = ctx->chunk_shadow > 0 ? (uint64_t)ctx->chunk_shadow : chunk;
     W.chunk_shadow = (uint32_t)std::min<uint64_t>(std::max<uint64_t>((chunk_shadow + 63) / 64 * 64, 64), 4096);
     W.thresh_r = ctx->walk_thresh[0]; W.thresh_a = ctx->walk_thresh[1]; W.thresh_b = ctx->walk_thresh[2];
-    if (W.n_samples >= 0xfffffff0ull) return fail(CTGPU_ERR_ARG, "frame too large: %llu samples", (unsigned long long)W.n_samples);
+    if (W.n_samples >= 0xfffffff0ull) return ctgpu_fail(CTGPU_ERR_ARG, "frame too large: %llu samples", (unsigned long long)W.n_samples);
     HIP_TRY(ctx->spill.resize((size_t)W.walk_blocks * (size_t)std::max(W.lds_depth + W.spill_depth, W.packet_depth) * 64 * 12 / 8 + 64));
     W.queue = ctx->queue.ptr; W.spill = ctx->spill.ptr; W.shadow_lights = ctx->shadow_lights.ptr;
+    W.walk_work = ctx->walk_work.ptr;
     return CTGPU_OK;
 }
 
@@ -642,7 +686,7 @@ int fill_pipeline(ctgpu_ctx *ctx, uint64_t n_samples, PipelineParams &W) {
 
 // ------------------------------------------------------------------ multi-GPU building blocks
 extern "C" int ctgpu_partition_pixels(const ctgpu_frame_desc *frame, const ctgpu_partition *part, uint64_t *count) {
-    if (!count) return fail(CTGPU_ERR_ARG, "ctgpu_partition_pixels: null argument");
+    if (!count) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_partition_pixels: null argument");
     int rc = check_frame(frame); if (rc) return rc;
     rc = check_partition(part); if (rc) return rc;
     const Geometry g = geometry(frame);
@@ -652,8 +696,8 @@ extern "C" int ctgpu_partition_pixels(const ctgpu_frame_desc *frame, const ctgpu
 
 extern "C" int ctgpu_render_partition(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, const ctgpu_partition *part,
                                       void *d_tiles, void *stream) {
-    if (!ctx || !d_tiles) return fail(CTGPU_ERR_ARG, "ctgpu_render_partition: null argument");
-    if (!ctx->has_scene) return fail(CTGPU_ERR_NO_SCENE, "no scene uploaded");
+    if (!ctx || !d_tiles) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_render_partition: null argument");
+    if (!ctx->has_scene) return ctgpu_fail(CTGPU_ERR_NO_SCENE, "no scene uploaded");
     int rc = check_frame(frame); if (rc) return rc;
     rc = check_partition(part); if (rc) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -665,7 +709,7 @@ extern "C" int ctgpu_render_partition(ctgpu_ctx *ctx, const ctgpu_frame_desc *fr
 
 extern "C" int ctgpu_assemble(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, const ctgpu_partition *part,
                               const void *d_all_tiles, void *d_fb, void *stream) {
-    if (!ctx || !d_all_tiles || !d_fb) return fail(CTGPU_ERR_ARG, "ctgpu_assemble: null argument");
+    if (!ctx || !d_all_tiles || !d_fb) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_assemble: null argument");
     int rc = check_frame(frame); if (rc) return rc;
     rc = check_partition(part); if (rc) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -679,7 +723,7 @@ extern "C" int ctgpu_assemble(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, con
 }
 
 extern "C" int ctgpu_read_counters(ctgpu_ctx *ctx, ctgpu_stats *stats) {
-    if (!ctx || !stats) return fail(CTGPU_ERR_ARG, "ctgpu_read_counters: null argument");
+    if (!ctx || !stats) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_read_counters: null argument");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipDeviceSynchronize());
     std::memset(stats, 0, sizeof *stats);
@@ -689,8 +733,8 @@ extern "C" int ctgpu_read_counters(ctgpu_ctx *ctx, ctgpu_stats *stats) {
 
 // ------------------------------------------------------------------ whole frame on one GPU
 extern "C" int ctgpu_render(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, uint32_t *host_fb, ctgpu_stats *stats) {
-    if (!ctx || !host_fb) return fail(CTGPU_ERR_ARG, "ctgpu_render: null argument");
-    if (!ctx->has_scene) return fail(CTGPU_ERR_NO_SCENE, "no scene uploaded");
+    if (!ctx || !host_fb) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_render: null argument");
+    if (!ctx->has_scene) return ctgpu_fail(CTGPU_ERR_NO_SCENE, "no scene uploaded");
     int rc = check_frame(frame); if (rc) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
     const auto t0 = std::chrono::steady_clock::now();
@@ -743,11 +787,11 @@ extern "C" int ctgpu_render(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, uint3
 // xGMI (the gather), and that device assembles and hands the frame to the host.
 extern "C" int ctgpu_render_multi(ctgpu_ctx *const *ctxs, int n_ctx, const ctgpu_frame_desc *frame, uint32_t *host_fb,
                                   ctgpu_stats *stats) {
-    if (!ctxs || n_ctx < 1 || !host_fb) return fail(CTGPU_ERR_ARG, "ctgpu_render_multi: bad argument");
+    if (!ctxs || n_ctx < 1 || !host_fb) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_render_multi: bad argument");
     if (n_ctx == 1) return ctgpu_render(ctxs[0], frame, host_fb, stats);
     for (int i = 0; i < n_ctx; i++) {
-        if (!ctxs[i]) return fail(CTGPU_ERR_ARG, "ctgpu_render_multi: null context %d", i);
-        if (!ctxs[i]->has_scene) return fail(CTGPU_ERR_NO_SCENE, "context %d has no scene", i);
+        if (!ctxs[i]) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_render_multi: null context %d", i);
+        if (!ctxs[i]->has_scene) return ctgpu_fail(CTGPU_ERR_NO_SCENE, "context %d has no scene", i);
     }
     int rc = check_frame(frame); if (rc) return rc;
     const auto t0 = std::chrono::steady_clock::now();
@@ -760,7 +804,25 @@ extern "C" int ctgpu_render_multi(ctgpu_ctx *const *ctxs, int n_ctx, const ctgpu
     HIP_TRY(root->gathered.resize(per_part * (size_t)n_ctx));
     HIP_TRY(root->fb.resize((size_t)frame->width * frame->height));
 
+    // The gather is RCCL's (one communicator per device, made once and kept by the root context) whenever
+    // every context sits on a device of its own; RCCL cannot address one device twice, so contexts that share
+    // a device (a test on a one-GPU box) hand their tiles over with plain device copies instead.
+    std::vector<int> devices;
+    bool distinct = true;
+    for (int i = 0; i < n_ctx; i++) {
+        for (int d : devices) distinct = distinct && d != ctxs[i]->device;
+        devices.push_back(ctxs[i]->device);
+    }
+    if (distinct && root->multi_devices != devices) {
+        ctgpu_multi_comms_release(root->multi_comms);
+        root->multi_devices.clear();
+        rc = ctgpu_multi_comms(devices.data(), n_ctx, root->multi_comms); if (rc) return rc;
+        root->multi_devices = devices;
+    }
+
     // trace: each device on its own stream; then its tiles go to the root's gather buffer
+    std::vector<void *> tile_ptrs;
+    std::vector<hipStream_t> streams;
     for (int i = 0; i < n_ctx; i++) {
         ctgpu_ctx *c = ctxs[i];
         HIP_TRY(hipSetDevice(c->device));
@@ -772,6 +834,9 @@ extern "C" int ctgpu_render_multi(ctgpu_ctx *const *ctxs, int n_ctx, const ctgpu
         if (i == 0) HIP_TRY(hipEventRecord(root->ev0, root->stream));
         rc = launch_frame(c, frame, P, c->stream); if (rc) return rc;
         if (i == 0) HIP_TRY(hipEventRecord(root->ev1, root->stream));
+        tile_ptrs.push_back(c->tiles.ptr);
+        streams.push_back(c->stream);
+        if (distinct) continue;
         HIP_TRY(hipMemcpyPeerAsync(root->gathered.ptr + per_part * (size_t)i, root->device, c->tiles.ptr, c->device,
                                    per_part * sizeof(uint32_t), c->stream));
         if (i != 0) {
@@ -779,6 +844,10 @@ extern "C" int ctgpu_render_multi(ctgpu_ctx *const *ctxs, int n_ctx, const ctgpu
             HIP_TRY(hipSetDevice(root->device));
             HIP_TRY(hipStreamWaitEvent(root->stream, c->ev1, 0));
         }
+    }
+    if (distinct) {     // ncclGather from every device's stream; the root's completes when all tiles have arrived
+        rc = ctgpu_multi_gather(root->multi_comms, devices.data(), tile_ptrs.data(), per_part, root->gathered.ptr, streams.data());
+        if (rc) return rc;
     }
 
     // assemble on the root device and copy back the rectangle the reference writes
@@ -822,8 +891,8 @@ extern "C" int ctgpu_render_multi(ctgpu_ctx *const *ctxs, int n_ctx, const ctgpu
 }
 
 extern "C" int ctgpu_count_work(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, ctgpu_stats *stats) {
-    if (!ctx || !stats) return fail(CTGPU_ERR_ARG, "ctgpu_count_work: null argument");
-    if (!ctx->has_scene) return fail(CTGPU_ERR_NO_SCENE, "no scene uploaded");
+    if (!ctx || !stats) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_count_work: null argument");
+    if (!ctx->has_scene) return ctgpu_fail(CTGPU_ERR_NO_SCENE, "no scene uploaded");
     int rc = check_frame(frame); if (rc) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
     const ctgpu_partition whole = {8, 0, 1};
@@ -849,8 +918,8 @@ extern "C" int ctgpu_count_work(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, c
 
 // ------------------------------------------------------------------ test hook
 extern "C" int ctgpu_trace_rays(ctgpu_ctx *ctx, const ctgpu_ray *rays, uint64_t n, ctgpu_hit *hits) {
-    if (!ctx || (n && (!rays || !hits))) return fail(CTGPU_ERR_ARG, "ctgpu_trace_rays: null argument");
-    if (!ctx->has_scene) return fail(CTGPU_ERR_NO_SCENE, "no scene uploaded");
+    if (!ctx || (n && (!rays || !hits))) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_trace_rays: null argument");
+    if (!ctx->has_scene) return ctgpu_fail(CTGPU_ERR_NO_SCENE, "no scene uploaded");
     if (n == 0) return CTGPU_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     ctgpu_frame_desc f;
@@ -864,7 +933,7 @@ extern "C" int ctgpu_trace_rays(ctgpu_ctx *ctx, const ctgpu_ray *rays, uint64_t 
     ctgpu_hit *d_hits = nullptr;
     HIP_TRY(hipMalloc((void **)&d_rays, n * sizeof(ctgpu_ray)));
     hipError_t e = hipMalloc((void **)&d_hits, n * sizeof(ctgpu_hit));
-    if (e != hipSuccess) { (void)hipFree(d_rays); return fail(CTGPU_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { (void)hipFree(d_rays); return ctgpu_fail(CTGPU_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
     e = hipMemcpy(d_rays, rays, n * sizeof(ctgpu_ray), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
         launch_trace_ray_list(P, d_rays, n, d_hits, ctx->stream);
@@ -874,7 +943,7 @@ extern "C" int ctgpu_trace_rays(ctgpu_ctx *ctx, const ctgpu_ray *rays, uint64_t 
     if (e == hipSuccess) e = hipMemcpy(hits, d_hits, n * sizeof(ctgpu_hit), hipMemcpyDeviceToHost);
     (void)hipFree(d_rays);
     (void)hipFree(d_hits);
-    if (e != hipSuccess) return fail(CTGPU_ERR_HIP, "ctgpu_trace_rays: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return ctgpu_fail(CTGPU_ERR_HIP, "ctgpu_trace_rays: %s", hipGetErrorString(e));
     return check_overflow(ctx);
 }
 
@@ -882,10 +951,10 @@ extern "C" int ctgpu_trace_rays(ctgpu_ctx *ctx, const ctgpu_ray *rays, uint64_t 
 // ones a packet, walked by ct_walk_packet (folded tree, binary32 filter, exact levels, unfolded
 // second pass) exactly as the samples of a frame are.
 extern "C" int ctgpu_trace_rays_packet(ctgpu_ctx *ctx, const ctgpu_ray *rays, uint64_t n, uint32_t flags, ctgpu_hit *hits) {
-    if (!ctx || (n && (!rays || !hits))) return fail(CTGPU_ERR_ARG, "ctgpu_trace_rays_packet: null argument");
-    if (flags & ~(uint32_t)CTGPU_TRACE_ANY_HIT) return fail(CTGPU_ERR_ARG, "ctgpu_trace_rays_packet: unknown flags %u", flags);
-    if (!ctx->has_scene) return fail(CTGPU_ERR_NO_SCENE, "no scene uploaded");
-    if (ctx->quad_pending > 64u) return fail(CTGPU_ERR_STACK, "the packet walk does not serve this tree (%u entries pending)", ctx->quad_pending);
+    if (!ctx || (n && (!rays || !hits))) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_trace_rays_packet: null argument");
+    if (flags & ~(uint32_t)CTGPU_TRACE_ANY_HIT) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_trace_rays_packet: unknown flags %u", flags);
+    if (!ctx->has_scene) return ctgpu_fail(CTGPU_ERR_NO_SCENE, "no scene uploaded");
+    if (ctx->quad_pending > 64u) return ctgpu_fail(CTGPU_ERR_STACK, "the packet walk does not serve this tree (%u entries pending)", ctx->quad_pending);
     if (n == 0) return CTGPU_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     ctgpu_frame_desc f;
@@ -902,7 +971,7 @@ extern "C" int ctgpu_trace_rays_packet(ctgpu_ctx *ctx, const ctgpu_ray *rays, ui
     ctgpu_hit *d_hits = nullptr;
     HIP_TRY(hipMalloc((void **)&d_rays, n * sizeof(ctgpu_ray)));
     hipError_t e = hipMalloc((void **)&d_hits, n * sizeof(ctgpu_hit));
-    if (e != hipSuccess) { (void)hipFree(d_rays); return fail(CTGPU_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { (void)hipFree(d_rays); return ctgpu_fail(CTGPU_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
     e = hipMemcpy(d_rays, rays, n * sizeof(ctgpu_ray), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemsetAsync(ctx->queue.ptr, 0, 33 * 8 * 16 * sizeof(unsigned long long), ctx->stream);
     if (e == hipSuccess) {
@@ -915,6 +984,50 @@ extern "C" int ctgpu_trace_rays_packet(ctgpu_ctx *ctx, const ctgpu_ray *rays, ui
     if (e == hipSuccess) e = hipMemcpy(hits, d_hits, n * sizeof(ctgpu_hit), hipMemcpyDeviceToHost);
     (void)hipFree(d_rays);
     (void)hipFree(d_hits);
-    if (e != hipSuccess) return fail(CTGPU_ERR_HIP, "ctgpu_trace_rays_packet: %s", hipGetErrorString(e));
+    if (e != hipSuccess) return ctgpu_fail(CTGPU_ERR_HIP, "ctgpu_trace_rays_packet: %s", hipGetErrorString(e));
     return check_overflow(ctx);
+}
+
+// ------------------------------------------------------------------ measurement hooks
+extern "C" int ctgpu_read_walk_work(ctgpu_ctx *ctx, ctgpu_walk_work *out) {
+    if (!ctx || !out) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_read_walk_work: null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipDeviceSynchronize());
+    unsigned long long w[64 * 8];
+    HIP_TRY(hipMemcpy(w, ctx->walk_work.ptr, sizeof w, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(ctx->walk_work.ptr, 0, sizeof w));
+    std::memset(out, 0, sizeof *out);
+    for (int slot = 0; slot < 64; slot++)
+        for (int k = 0; k < 2; k++) {
+            out->packets[k] += w[slot * 8 + k * 3 + 0];
+            out->quad_nodes[k] += w[slot * 8 + k * 3 + 1];
+            out->triangle_records[k] += w[slot * 8 + k * 3 + 2];
+        }
+    return CTGPU_OK;
+}
+
+extern "C" int ctgpu_kernel_timing(ctgpu_ctx *ctx, int enable) {
+    if (!ctx) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_kernel_timing: null argument");
+    ctx->kernel_timing = enable != 0;
+    ctx->marks_used = 0;
+    return CTGPU_OK;
+}
+
+extern "C" int ctgpu_read_kernel_times(ctgpu_ctx *ctx, ctgpu_kernel_times *out) {
+    if (!ctx || !out) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_read_kernel_times: null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::memset(out, 0, sizeof *out);
+    const size_t per_frame = kPipelineKernels + 1;
+    static_assert(kPipelineKernels == CTGPU_PIPELINE_KERNELS, "ctgpu_kernel_times layout");
+    for (size_t f = 0; f + per_frame <= ctx->marks_used; f += per_frame) {
+        HIP_TRY(hipEventSynchronize(ctx->marks[f + kPipelineKernels]));
+        for (int k = 0; k < kPipelineKernels; k++) {
+            float ms = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&ms, ctx->marks[f + k], ctx->marks[f + k + 1]));
+            out->total_ms[k] += ms;
+            out->launches[k] += 1;
+        }
+    }
+    ctx->marks_used = 0;
+    return CTGPU_OK;
 }

@@ -1,0 +1,198 @@
+// ctgpu_comm.hip -- the frame's one collective, native: an RCCL gather of the ranks' row-tile buffers to
+// the root over xGMI, issued from this library on the frame's own stream.
+//
+// The reference shards a frame over worker threads by row bands that all write one framebuffer
+// (raythread.cpp:574-618).  Across GPUs the shards are interleaved row tiles (ctgpu_render_partition),
+// each rank traces into a compact tile buffer in its own HBM, and ONE collective per frame brings the
+// buffers to the root, where ct_assemble writes the framebuffer.  xGMI is point to point: a gather is
+// seven peers each sending 1/8 of the image straight to the root, no ring.
+//
+// librccl is opened at run time (preferring a copy the process has already loaded, e.g. PyTorch's, so
+// that there is one RCCL and one HIP runtime per process); without it the comm entry points fail with
+// CTGPU_ERR_COMM -- nothing here has a host-memory fallback.
+#include "ctgpu_internal.h"
+
+#include <rccl/rccl.h>
+
+#include <dlfcn.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
+namespace {
+
+struct Rccl {
+    void *lib = nullptr;
+    decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+    decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+    decltype(&ncclCommInitAll) comm_init_all = nullptr;
+    decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclGather) gather = nullptr;
+    decltype(&ncclGroupStart) group_start = nullptr;
+    decltype(&ncclGroupEnd) group_end = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+    std::string why;            // set when loading failed
+};
+
+Rccl &rccl() {
+    static Rccl api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *override_path = std::getenv("CTGPU_RCCL_LIBRARY");
+        if (override_path) api.lib = dlopen(override_path, RTLD_NOW | RTLD_GLOBAL);
+        // a copy the process already holds (PyTorch maps its own librccl.so without a soname) ...
+        const char *names[] = {"librccl.so", "librccl.so.1"};
+        for (const char *n : names)
+            if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD);
+        // ... else ROCm's
+        for (const char *n : {"librccl.so.1", "librccl.so"})
+            if (!api.lib) api.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+        if (!api.lib) { api.why = std::string("librccl not found: ") + dlerror(); return; }
+        bool ok = true;
+#define RESOLVE(field, symbol)                                                              \
+        api.field = reinterpret_cast<decltype(api.field)>(dlsym(api.lib, symbol));          \
+        if (!api.field) { ok = false; api.why = std::string("librccl lacks ") + symbol; }
+        RESOLVE(get_unique_id, "ncclGetUniqueId");
+        RESOLVE(comm_init_rank, "ncclCommInitRank");
+        RESOLVE(comm_init_all, "ncclCommInitAll");
+        RESOLVE(comm_destroy, "ncclCommDestroy");
+        RESOLVE(gather, "ncclGather");
+        RESOLVE(group_start, "ncclGroupStart");
+        RESOLVE(group_end, "ncclGroupEnd");
+        RESOLVE(error_string, "ncclGetErrorString");
+#undef RESOLVE
+        if (!ok) api.lib = nullptr;
+    });
+    return api;
+}
+
+int rccl_ready() {
+    Rccl &r = rccl();
+    if (!r.lib) return ctgpu_fail(CTGPU_ERR_COMM, "%s", r.why.c_str());
+    return CTGPU_OK;
+}
+
+#define RCCL_TRY(expr)                                                                                         \
+    do {                                                                                                       \
+        ncclResult_t r_ = (expr);                                                                              \
+        if (r_ != ncclSuccess) return ctgpu_fail(CTGPU_ERR_COMM, "%s: %s", #expr, rccl().error_string(r_));    \
+    } while (0)
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return ctgpu_fail(CTGPU_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+}  // namespace
+
+struct ctgpu_comm_state {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1;
+};
+
+static_assert(CTGPU_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "ctgpu.h promises room for an ncclUniqueId");
+
+extern "C" int ctgpu_comm_unique_id(void *id) {
+    if (!id) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_comm_unique_id: null argument");
+    int rc = rccl_ready(); if (rc) return rc;
+    ncclUniqueId uid;
+    RCCL_TRY(rccl().get_unique_id(&uid));
+    std::memcpy(id, &uid, sizeof uid);
+    return CTGPU_OK;
+}
+
+extern "C" int ctgpu_comm_init(ctgpu_ctx *ctx, const void *id, int rank, int world) {
+    if (!ctx || !id) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_comm_init: null argument");
+    if (world < 1 || rank < 0 || rank >= world) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_comm_init: rank %d of %d", rank, world);
+    int rc = rccl_ready(); if (rc) return rc;
+    ctgpu_comm_state *&slot = ctgpu_comm_slot(ctx);
+    if (slot) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_comm_init: this context already has a communicator");
+    HIP_TRY(hipSetDevice(ctgpu_device_of(ctx)));
+    ncclUniqueId uid;
+    std::memcpy(&uid, id, sizeof uid);
+    ncclComm_t comm = nullptr;
+    RCCL_TRY(rccl().comm_init_rank(&comm, world, uid, rank));
+    slot = new ctgpu_comm_state();
+    slot->comm = comm; slot->rank = rank; slot->world = world;
+    return CTGPU_OK;
+}
+
+extern "C" int ctgpu_comm_destroy(ctgpu_ctx *ctx) {
+    if (!ctx) return CTGPU_OK;
+    ctgpu_comm_state *&slot = ctgpu_comm_slot(ctx);
+    if (!slot) return CTGPU_OK;
+    if (slot->comm && rccl().lib) (void)rccl().comm_destroy(slot->comm);
+    delete slot;
+    slot = nullptr;
+    return CTGPU_OK;
+}
+
+extern "C" int ctgpu_comm_rank(ctgpu_ctx *ctx, int *rank, int *world) {
+    if (!ctx) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_comm_rank: null argument");
+    ctgpu_comm_state *s = ctgpu_comm_slot(ctx);
+    if (!s) return ctgpu_fail(CTGPU_ERR_COMM, "this context has no communicator (ctgpu_comm_init)");
+    if (rank) *rank = s->rank;
+    if (world) *world = s->world;
+    return CTGPU_OK;
+}
+
+// every rank's n uint32 -> back to back in d_all on rank `root` (ncclGather, asynchronous on `stream`)
+extern "C" int ctgpu_gather_tiles(ctgpu_ctx *ctx, const void *d_tiles, uint64_t n, void *d_all, int root, void *stream) {
+    if (!ctx || !d_tiles) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_gather_tiles: null argument");
+    ctgpu_comm_state *s = ctgpu_comm_slot(ctx);
+    if (!s) return ctgpu_fail(CTGPU_ERR_COMM, "this context has no communicator (ctgpu_comm_init)");
+    if (root < 0 || root >= s->world) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_gather_tiles: root %d of %d", root, s->world);
+    if (s->rank == root && !d_all) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_gather_tiles: the root needs a receive buffer");
+    HIP_TRY(hipSetDevice(ctgpu_device_of(ctx)));
+    RCCL_TRY(rccl().gather(d_tiles, d_all, (size_t)n, ncclUint32, root, s->comm, (hipStream_t)stream));
+    return CTGPU_OK;
+}
+
+// One frame, this rank's part of it: trace my row tiles, gather to rank 0, assemble there -- all queued on
+// `stream`, nothing synchronises.  d_fb: the root's device framebuffer (width * height uint32); ignored elsewhere.
+extern "C" int ctgpu_render_sharded(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, int tile_rows, void *d_fb, void *stream) {
+    if (!ctx) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_render_sharded: null argument");
+    ctgpu_comm_state *s = ctgpu_comm_slot(ctx);
+    if (!s) return ctgpu_fail(CTGPU_ERR_COMM, "this context has no communicator (ctgpu_comm_init)");
+    if (s->rank == 0 && !d_fb) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_render_sharded: rank 0 needs a framebuffer");
+    const ctgpu_partition part = {tile_rows, s->rank, s->world};
+    uint64_t n = 0;
+    int rc = ctgpu_partition_pixels(frame, &part, &n); if (rc) return rc;
+    void *tiles = nullptr, *all = nullptr;
+    rc = ctgpu_shard_buffers(ctx, n, s->rank == 0 ? n * (uint64_t)s->world : 0, &tiles, &all); if (rc) return rc;
+    rc = ctgpu_render_partition(ctx, frame, &part, tiles, stream); if (rc) return rc;
+    rc = ctgpu_gather_tiles(ctx, tiles, n, all, 0, stream); if (rc) return rc;
+    if (s->rank == 0) return ctgpu_assemble(ctx, frame, &part, all, d_fb, stream);
+    return CTGPU_OK;
+}
+
+// ------------------------------------------------------------------ one process, several devices
+// ctgpu_render_multi's gather: one communicator per device (ncclCommInitAll), the gathers of all devices in
+// one group.  comms are cached by the caller (the root context) for as long as the device list is the same.
+int ctgpu_multi_comms(const int *devices, int n, std::vector<void *> &comms) {
+    int rc = rccl_ready(); if (rc) return rc;
+    std::vector<ncclComm_t> c((size_t)n, nullptr);
+    RCCL_TRY(rccl().comm_init_all(c.data(), n, devices));
+    comms.assign(c.begin(), c.end());
+    return CTGPU_OK;
+}
+
+void ctgpu_multi_comms_release(std::vector<void *> &comms) {
+    if (rccl().lib)
+        for (void *c : comms)
+            if (c) (void)rccl().comm_destroy((ncclComm_t)c);
+    comms.clear();
+}
+
+int ctgpu_multi_gather(const std::vector<void *> &comms, const int *devices, void *const *d_tiles, uint64_t n, void *d_all,
+                       hipStream_t const *streams) {
+    RCCL_TRY(rccl().group_start());
+    for (size_t i = 0; i < comms.size(); i++) {
+        HIP_TRY(hipSetDevice(devices[i]));
+        RCCL_TRY(rccl().gather(d_tiles[i], i == 0 ? d_all : nullptr, (size_t)n, ncclUint32, 0, (ncclComm_t)comms[i], streams[i]));
+    }
+    RCCL_TRY(rccl().group_end());
+    return CTGPU_OK;
+}

@@ -4,6 +4,7 @@
 #include "cobbletrace_host.h"
 #include "host_internal.h"
 #include "scene_pack.h"
+#include "ct_tiles.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -152,6 +153,30 @@ int cth_raythread_frames(void *p, int width, int height, uint32_t *fb, const cha
         calls++;
     }
     return calls;
+}
+
+// Host-side counterpart of the ct_assemble kernel, for tile buffers that arrive in HOST memory (ranks on
+// different nodes gathering over MPI / gloo): `gathered` holds the part_count partitions' compact buffers back
+// to back, as ctgpu_render_partition leaves them; fb gets exactly the pixels ct_assemble would write.
+// The layout arithmetic is the one definition both share, include/ct_tiles.h.
+int cth_assemble_tiles(const ctgpu_frame_desc *frame, int tile_rows, int part_count, const uint32_t *gathered, uint32_t *fb) {
+    if (!frame || !gathered || !fb || tile_rows < 1 || part_count < 1 || frame->width <= 0 || frame->height <= 1 ||
+        frame->num_threads <= 0 || frame->num_threads > frame->height)
+        return -1;
+    ct_tile_layout L;
+    L.width = frame->width; L.height = frame->height; L.half = frame->height / 2;
+    L.square = (uint32_t)(2 * L.half);
+    L.rows_per_band = (uint32_t)(frame->height / frame->num_threads);
+    L.rendered_rows = (uint32_t)frame->num_threads * L.rows_per_band;
+    L.subsample = (frame->flags & CTGPU_F_SUBSAMPLE) ? 1u : 0u;
+    L.tile_rows = (uint32_t)tile_rows; L.part_count = (uint32_t)part_count;
+    L.local_rows = ct_tiles_local_rows(L.rendered_rows, L.tile_rows, L.part_count);
+    for (uint32_t yi = 0; yi < L.rendered_rows; yi++)
+        for (uint32_t xi = 0; xi < L.square; xi++) {
+            uint64_t slot;
+            if (ct_tiles_bitmap_slot(&L, xi, yi, &slot)) fb[slot] = ct_tiles_pixel(&L, gathered, xi, yi);
+        }
+    return 0;
 }
 
 void cth_get_rotation(void *p, double rot[9]) { std::memcpy(rot, H(p)->scene.camera.rotation.data, 72); }

@@ -15,7 +15,10 @@
  *                               raythread.cpp:437-543, 353-386, 197-228, 275-350, 176-184;
  *                               bvh.cpp:147-222; color.h:18-126; draw2d.h:8-20
  *   ctgpu_render_multi          the same with the row bands of HandleUpdates (raythread.cpp:574-588)
- *                               dealt to several GPUs of one process
+ *                               dealt to several GPUs of one process (RCCL gather between them)
+ *   ctgpu_comm_* /              the same for one process per GPU: communicator set-up, the gather, and one
+ *   ctgpu_gather_tiles /        rank's whole share of a frame (trace, gather, assemble on rank 0)
+ *   ctgpu_render_sharded
  *   ctgpu_render_partition /    the row-band split of HandleUpdates (raythread.cpp:574-588)
  *   ctgpu_assemble              re-cut into interleaved row tiles for N GPUs, and the merge of
  *                               the per-GPU tiles into the caller's framebuffer
@@ -50,6 +53,7 @@ typedef struct ctgpu_ctx ctgpu_ctx;
 #define CTGPU_ERR_STACK      -4   /* traversal stack overflow (tree deeper than the
                                      library's capacity, CTGPU_MAX_TREE_DEPTH)      */
 #define CTGPU_ERR_NO_DEVICE  -5
+#define CTGPU_ERR_COMM       -6   /* RCCL: library missing, no communicator, or a failed call */
 
 #define CTGPU_MAX_TREE_DEPTH 64
 
@@ -177,6 +181,23 @@ int  ctgpu_render_partition(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, const
                             void *d_tiles, void *stream);
 int  ctgpu_assemble(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, const ctgpu_partition *part,
                     const void *d_all_tiles, void *d_fb, void *stream);
+/* One process per GPU (raythread.cpp:574-618 had one worker thread per band; here one rank per device):
+ * the frame's only collective -- an RCCL gather (ncclGather) of the ranks' tile buffers to rank 0 over xGMI --
+ * issued by this library on the frame's stream.
+ * ctgpu_comm_unique_id: rank 0 makes the id (ncclGetUniqueId) and hands its CTGPU_COMM_ID_BYTES bytes to the
+ *   other ranks by whatever channel the host application has (bench.py: a torch.distributed broadcast).
+ * ctgpu_comm_init: every rank, collectively (ncclCommInitRank on the context's device).
+ * ctgpu_gather_tiles: n uint32 from every rank, back to back into d_all on `root` (d_all ignored elsewhere).
+ * ctgpu_render_sharded: this rank's share of one frame -- trace my tiles, gather to rank 0, assemble there into
+ *   d_fb (rank 0's device framebuffer, width*height uint32) -- all queued on `stream`, nothing synchronises. */
+#define CTGPU_COMM_ID_BYTES 128
+int  ctgpu_comm_unique_id(void *id);
+int  ctgpu_comm_init(ctgpu_ctx *ctx, const void *id, int rank, int world);
+int  ctgpu_comm_rank(ctgpu_ctx *ctx, int *rank, int *world);
+int  ctgpu_comm_destroy(ctgpu_ctx *ctx);
+int  ctgpu_gather_tiles(ctgpu_ctx *ctx, const void *d_tiles, uint64_t n, void *d_all, int root, void *stream);
+int  ctgpu_render_sharded(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, int tile_rows, void *d_fb, void *stream);
+
 /* Ray counters accumulated by render calls since the last read (resets them). Synchronises. */
 int  ctgpu_read_counters(ctgpu_ctx *ctx, ctgpu_stats *stats);
 
@@ -194,6 +215,19 @@ int  ctgpu_trace_rays_packet(ctgpu_ctx *ctx, const ctgpu_ray *rays, uint64_t n, 
 /* Instrumented render of the same frame (slower; no framebuffer): fills node_visits and
  * triangle_tests besides the ray counts.  These are the V_r / Q_r sums of the roofline model. */
 int  ctgpu_count_work(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, ctgpu_stats *stats);
+
+/* ---- measurement hooks (bench.py's roofline object; no effect on pixels) ----
+ * ctgpu_read_walk_work: what the two traversal launches (the shared "packet" walk of the fast path) asked the
+ *   memory system for since the last read -- packets walked, QuadNodes (128 B) and triangle records (80 B)
+ *   fetched; [0] primary walk, [1] shadow walk.  Counted by the production kernels themselves.  Synchronises, resets.
+ * ctgpu_kernel_timing / ctgpu_read_kernel_times: HIP events on the frame's own stream around every kernel of the
+ *   fast path, for every frame rendered while enabled; read = synchronise on them, sum, reset. */
+#define CTGPU_PIPELINE_KERNELS 5       /* ct_sample_grid, primary walk, ct_light_gate, shadow walk, ct_shade */
+typedef struct ctgpu_walk_work { uint64_t packets[2], quad_nodes[2], triangle_records[2]; } ctgpu_walk_work;
+typedef struct ctgpu_kernel_times { uint64_t launches[CTGPU_PIPELINE_KERNELS]; double total_ms[CTGPU_PIPELINE_KERNELS]; } ctgpu_kernel_times;
+int  ctgpu_read_walk_work(ctgpu_ctx *ctx, ctgpu_walk_work *out);
+int  ctgpu_kernel_timing(ctgpu_ctx *ctx, int enable);
+int  ctgpu_read_kernel_times(ctgpu_ctx *ctx, ctgpu_kernel_times *out);
 
 /* The jitter stream CTGPU_RNG_LIBC uses: glibc 2.35 rand() after srand(seed), skipping the
  * first `offset` values (host-side; exported so a test can compare it with libc itself). */

@@ -10,18 +10,25 @@
  * the reference lines it follows.  It deliberately keeps the reference's shape
  * (recursive traversal, one OS thread per row band) and none of the GPU design.
  *
- * PARITY PIN: the reference cannot be compiled in this image without writing a
- * stand-in for SDL.h (every translation unit includes it; SDL2 is not installed)
- * and without patching raythread.cpp:119 (a hard error on g++ 11), so no
- * oracle/_ref build of the renderer exists.  The oracle is pinned instead
- * against the reference outputs recorded in SURVEY.md section 8(c) -- FNV-1a-64
- * hashes of whole framebuffers of the compiled reference for the cube, import and
- * bunny scenes (ss off at T=8/32, ss on at T=1 with glibc rand()), plus triangle,
- * node and index hashes and the BvhTest known answer -- see tests/golden/
- * reference_kat.json and tests/test_oracle_kat.py.  The header-only parts of the
- * reference that DO compile on their own (mymath.h, color.h) are additionally
- * compiled in place by oracle/Makefile into oracle/_ref/ and compared function
- * by function (tests/test_oracle_vs_ref_headers.py).
+ * PARITY PIN -- "parity unpinned" beyond the header slice.  The reference's renderer
+ * cannot be compiled in this image under the task's rules: every translation unit
+ * includes SDL.h (SDL2 is not installed; writing a stand-in header is not allowed) and
+ * raythread.cpp:119 is a hard error on g++ 11.  So no oracle/_ref build of the renderer
+ * exists, and the reference holds no tests, fixtures or golden vectors of its own.
+ * What pins this oracle:
+ *   (1) the parts of the reference that DO compile from their own files -- mymath.h and
+ *       color.h -- built in place by oracle/Makefile into oracle/_ref/ and compared
+ *       function by function (tests/test_oracle_vs_ref_headers.py), 5,500 of those
+ *       input/output vectors frozen in tests/golden/color_vectors.json;
+ *   (2) the countable known answers of the compiled reference that the survey recorded
+ *       (tests/golden/reference_kat.json, tests/test_oracle_kat.py):
+ *       triangle / node counts, the bunny's leaf histogram and depth, its first vertex,
+ *       parsed constants, seven individual pixel values, hit-pixel counts, and the
+ *       67,022,780 IntersectAABB / 5,535,094 IntersectTriangle calls of one bunny frame.
+ * The survey's FNV-1a-64 hashes of whole reference framebuffers are listed in
+ * reference_kat.json as "hashes_unverified" and are NOT asserted: they could not be
+ * reproduced with the hash the survey describes.  Traversal and lighting are therefore
+ * pinned by counts and single pixels, not by a whole-frame golden of the reference.
  *
  * Descriptors are shared with include/ctgpu.h so that a test feeds the very same
  * bytes to the oracle and to the HIP library.

@@ -185,6 +185,73 @@ def test_partitions_assemble_to_the_same_frame(scenes, gpu_ctx):
             got = fb.cpu().numpy().view(np.uint32).reshape(frame.height, frame.width)
             assert (got == whole).all(), "parts=%d tile_rows=%d ss=%d sub=%d" % (parts, tile_rows, ss, sub)
             bufs.append(got)
+            # the host layer's assemble (tile buffers gathered into host memory) writes the same pixels
+            on_host = np.zeros((frame.height, frame.width), dtype=np.uint32)
+            tiles_host = np.ascontiguousarray(gathered.cpu().numpy().view(np.uint32))
+            assert ca.host_library().cth_assemble_tiles(C.byref(frame), tile_rows, parts, tiles_host.ctypes.data,
+                                                        on_host.ctypes.data) == 0
+            assert (on_host == whole).all(), "host assemble: parts=%d tile_rows=%d ss=%d sub=%d" % (parts, tile_rows, ss, sub)
+
+
+def test_native_rccl_frame_on_a_world_of_one(scenes, gpu_ctx):
+    """The C++ side of the multi-GPU frame -- ctgpu_comm_init (ncclCommInitRank), ctgpu_render_sharded = trace my
+    tiles + ncclGather to rank 0 + ct_assemble -- exercised with the only world a one-GPU box can form (RCCL does
+    not let two ranks share a device): librccl is found and bound, the communicator comes up, the gather runs on
+    the frame's stream, the assembled frame equals ctgpu_render's."""
+    torch = pytest.importorskip("torch")
+    scene = scenes("bunny")
+    ctx = ca.GpuContext(0)
+    ctx.upload(scene.desc)
+    try:
+        ctx.comm_init(ca.GpuContext.comm_unique_id(), 0, 1)
+        with pytest.raises(RuntimeError, match="already has a communicator"):
+            ctx.comm_init(ca.GpuContext.comm_unique_id(), 0, 1)
+        stream = torch.cuda.Stream()
+        for ss, sub in ((False, False), (True, False), (False, True)):
+            frame = scene.frame(640, 360, threads=8, supersampling=ss, subsampling=sub, rng_seed=9)
+            want, _ = gpu_ctx("bunny").render(frame)
+            fb = torch.zeros(frame.height * frame.width, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            ctx.render_sharded(frame, 8, fb.data_ptr(), stream.cuda_stream)
+            stream.synchronize()
+            ctx.read_counters()
+            assert (fb.cpu().numpy().view(np.uint32).reshape(frame.height, frame.width) == want).all()
+    finally:
+        ctx.close()
+    # no communicator: the sharded entry points say so instead of falling back to anything
+    with pytest.raises(RuntimeError, match="no communicator"):
+        gpu_ctx("bunny").render_sharded(scene.frame(64, 64, threads=1), 8, 0)
+
+
+def test_measurement_hooks(scenes):
+    """ctgpu_kernel_timing / ctgpu_read_kernel_times and ctgpu_read_walk_work, what bench.py's roofline object is
+    made of: one launch of each pipeline kernel per frame, event times that add up to the frame's kernel time,
+    fetch counts of the two walks that are plausible (every packet fetches at least the root QuadNode)."""
+    scene = scenes("bunny")
+    ctx = ca.GpuContext(0)
+    ctx.upload(scene.desc)
+    try:
+        frame = scene.frame(640, 360, threads=8, supersampling=True, rng_seed=1)
+        ctx.render(frame)
+        ctx.read_walk_work()
+        ctx.kernel_timing(True)
+        _, st = ctx.render(frame)
+        _, st2 = ctx.render(frame)
+        times = ctx.read_kernel_times()
+        assert list(times.launches) == [2] * 5
+        total = sum(times.total_ms)
+        assert 0.7 * (st.kernel_ms + st2.kernel_ms) < total < 1.3 * (st.kernel_ms + st2.kernel_ms) + 0.1
+        work = ctx.read_walk_work()
+        n_primary = st.rays_primary + st2.rays_primary
+        assert work.packets[0] * 64 >= n_primary and work.packets[0] * 64 < n_primary + 2 * 64 * 6144
+        assert work.quad_nodes[0] >= work.packets[0] * 0.5 and work.triangle_records[0] > 0
+        assert 0 < work.packets[1] * 64 < 2 * (st.rays_shadow + st2.rays_shadow) + 2 * 64 * 6144
+        assert work.quad_nodes[1] > 0 and work.triangle_records[1] > 0
+        ctx.kernel_timing(False)
+        ctx.render(frame)
+        assert list(ctx.read_kernel_times().launches) == [0] * 5
+    finally:
+        ctx.close()
 
 
 def test_dragon_full_size_properties(scenes, gpu_ctx):

@@ -1,7 +1,8 @@
 """The N > 1 path on CPU: two gloo ranks shard a frame by interleaved row tiles exactly as
 bench.py does on N GPUs (cobbletrace_amd.multi_gpu), gather the tile buffers to rank 0 and
 assemble them.  The per-rank tracing stands in for the HIP kernel by using the oracle (this is a
-test), the layout / gather / assemble logic is the product's."""
+test); the partition arithmetic (ctgpu_partition_pixels), the gather plumbing and the assemble
+(cth_assemble_tiles, compiled from the same include/ct_tiles.h as the ct_assemble kernel) are the product's."""
 import os
 import socket
 import sys
@@ -40,19 +41,14 @@ def _local_tiles(frame, part, scene_desc, oracle, n_pixels):
     return tiles
 
 
-def _assemble_numpy(frame, tile_rows, world, gathered):
-    """ct_assemble restated in numpy (subsampling off)."""
-    half = frame.height // 2
-    square = 2 * half
-    rows = frame.num_threads * (frame.height // frame.num_threads)
-    per_rank = gathered.reshape(world, -1, square)
+def _assemble(frame, tile_rows, world, gathered):
+    """The product's own host-side assemble (libcthost.so cth_assemble_tiles; the same include/ct_tiles.h
+    arithmetic the ct_assemble kernel is compiled from)."""
+    import ctypes as C
+    import cobbletrace_amd as ca
     fb = np.zeros((frame.height, frame.width), dtype=np.uint32)
-    for yi in range(rows):
-        tile = yi // tile_rows
-        owner, lr = tile % world, (tile // world) * tile_rows + yi % tile_rows
-        row = frame.height // 2 - (yi - half)
-        if 0 <= row < frame.height:
-            fb[row, frame.width // 2 - half: frame.width // 2 + half] = per_rank[owner, lr]
+    gathered = np.ascontiguousarray(gathered, dtype=np.uint32)
+    assert ca.host_library().cth_assemble_tiles(C.byref(frame), tile_rows, world, gathered.ctypes.data, fb.ctypes.data) == 0
     return fb
 
 
@@ -81,7 +77,7 @@ def _worker(rank, world, port, result_path):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         ok = ok and tmax.item() == world
         if rank == 0:
-            fb = _assemble_numpy(frame, tile_rows, world, gathered.numpy().view(np.uint32))
+            fb = _assemble(frame, tile_rows, world, gathered.numpy().view(np.uint32))
             want, _ = oracle.render(scene.desc, frame, os_threads=2)
             ok = ok and bool((fb == want).all())
         else:
