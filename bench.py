@@ -1,21 +1,27 @@
 #!/usr/bin/env python3
-"""bench.py -- Mrays/s of the CobbleTrace hot path on MI355X.
+"""bench.py -- Mrays/s and ms/frame of the CobbleTrace hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
 
-A step is ONE FRAME of BASELINE.json's headline workload: scene_import_dragon.json at
-1920x1080 with the scene file's own settings (32 row bands, supersampling on = 16 jittered
-samples per pixel, subsampling off), jitter from the counter-based generator (the mode in
-which GPU and CPU pixels are comparable).  The Stanford dragon itself is not
-distributed with the reference; the mesh is the repository's deterministic 871,200-triangle
-stand-in (tools/make_dragon_standin.py) -- "data" says so.
+A step is ONE FRAME of BASELINE.json's headline workload: scene_import_dragon.json at 1920x1080 with
+the scene file's own settings (32 row bands, supersampling on = 16 jittered samples per pixel,
+subsampling off, three lights with shadow rays), jitter from the counter-based generator (the mode in
+which GPU and CPU pixels are comparable).  The Stanford dragon itself is not distributed
+with the reference; the mesh is the repository's deterministic 871,200-triangle stand-in
+(tools/make_dragon_standin.py) -- "data" says so.
 
-For N > 1 (launched by torch.distributed.run, one rank per GPU) the frame's row tiles are
-dealt round-robin to the ranks and assembled with one RCCL gather; the total work per step
-is fixed, so scaling is "strong".  value = rays of all ranks / wall time (max over ranks),
-everything resident in HBM; the host-framebuffer copy is reported separately.
+What is timed (dispatch -> last pixel in the HOST framebuffer): every frame is traced,
+gathered (N > 1), assembled and copied into a pinned host framebuffer; `value` = rays traced by all
+ranks / wall time of K frames (max over ranks), scene resident in HBM, a few frames in flight so that
+frame i's tail, gather and copy overlap frame i+1's tracing.  The device-only rate is reported beside it.
+
+For N > 1 (launched by torch.distributed.run, one rank per GPU) the frame's row tiles are dealt
+round-robin to the ranks and assembled on rank 0 after ONE RCCL gather, issued natively by libctgpu.so
+(ctgpu_render_sharded: ncclGather on the frame's stream); the total work per step is fixed, so scaling
+is "strong".  torch.distributed only carries the communicator id, the barriers and the timing reduction.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -28,6 +34,10 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 # algorithmic bytes, reference layout: node 64 B, triangle test 4 B index + 72 B
 # vertices, shaded hit 12 B material + 72 B vertices, pixel 4 B
 B_NODE, B_TRI, B_HIT, B_PIXEL = 64, 76, 84, 4
+# the kernels' own records (ct_device.h): QuadNode 128 B, TriRecord 80 B
+B_QUAD, B_RECORD = 128, 80
+KERNELS = ("ct_sample_grid", "ct_walk_packet<primary>", "ct_light_gate", "ct_walk_packet<shadow>", "ct_shade")
+KERNEL_SOURCES = ("ct_pipeline.hip", "ct_device.h", "ct_params.h", "ct_raygen.h", "ctgpu_api.hip")
 
 
 def parse_args():
@@ -41,10 +51,11 @@ def parse_args():
     ap.add_argument("--supersampling", type=int, default=-1, help="-1: scene file's setting")
     ap.add_argument("--inflight", type=int, default=3, help="frames in flight (1 = strictly serial frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-bands", type=int, default=16, help="row bands (of T) the CPU baseline samples")
-    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
-                    help="development aid: run the N-rank code path with every rank on GPU 0 and the gather "
-                         "staged through gloo (RCCL refuses two ranks on one device); numbers are meaningless")
+    ap.add_argument("--cpu-seconds", type=float, default=60.0, help="budget of the CPU baseline leg (it drops variants to fit)")
+    ap.add_argument("--collective", default="native", choices=["native", "torch"],
+                    help="N > 1: the RCCL gather issued by libctgpu.so (default) or by torch.distributed")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="N = 1: still go through communicator set-up and the gather (a world of one)")
     return ap.parse_args()
 
 
@@ -52,56 +63,107 @@ SCENE_FILES = {"dragon": "scene_import_dragon.json", "bunny": "scene_import_bunn
                "import": "scene_import.json", "cube": "scene_file_cube.json"}
 
 
-def algorithmic_bytes(st, pixels):
-    hits = st.rays_shadow // 2 if st.rays_shadow else 0
-    return st.node_visits * B_NODE + st.triangle_tests * B_TRI + hits * B_HIT + pixels * B_PIXEL
+def kernel_source_hash():
+    """Identifies the kernels a profiles/ record was measured on (the GPU box has no .git)."""
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "cobbletrace_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
 
 
-def cpu_baseline(scene, frame, n_bands):
-    """The oracle -- a plain-C port of the reference's Boss/Worker path, one worker thread per
-    row band like raythread.cpp:596-618 -- timed on this box's host cores on a bounded sample:
-    n_bands of the frame's T bands spread evenly over the image, all running concurrently."""
-    from oracle import oracle           # the checker, used here only as the timed CPU baseline
+def profile_record(kind):
+    """Newest profiles/rNN_<kind>.json whose kernel_source_hash is that of the sources on disk, else None:
+    PMC counters cannot be collected from inside this process, and a stale file must not be quoted."""
+    import glob
+    want = kernel_source_hash()
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s.json" % kind)), reverse=True):
+        try:
+            rec = json.load(open(path))
+        except ValueError:
+            continue
+        if rec.get("kernel_source_hash") == want:
+            rec["_source"] = os.path.relpath(path, ROOT)
+            return rec
+    return None
+
+
+def cpu_baseline(ca, scene, frame, gpu_host_fb, budget_s):
+    """The oracle -- a plain-C port of the reference's Boss/Worker path, one worker thread per row band like
+    raythread.cpp:596-618 -- timed on this box's host cores, WHOLE frames of the same workload:
+    the scene file's configuration first (its frame is also compared with the GPU's, pixel by pixel), then
+    the other thread counts / sampling / jitter modes while the time budget lasts."""
+    from oracle import oracle           # the checker, used here only as the timed CPU baseline + parity check
+    import copy
     import numpy as np
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    spent = [0.0]
+
+    def run(label, ss, rng, threads):
+        f = copy.copy(frame)
+        f.flags = (f.flags & ~ca.F_SUPERSAMPLE) | (ca.F_SUPERSAMPLE if ss else 0)
+        f.rng_mode = rng
+        f.rng_seed = frame.rng_seed if rng == ca.RNG_HASH else 1
+        f.num_threads = threads
+        t0 = time.perf_counter()
+        fb, st = oracle.render(scene.desc, f, os_threads=0)          # one OS thread per band, as the reference
+        s = time.perf_counter() - t0
+        spent[0] += s
+        return {"config": label, "threads": threads, "rays": int(st.rays), "seconds": round(s, 3),
+                "Mrays/s": round(st.rays / s / 1e6, 3), "ms/frame": round(s * 1e3, 1)}, fb
+
     T = frame.num_threads
-    n_bands = max(1, min(n_bands, T))
-    stride = max(1, T // n_bands)
-    first = (T - ((n_bands - 1) * stride + 1)) // 2
-    threads = min(cores, n_bands)
-    fb = np.zeros((frame.height, frame.width), dtype=np.uint32)
-    t0 = time.perf_counter()
-    _, st = oracle.render(scene.desc, frame, os_threads=threads, band_first=first, band_count=n_bands,
-                          band_stride=stride, fb=fb)
-    seconds = time.perf_counter() - t0
-    picks = [first + i * stride for i in range(n_bands)]
-    return st.rays / seconds / 1e6, threads, picks, st.rays, seconds
+    is_ss = bool(frame.flags & ca.F_SUPERSAMPLE)
+    head, fb = run("scene file: ss=%s, T=%d, hash jitter" % ("on" if is_ss else "off", T), is_ss, ca.RNG_HASH, T)
+    parity = None
+    if gpu_host_fb is not None:
+        a, b = gpu_host_fb, fb
+        shifts = np.array([0, 8, 16])
+        diff = np.abs(((a[..., None] >> shifts) & 255).astype(np.int32) - ((b[..., None] >> shifts) & 255).astype(np.int32))
+        parity = {"compared": "whole frame, GPU host framebuffer of the last timed frame vs oracle (%d x %d)" % a.shape[::-1],
+                  "differing_pixels": int((a != b).sum()), "parity_max_lsb": int(diff.max()),
+                  "pixels_written": int((b != 0).sum())}
+    variants = [head]
+    plan = [("ss=%s, T=%d, hash jitter" % ("off" if is_ss else "on", T), not is_ss, ca.RNG_HASH, T),
+            ("ss=on, T=nproc=%d, hash jitter" % min(cores, frame.height), True, ca.RNG_HASH, min(cores, frame.height)),
+            ("ss=off, T=nproc=%d" % min(cores, frame.height), False, ca.RNG_HASH, min(cores, frame.height)),
+            ("ss=on, T=1, libc rand() (the reference's own generator; deterministic only at T=1)", True, ca.RNG_LIBC, 1)]
+    for label, ss, rng, threads in plan:
+        # a variant costs about the head's time scaled by its ray count and thread count
+        guess = head["seconds"] * (1.0 if ss == is_ss else (1 / 16.0 if is_ss else 16.0)) * (max(1, min(T, cores)) / max(1, min(threads, cores)))
+        if spent[0] + guess > budget_s:
+            variants.append({"config": label, "skipped": "over the --cpu-seconds budget (estimated %.0f s)" % guess})
+            continue
+        variants.append(run(label, ss, rng, threads)[0])
+    out = {"value": head["Mrays/s"], "unit": "Mrays/s", "cores": min(T, cores), "kind": "port",
+           "sample": "the WHOLE frame of the same workload (%d rays in %.2f s): oracle/ct_oracle.c, one worker thread per row "
+                     "band (T = %d threads on the %d host cores this process may use)" % (head["rays"], head["seconds"], T, cores),
+           "ms_per_frame": head["ms/frame"], "host_cores": cores, "variants": variants,
+           "note": "libc mode draws rand() into a table up front, so it does not reproduce the reference's rand() lock "
+                   "contention (BASELINE.md: 32 reference threads are slower than 1 with supersampling on)"}
+    return out, parity
 
 
 def main():
     args = parse_args()
+    import numpy as np
     import torch
     import torch.distributed as dist
     import cobbletrace_amd as ca
-    from cobbletrace_amd.multi_gpu import ShardedRenderer
+    from cobbletrace_amd import multi_gpu
     import __graft_entry__ as entry
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    if world != args.gpus and world == 1 and args.gpus > 1:
+        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device is visible")
-    if args.rehearse_on_one_gpu:
-        local_rank = 0
     torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
     if world > 1:
-        if args.rehearse_on_one_gpu:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", device_id=device)
 
     # every rank needs the assets and the native libraries; rank 0 prepares, the others wait
     if rank == 0:
@@ -118,31 +180,56 @@ def main():
     ss = None if args.supersampling < 0 else bool(args.supersampling)
     frame = scene.frame(args.width, args.height, supersampling=ss, rng_mode=ca.RNG_HASH, rng_seed=0)
     is_ss = bool(frame.flags & ca.F_SUPERSAMPLE)
+    tile_rows = 8
 
-    # Frames are double-buffered (--inflight 2): frame i+1 is traced on a second stream / context
-    # while frame i's kernels drain their tail and its tiles are gathered and assembled, the way a
-    # renderer producing a stream of frames runs.  Each context owns its scene copy and scratch arrays.
+    # A few frames in flight: frame i+1 is traced on another stream / context while frame i's kernels drain
+    # their tail and its tiles are gathered, assembled and copied to the host, the way a renderer producing a
+    # stream of frames runs.  Each slot owns a context (scene copy + scratch arrays), a stream, a communicator,
+    # a device framebuffer and a pinned host framebuffer.
     inflight = max(1, args.inflight)
     # Throughput tuning through the library's documented knobs (read at context creation): with several
-    # frames in flight and only a slice of the frame per rank, a smaller persistent grid per context
-    # and 128-ray-id chunks beat the defaults, which are tuned for one frame's latency
-    # (tools/overlap.py: 8-way share 0.57 -> 0.50 ms, while a quarter of the frame is better off with the
-    # defaults: 0.90 vs 0.94 ms).
+    # frames in flight and only an eighth of the frame per rank, a smaller persistent grid per context
+    # and 128-ray-id chunks beat the defaults, which are tuned for one frame's latency.
     if inflight > 1 and world >= 8:
         os.environ.setdefault("CTGPU_BLOCKS_PER_CU", "12")
         os.environ.setdefault("CTGPU_CHUNK", "128")
-    renderers = [ShardedRenderer(scene.desc, rank, world, local_rank) for _ in range(inflight)]
-    streams = [torch.cuda.Stream() for _ in range(inflight)]
-    renderer = renderers[0]
 
-    def gather(tiles):
-        if world == 1:
-            return tiles
-        if args.rehearse_on_one_gpu:                      # gloo cannot move device memory: stage through the host
-            torch.cuda.current_stream().synchronize()
-            staged = ca.multi_gpu.gather_to_root(tiles.cpu(), world, rank)
-            return staged.cuda() if staged is not None else None
-        return ca.multi_gpu.gather_to_root(tiles, world, rank)
+    use_comm = world > 1 or args.force_collective
+    collective = "none"
+    slots = []
+    for i in range(inflight):
+        ctx = ca.GpuContext(local_rank)
+        ctx.upload(scene.desc)
+        part = ca.Partition(tile_rows, rank, world)
+        n_tile = ctx.partition_pixels(frame, part)
+        slot = {"ctx": ctx, "part": part, "stream": torch.cuda.Stream(device=device), "n_tile": n_tile,
+                "tiles": torch.zeros(n_tile, dtype=torch.int32, device=device),
+                "fb": torch.zeros(frame.height * frame.width, dtype=torch.int32, device=device) if rank == 0 else None,
+                "host_fb": torch.zeros(frame.height * frame.width, dtype=torch.int32).pin_memory() if rank == 0 else None,
+                "native": False}
+        if use_comm and args.collective == "native":
+            # rank 0 makes the RCCL unique id, torch.distributed carries its 128 bytes to the other ranks
+            try:
+                uid = torch.zeros(128, dtype=torch.uint8, device=device)
+                if rank == 0:
+                    uid.copy_(torch.frombuffer(bytearray(ca.GpuContext.comm_unique_id()), dtype=torch.uint8))
+                if world > 1:
+                    dist.broadcast(uid, src=0)
+                ctx.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
+                slot["native"] = True
+            except RuntimeError as e:                      # stay measurable: the same collective through torch.distributed
+                if rank == 0:
+                    print("bench.py: native communicator unavailable (%s); gathering through torch.distributed" % e, file=sys.stderr)
+        slots.append(slot)
+    if use_comm:
+        native_everywhere = torch.tensor([1.0 if all(s["native"] for s in slots) else 0.0], device=device)
+        if world > 1:
+            dist.all_reduce(native_everywhere, op=dist.ReduceOp.MIN)
+        if native_everywhere.item() < 1.0:
+            for s in slots:
+                s["native"] = False
+        collective = ("RCCL ncclGather to rank 0, issued by libctgpu.so (ctgpu_render_sharded)" if slots[0]["native"]
+                      else "RCCL gather to rank 0 through torch.distributed")
 
     def sync_all():
         torch.cuda.synchronize()
@@ -150,100 +237,152 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def one_frame(i, events=None):
-        """Issue frame i: trace my tiles, gather to rank 0, assemble there (all asynchronous)."""
-        r, s_ = renderers[i % inflight], streams[i % inflight]
-        with torch.cuda.stream(s_):
-            if events:
-                events[0].record(s_)
-            tiles = r.trace(frame)
-            if events:
-                events[1].record(s_)
-            gathered = gather(tiles)
-            if rank == 0:
-                _, fb = r._buffers_for(frame)
-                r.ctx.assemble(frame, r.part, gathered.data_ptr(), fb.data_ptr(), s_.cuda_stream)
-                return fb
-        return None
+    def one_frame(i, to_host=True):
+        """Issue frame i: trace my tiles, gather to rank 0, assemble there, copy to the host framebuffer -- all
+        asynchronous on the slot's stream."""
+        s = slots[i % inflight]
+        stream = s["stream"]
+        with torch.cuda.stream(stream):
+            if s["native"]:
+                s["ctx"].render_sharded(frame, tile_rows, s["fb"].data_ptr() if rank == 0 else 0, stream.cuda_stream)
+            else:
+                s["ctx"].render_partition(frame, s["part"], s["tiles"].data_ptr(), stream.cuda_stream)
+                gathered = s["tiles"] if world == 1 else multi_gpu.gather_to_root(s["tiles"], world, rank)
+                if rank == 0:
+                    s["ctx"].assemble(frame, s["part"], gathered.data_ptr(), s["fb"].data_ptr(), stream.cuda_stream)
+            if rank == 0 and to_host:
+                s["host_fb"].copy_(s["fb"], non_blocking=True)
+        return s
+
+    def timed(n_frames, to_host):
+        sync_all()
+        t0 = time.perf_counter()
+        for i in range(n_frames):
+            one_frame(i, to_host)
+        sync_all()
+        return time.perf_counter() - t0
 
     for i in range(max(args.warmup, inflight)):
         one_frame(i)
     sync_all()
-    for r in renderers:
-        r.ctx.read_counters()             # reset the ray counters
+    for s in slots:
+        s["ctx"].read_counters()             # reset the ray counters
+        s["ctx"].read_walk_work()
+        s["ctx"].kernel_timing(True)         # HIP events around every pipeline kernel, on the frame's own stream
 
-    # ---- timed region: exactly K frames
-    sync_all()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        one_frame(i)
-    sync_all()
-    elapsed = time.perf_counter() - t0
+    # ---- timed region: exactly K frames, dispatch -> pixels in the host framebuffer
+    elapsed = timed(args.steps, to_host=True)
 
-    counted = [r.ctx.read_counters() for r in renderers]
+    counted = [s["ctx"].read_counters() for s in slots]
+    times = [s["ctx"].read_kernel_times() for s in slots]
+    works = [s["ctx"].read_walk_work() for s in slots]
+    for s in slots:
+        s["ctx"].kernel_timing(False)
     my_rays = float(sum(c.rays for c in counted))
-    totals = torch.tensor([my_rays, elapsed], dtype=torch.float64,
-                          device="cpu" if args.rehearse_on_one_gpu else "cuda")
+    my_elided = float(sum(c.rays_shadow_elided for c in counted))
+    totals = torch.tensor([my_rays, my_elided, elapsed], dtype=torch.float64, device=device)
     if world > 1:
-        rays_all = totals[:1].clone()
-        dist.all_reduce(rays_all, op=dist.ReduceOp.SUM)
-        time_max = totals[1:].clone()
+        sums = totals[:2].clone()
+        dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        time_max = totals[2:].clone()
         dist.all_reduce(time_max, op=dist.ReduceOp.MAX)
-        total_rays, elapsed = float(rays_all.item()), float(time_max.item())
+        total_rays, total_elided, elapsed = float(sums[0].item()), float(sums[1].item()), float(time_max.item())
     else:
-        total_rays = my_rays
+        total_rays, total_elided = my_rays, my_elided
     rays_per_frame = total_rays / args.steps
     ms_per_step = elapsed / args.steps * 1e3
     value = total_rays / elapsed / 1e6
 
-    # ---- un-overlapped passes (outside the timed region): kernel time for the roofline, one frame's
-    # latency, and the frame -> host framebuffer hand-off (PCIe included; never `value`)
+    # ---- outside the timed region: the same K frames left on the device (no host copy), and one frame alone
+    elapsed_device = timed(args.steps, to_host=False)
+    if world > 1:
+        t = torch.tensor([elapsed_device], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed_device = float(t.item())
     serial = 5
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(serial)]
+    slots[0]["ctx"].kernel_timing(True)
     sync_all()
     t0 = time.perf_counter()
     for k in range(serial):
-        one_frame(0, ev[k])
+        one_frame(0)
         sync_all()
     latency_ms = (time.perf_counter() - t0) / serial * 1e3
-    kernel_ms = sum(a.elapsed_time(b) for a, b in ev) / serial
-    rank0_rays_per_frame = renderers[0].ctx.read_counters().rays / serial
-    host_fb = torch.empty(frame.height * frame.width, dtype=torch.int32).pin_memory() if rank == 0 else None
-    sync_all()
-    t0 = time.perf_counter()
-    fb = one_frame(0)
-    if rank == 0:
-        with torch.cuda.stream(streams[0]):
-            host_fb.copy_(fb, non_blocking=True)
-    torch.cuda.synchronize()
-    to_host_ms = (time.perf_counter() - t0) * 1e3
+    alone = slots[0]["ctx"].read_kernel_times()          # the same kernels with nothing else on the GPU
+    slots[0]["ctx"].kernel_timing(False)
+    for s in slots:
+        s["ctx"].read_counters()
 
     out = None
     if rank == 0:
-        # ---- roofline of the frame trace (ct_walk_packet dominates): algorithmic bytes of ONE frame
-        work = renderer.ctx.count_work(frame)           # whole frame, instrumented variant
-        pixels = int(work.rays_primary // (16 if is_ss else 1))
-        frame_bytes = algorithmic_bytes(work, pixels)
-        launch_bytes = frame_bytes * rank0_rays_per_frame / max(work.rays, 1)     # rank 0's share of the frame
-        achieved = launch_bytes / (kernel_ms * 1e-3) / 1e9
-        # HBM bytes per frame from the PMC passes of the same command (tools/collect_profiles.sh ->
-        # profiles/*_traffic.json); PMC counters cannot be collected from inside this process
-        traffic, traffic_src = None, None
-        if world == 1 and args.scene == "dragon" and args.width == 1920 and args.height == 1080 and is_ss:
-            import glob
-            found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
-            if found:
-                rec = json.load(open(found[-1]))
-                traffic, traffic_src = rec["hbm_bytes_per_frame"], os.path.relpath(found[-1], ROOT)
-        roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                    "kernel": "frame trace = ct_sample_grid + ct_walk_packet<primary> + ct_walk_packet<shadow> + ct_shade "
-                              "(the two ct_walk_packet launches are ~95 % of it; rocprof per-kernel split in profiles/)",
-                    "kernel_ms": round(kernel_ms, 4),
-                    "traffic_rate": (round(traffic / (kernel_ms * 1e-3) / 1e9, 1) if traffic else None),   # measured HBM GB/s
-                    "bytes_per_launch": int(launch_bytes), "bytes_per_ray": round(frame_bytes / max(work.rays, 1), 1),
-                    "node_visits_per_ray": round(work.node_visits / max(work.rays, 1), 2),
-                    "triangle_tests_per_ray": round(work.triangle_tests / max(work.rays, 1), 2)}
+        # ---- roofline of the dominant kernel, from what was measured live in the timed region
+        launches = [sum(t.launches[k] for t in times) for k in range(5)]
+        avg_ms = [sum(t.total_ms[k] for t in times) / max(launches[k], 1) for k in range(5)]
+        n_launch = max(launches[1], 1)
+        packets = [sum(w.packets[k] for w in works) / n_launch for k in range(2)]
+        quads = [sum(w.quad_nodes[k] for w in works) / n_launch for k in range(2)]
+        records = [sum(w.triangle_records[k] for w in works) / n_launch for k in range(2)]
+        per_launch_primary = sum(c.rays_primary for c in counted) / n_launch
+        per_launch_shadow = sum(c.rays_shadow for c in counted) / n_launch
+        per_launch_elided = sum(c.rays_shadow_elided for c in counted) / n_launch
+        n_lights = 2 if per_launch_shadow else 0
+        samples = per_launch_primary                                       # sample slots of this rank's share (traced ones)
+        pixels = samples / (16 if is_ss else 1)
+        hits = (per_launch_shadow + per_launch_elided) / max(n_lights, 1)
+        # bytes each kernel itself asks the memory system for, per launch (ct_device.h record sizes; per-sample
+        # arrays: position 8 B, hit record 8 B, one shadow byte per light)
+        own = {
+            "ct_sample_grid": samples * 8 if is_ss else 0,
+            "ct_walk_packet<primary>": quads[0] * B_QUAD + records[0] * B_RECORD + samples * ((8 if is_ss else 0) + 8),
+            "ct_light_gate": samples * (8 + (8 if is_ss else 0) + n_lights) + hits * 60,
+            "ct_walk_packet<shadow>": quads[1] * B_QUAD + records[1] * B_RECORD + samples * n_lights * 1
+                                      + per_launch_shadow * ((8 if is_ss else 0) + 8 + 1),
+            "ct_shade": samples * (8 + (8 if is_ss else 0) + n_lights) + hits * 60 + pixels * 4,
+        }
+        alone_ms = [alone.total_ms[k] / max(alone.launches[k], 1) for k in range(5)]
+        kernels = {KERNELS[k]: {"avg_ms": round(avg_ms[k], 4), "avg_ms_alone": round(alone_ms[k], 4), "launches": int(launches[k]),
+                                "own_bytes": int(own[KERNELS[k]]),
+                                "own_GB/s": round(own[KERNELS[k]] / max(avg_ms[k], 1e-9) / 1e6, 1)} for k in range(5)}
+        dom = max(range(5), key=lambda k: avg_ms[k])
+        dom_name = KERNELS[dom]
+        achieved = own[dom_name] / (avg_ms[dom] * 1e-3) / 1e9
+        traffic_rec, issue_rec = profile_record("traffic"), profile_record("issue")
+        traffic = None
+        if traffic_rec and world == 1 and args.scene == "dragon" and (args.width, args.height) == (1920, 1080) and is_ss:
+            traffic = traffic_rec.get("hbm_bytes_per_launch", {}).get(dom_name)
+        # the reference-layout figure of SURVEY.md 8(d), whole frame, instrumented kernel (not the bound: see DESIGN.md)
+        work = slots[0]["ctx"].count_work(frame) if world == 1 else None
+        roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "traffic_source": (traffic_rec["_source"] if traffic is not None else None),
+                    "launch_ms": round(avg_ms[dom], 4), "launches_timed": int(launches[dom]),
+                    "timing": "HIP events around each kernel on the frame's stream, all frames of the timed region" +
+                              (" (%d frames in flight: kernels of different frames share the GPU, so a launch lasts longer "
+                               "than it does alone -- launch_ms_alone / frac_alone, from %d serial frames after the timed region)"
+                               % (inflight, serial) if inflight > 1 else ""),
+                    "launch_ms_alone": round(alone_ms[dom], 4),
+                    "achieved_alone": round(own[dom_name] / (alone_ms[dom] * 1e-3) / 1e9, 1),
+                    "frac_alone": round(own[dom_name] / (alone_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "bytes_per_launch": int(own[dom_name]),
+                    "bytes_model": "the kernel's own requests: QuadNodes fetched x 128 B + triangle records fetched x 80 B "
+                                   "(counted by the kernel) + its per-sample / per-ray arrays",
+                    "per_launch": {"rays": int(per_launch_shadow if dom == 3 else per_launch_primary),
+                                   "packets": int(packets[1 if dom == 3 else 0]), "quad_nodes": int(quads[1 if dom == 3 else 0]),
+                                   "triangle_records": int(records[1 if dom == 3 else 0])},
+                    "kernels": kernels}
+        if work is not None:
+            ref_bytes = (work.node_visits * B_NODE + work.triangle_tests * B_TRI + (work.rays_shadow // 2) * B_HIT
+                         + int(work.rays_primary // (16 if is_ss else 1)) * B_PIXEL)
+            frame_kernel_ms = sum(avg_ms)
+            roofline["reference_bytes"] = {
+                "per_frame": int(ref_bytes), "per_ray": round(ref_bytes / max(work.rays, 1), 1),
+                "node_visits_per_ray": round(work.node_visits / max(work.rays, 1), 2),
+                "triangle_tests_per_ray": round(work.triangle_tests / max(work.rays, 1), 2),
+                "rate_GB/s": round(ref_bytes / (frame_kernel_ms * 1e-3) / 1e9, 1),
+                "note": "SURVEY.md 8(d): per-ray node / triangle fetches of the reference layout over the frame's kernel time; "
+                        "above the HBM peak because a wave fetches a node once for its 64 rays -- bytes the design does not move"}
+        if issue_rec:
+            roofline["issue"] = {k: v for k, v in issue_rec.items() if not k.startswith("_") and k != "kernel_source_hash"}
+            roofline["issue"]["source"] = issue_rec["_source"]
         out = {
             "metric": "Mrays/sec + ms/frame, scene_import_dragon.json @1920x1080" if args.scene == "dragon"
                       else "Mrays/sec + ms/frame, %s @%dx%d" % (SCENE_FILES[args.scene], args.width, args.height),
@@ -254,22 +393,24 @@ def main():
             "config": {"workload": "%s %dx%d T=%d %s, 3 lights with shadow rays" %
                                    (SCENE_FILES[args.scene], args.width, args.height, frame.num_threads,
                                     "supersampling 16 spp (hash jitter)" if is_ss else "1 spp"),
-                       "rays_per_frame": int(rays_per_frame), "row_tiles": "8 rows, round-robin over %d GPU(s)" % world,
-                       "collective": "RCCL gather to rank 0" if world > 1 else "none"},
+                       "rays_per_frame": int(rays_per_frame),
+                       "reference_rays_per_frame": int(rays_per_frame + total_elided / args.steps),
+                       "rays_note": "value counts rays actually traced; the reference also starts the shadow rays "
+                                    "ct_light_gate proves irrelevant (reference_rays_per_frame)",
+                       "row_tiles": "%d rows, round-robin over %d GPU(s)" % (tile_rows, world), "collective": collective},
+            "timed": "dispatch -> pixels in the pinned host framebuffer, every frame",
             "frames_in_flight": inflight, "ms_frame_latency": round(latency_ms, 4),
-            "ms_per_frame_to_host": round(to_host_ms, 4),
+            "value_device_only": round(total_rays / elapsed_device / 1e6, 2),
+            "ms_per_step_device_only": round(elapsed_device / args.steps * 1e3, 4),
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
-            mrays, threads, picks, rays, seconds = cpu_baseline(scene, frame, args.cpu_bands)
-            out["cpu_baseline"] = {"value": round(mrays, 3), "unit": "Mrays/s", "cores": threads, "kind": "port",
-                                   "sample": "row bands %s of %d of the same frame (%d rays, %.1f s wall), one worker "
-                                             "thread per band, oracle/ct_oracle.c" %
-                                             (picks, frame.num_threads, rays, seconds),
-                                   "host_cores": os.cpu_count()}
+            last = slots[(args.steps - 1) % inflight]["host_fb"].numpy().view(np.uint32).reshape(frame.height, frame.width)
+            out["cpu_baseline"], out["parity"] = cpu_baseline(ca, scene, frame, last, args.cpu_seconds)
+            out["speedup_vs_cpu_ms_per_frame"] = round(out["cpu_baseline"]["ms_per_frame"] / ms_per_step, 1)
         print(json.dumps(out), flush=True)
-    for r in renderers:
-        r.close()
+    for s in slots:
+        s["ctx"].close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -84,6 +84,7 @@ struct ctgpu_ctx {
     DeviceArray<int32_t> rand_table;   // LIBC jitter stream
     DeviceArray<int32_t> row_ordinal;
     uint64_t rand_key[4] = {~0ull, ~0ull, ~0ull, ~0ull};   // (seed, offset, count, rows) of the cached table
+    std::vector<int32_t> rand_host, ordinal_host;          // host copies the asynchronous uploads read from
 
     // wavefront pipeline (ct_pipeline.hip)
     DeviceArray<float2> coords;
@@ -509,8 +510,11 @@ void traced_row_ordinals(const ctgpu_frame_desc *f, const Geometry &g, std::vect
     }
 }
 
+// `stream`: the stream the frame's kernels will run on -- the LIBC jitter table is uploaded in that stream's
+// order (a frame still running there may be reading the previous table).  One context serves one frame at a
+// time; frames in flight on different streams use a context each.
 int fill_params(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, const ctgpu_partition *part, bool count_mode,
-                FrameParams &P) {
+                FrameParams &P, hipStream_t stream) {
     const Geometry g = geometry(f);
     std::memset(&P, 0, sizeof P);
     P.nodes = ctx->nodes.ptr; P.quads = ctx->quads.ptr; P.quad_source = ctx->quad_source.ptr; P.quad_root = ctx->quad_root;
@@ -546,13 +550,16 @@ int fill_params(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, const ctgpu_partition
         const uint64_t n = (uint64_t)g.square * n_rows * 32u;
         const uint64_t key[4] = {f->rng_seed, f->rng_offset, n, ((uint64_t)n_rows << 32) | g.rendered_rows | ((uint64_t)P.subsample << 63)};
         if (std::memcmp(key, ctx->rand_key, sizeof key) != 0) {
-            std::vector<int32_t> table(std::max<uint64_t>(n, 1));
-            int rc = ctgpu_rand_stream((uint32_t)f->rng_seed, f->rng_offset, n, table.data());
+            // the staging copies live in the context until the next table replaces them
+            HIP_TRY(hipStreamSynchronize(stream));          // nobody may still be reading the old table (or a buffer resize frees)
+            ctx->rand_host.assign(std::max<uint64_t>(n, 1), 0);
+            int rc = ctgpu_rand_stream((uint32_t)f->rng_seed, f->rng_offset, n, ctx->rand_host.data());
             if (rc) return rc;
-            HIP_TRY(ctx->rand_table.resize(table.size()));
-            HIP_TRY(ctx->row_ordinal.resize(ordinal.size()));
-            HIP_TRY(hipMemcpy(ctx->rand_table.ptr, table.data(), table.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(ctx->row_ordinal.ptr, ordinal.data(), ordinal.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            ctx->ordinal_host = ordinal;
+            HIP_TRY(ctx->rand_table.resize(ctx->rand_host.size()));
+            HIP_TRY(ctx->row_ordinal.resize(ctx->ordinal_host.size()));
+            HIP_TRY(hipMemcpyAsync(ctx->rand_table.ptr, ctx->rand_host.data(), ctx->rand_host.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+            HIP_TRY(hipMemcpyAsync(ctx->row_ordinal.ptr, ctx->ordinal_host.data(), ctx->ordinal_host.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
             std::memcpy(ctx->rand_key, key, sizeof key);
         }
         P.rand_table = ctx->rand_table.ptr;
@@ -702,7 +709,7 @@ extern "C" int ctgpu_render_partition(ctgpu_ctx *ctx, const ctgpu_frame_desc *fr
     rc = check_partition(part); if (rc) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
     FrameParams P;
-    rc = fill_params(ctx, frame, part, false, P); if (rc) return rc;
+    rc = fill_params(ctx, frame, part, false, P, (hipStream_t)stream); if (rc) return rc;
     P.out = (uint32_t *)d_tiles;
     return launch_frame(ctx, frame, P, (hipStream_t)stream);
 }
@@ -716,7 +723,7 @@ extern "C" int ctgpu_assemble(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, con
     FrameParams P;
     ctgpu_frame_desc plain = *frame;
     plain.flags &= ~CTGPU_F_SUPERSAMPLE;            // the jitter table is not needed here
-    rc = fill_params(ctx, &plain, part, false, P); if (rc) return rc;
+    rc = fill_params(ctx, &plain, part, false, P, (hipStream_t)stream); if (rc) return rc;
     launch_assemble(P, (const uint32_t *)d_all_tiles, (uint32_t *)d_fb, (hipStream_t)stream);
     HIP_TRY(hipGetLastError());
     return CTGPU_OK;
@@ -742,7 +749,7 @@ extern "C" int ctgpu_render(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, uint3
     const ctgpu_partition whole = {8, 0, 1};
     const Geometry g = geometry(frame);
     FrameParams P;
-    rc = fill_params(ctx, frame, &whole, false, P); if (rc) return rc;
+    rc = fill_params(ctx, frame, &whole, false, P, ctx->stream); if (rc) return rc;
     HIP_TRY(ctx->tiles.resize((size_t)P.local_rows * P.square));
     HIP_TRY(ctx->fb.resize((size_t)frame->width * frame->height));
     P.out = ctx->tiles.ptr;
@@ -828,7 +835,7 @@ extern "C" int ctgpu_render_multi(ctgpu_ctx *const *ctxs, int n_ctx, const ctgpu
         HIP_TRY(hipSetDevice(c->device));
         const ctgpu_partition part = {8, i, n_ctx};
         FrameParams P;
-        rc = fill_params(c, frame, &part, false, P); if (rc) return rc;
+        rc = fill_params(c, frame, &part, false, P, c->stream); if (rc) return rc;
         HIP_TRY(c->tiles.resize(per_part));
         P.out = c->tiles.ptr;
         if (i == 0) HIP_TRY(hipEventRecord(root->ev0, root->stream));
@@ -853,7 +860,7 @@ extern "C" int ctgpu_render_multi(ctgpu_ctx *const *ctxs, int n_ctx, const ctgpu
     // assemble on the root device and copy back the rectangle the reference writes
     HIP_TRY(hipSetDevice(root->device));
     FrameParams P0;
-    rc = fill_params(root, frame, &part0, false, P0); if (rc) return rc;
+    rc = fill_params(root, frame, &part0, false, P0, root->stream); if (rc) return rc;
     launch_assemble(P0, root->gathered.ptr, root->fb.ptr, root->stream);
     HIP_TRY(hipGetLastError());
     const int row_hi = frame->height / 2 + g.half, row_lo = row_hi - (int)g.rendered_rows + 1;
@@ -897,7 +904,7 @@ extern "C" int ctgpu_count_work(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, c
     HIP_TRY(hipSetDevice(ctx->device));
     const ctgpu_partition whole = {8, 0, 1};
     FrameParams P;
-    rc = fill_params(ctx, frame, &whole, true, P); if (rc) return rc;
+    rc = fill_params(ctx, frame, &whole, true, P, ctx->stream); if (rc) return rc;
     HIP_TRY(ctx->tiles.resize((size_t)P.local_rows * P.square));
     P.out = ctx->tiles.ptr;
     HIP_TRY(hipMemsetAsync(ctx->counters.ptr, 0, kCounterWords * sizeof(unsigned long long), ctx->stream));
@@ -928,7 +935,7 @@ extern "C" int ctgpu_trace_rays(ctgpu_ctx *ctx, const ctgpu_ray *rays, uint64_t 
     f.cam_rot[0] = f.cam_rot[4] = f.cam_rot[8] = 1.0;
     const ctgpu_partition whole = {8, 0, 1};
     FrameParams P;
-    int rc = fill_params(ctx, &f, &whole, false, P); if (rc) return rc;
+    int rc = fill_params(ctx, &f, &whole, false, P, ctx->stream); if (rc) return rc;
     ctgpu_ray *d_rays = nullptr;
     ctgpu_hit *d_hits = nullptr;
     HIP_TRY(hipMalloc((void **)&d_rays, n * sizeof(ctgpu_ray)));
@@ -963,7 +970,7 @@ extern "C" int ctgpu_trace_rays_packet(ctgpu_ctx *ctx, const ctgpu_ray *rays, ui
     f.cam_rot[0] = f.cam_rot[4] = f.cam_rot[8] = 1.0;
     const ctgpu_partition whole = {8, 0, 1};
     FrameParams P;
-    int rc = fill_params(ctx, &f, &whole, false, P); if (rc) return rc;
+    int rc = fill_params(ctx, &f, &whole, false, P, ctx->stream); if (rc) return rc;
     PipelineParams W;
     rc = fill_pipeline(ctx, n, W); if (rc) return rc;
     W.packet = 1;

@@ -40,8 +40,8 @@ inline float component_f32(const v3_t &v, int axis) { return (float)component(v,
 inline double lesser(double a, double b) { return (a < b) ? a : b; }     // mymath.h:15-17
 inline double greater(double a, double b) { return (a > b) ? a : b; }    // mymath.h:11-13
 
-void fit_bounds(bvh_state_t *s, uint32_t node_id) {
-    bvh_node_t &node = s->bvhNodes[node_id];
+// a node's box from its triangles' corners, MinV3 / MaxV3 from +-1e30f (bvh.cpp:30-49)
+void fit_bounds_of(const bvh_state_t *s, bvh_node_t &node) {
     const double big = (double)1e30f;
     v3_t lo{big, big, big}, hi{-big, -big, -big};
     for (uint32_t k = 0; k < node.triangleCount; k++) {
@@ -57,6 +57,8 @@ void fit_bounds(bvh_state_t *s, uint32_t node_id) {
     node.aabbMin = lo;
     node.aabbMax = hi;
 }
+
+void fit_bounds(bvh_state_t *s, uint32_t node_id) { fit_bounds_of(s, s->bvhNodes[node_id]); }
 
 // Partitions the node's triangles about its split plane; returns false when the node stays a leaf,
 // else the sizes / first indices of the two children.
@@ -84,23 +86,6 @@ bool partition(bvh_state_t *s, const bvh_node_t &node, uint32_t &left_count, uin
     left_count = (uint32_t)(i - (int)node.firstTriangleIndex);
     right_first = (uint32_t)i;
     return !(left_count == 0 || left_count == node.triangleCount);
-}
-
-void fit_bounds_of(const bvh_state_t *s, bvh_node_t &node) {
-    const double big = (double)1e30f;
-    v3_t lo{big, big, big}, hi{-big, -big, -big};
-    for (uint32_t k = 0; k < node.triangleCount; k++) {
-        const triangle_t &t = s->triangles.data[s->triangles.indexes[node.firstTriangleIndex + k]];
-        const v3_t *corners[3] = {&t.p1, &t.p2, &t.p3};
-        for (const v3_t *p : corners) {
-            lo.x = lesser(lo.x, p->x); lo.y = lesser(lo.y, p->y); lo.z = lesser(lo.z, p->z);
-        }
-        for (const v3_t *p : corners) {
-            hi.x = greater(hi.x, p->x); hi.y = greater(hi.y, p->y); hi.z = greater(hi.z, p->z);
-        }
-    }
-    node.aabbMin = lo;
-    node.aabbMax = hi;
 }
 
 // the reference's recursion, in place (bvh.cpp:51-106)
