@@ -10,9 +10,13 @@
 #include "host_internal.h"
 #include "text_cursor.h"
 
+#include <atomic>
+#include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -95,6 +99,115 @@ std::string resolve(const scene_object_t &record) {
     return name;
 }
 
+// ---- the body of a large PLY file on several threads -------------------------------------------
+// The reference reads the body record by record through one cursor: three numbers, rest of the line
+// skipped (objectLoader.cpp:160-191).  When every record's numbers stand on a line of their own -- any
+// file a mesh tool writes -- record i is simply the i-th non-blank line, and the lines can be parsed
+// independently with the same TextCursor::number().  This function finds the line starts (threads over
+// byte ranges), parses vertices and then faces (threads over line ranges), and CHECKS the assumption on
+// every record: a number that ran past its line's end, a record count that does not match, a face the
+// serial code would reject -- and it gives up (returns false, nothing written) so that the serial code
+// below does whatever the reference does with such a file.
+unsigned loader_threads() {
+    if (const char *t = std::getenv("CT_LOAD_THREADS")) return (unsigned)std::max(1, std::atoi(t));
+    const unsigned hw = std::thread::hardware_concurrency();
+    return std::min(hw ? hw : 1u, 16u);
+}
+
+template <typename Fn>
+void run_threads(unsigned n, Fn fn) {
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < n; t++) pool.emplace_back(fn, t);
+    fn(0u);
+    for (std::thread &th : pool) th.join();
+}
+
+bool import_ply_body_parallel(const TextCursor &tc, const scene_object_t &record, const Placement &place, scene_t *scene,
+                              uint32_t n_vertices, uint32_t n_faces) {
+    const size_t n_records = (size_t)n_vertices + n_faces;
+    const unsigned n_threads = loader_threads();
+    if (n_threads < 2 || n_records < 20000) return false;
+    if ((size_t)scene->objectStack.index + n_faces > (size_t)scene->objectStack.size) return false;   // serial code reports it
+    const char *bytes = tc.bytes();
+    const size_t body = tc.position(), size = tc.size();
+    if (body >= size) return false;
+    const bool timing = std::getenv("CT_LOAD_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    const auto t0 = now();
+
+    // 1. record starts: a non-space byte whose preceding white space holds a line break (the first one is `body`)
+    std::vector<std::vector<size_t>> found(n_threads);
+    run_threads(n_threads, [&](unsigned t) {
+        const size_t lo = body + (size - body) * t / n_threads, hi = body + (size - body) * (t + 1) / n_threads;
+        std::vector<size_t> &out = found[t];
+        out.reserve((hi - lo) / 16 + 16);
+        for (size_t p = lo; p < hi; p++) {
+            if (TextCursor::is_space(bytes[p])) continue;
+            if (p == body) { out.push_back(p); continue; }
+            if (!TextCursor::is_space(bytes[p - 1])) continue;
+            for (size_t q = p; q > body && TextCursor::is_space(bytes[q - 1]); q--)
+                if (bytes[q - 1] == '\n' || bytes[q - 1] == '\r') { out.push_back(p); break; }
+        }
+    });
+    std::vector<size_t> starts;
+    starts.reserve(n_records + 1);
+    for (const std::vector<size_t> &part : found) starts.insert(starts.end(), part.begin(), part.end());
+    if (starts.size() < n_records) return false;          // the file ends early: the serial code's business
+    auto line_end = [&](size_t from) {
+        while (from < size && bytes[from] != '\n' && bytes[from] != '\r') from++;
+        return from;
+    };
+
+    const auto t1 = now();
+    // 2. vertices, then 3. faces straight into their object slots
+    std::atomic<bool> clean{true};
+    std::vector<v3_t> vertices(n_vertices);
+    run_threads(n_threads, [&](unsigned t) {
+        const size_t lo = (size_t)n_vertices * t / n_threads, hi = (size_t)n_vertices * (t + 1) / n_threads;
+        for (size_t i = lo; i < hi && clean.load(std::memory_order_relaxed); i++) {
+            TextCursor line(tc, starts[i]);
+            double v[3];
+            line.vec3_bare(v);
+            if (line.position() > line_end(starts[i])) { clean = false; break; }
+            vertices[i] = v3_t{v[0], v[1], v[2]};
+        }
+    });
+    if (!clean) return false;
+    const auto t2 = now();
+    scene_object_t *slots = scene->objectStack.objects + scene->objectStack.index;
+    run_threads(n_threads, [&](unsigned t) {
+        const size_t lo = (size_t)n_faces * t / n_threads, hi = (size_t)n_faces * (t + 1) / n_threads;
+        for (size_t i = lo; i < hi && clean.load(std::memory_order_relaxed); i++) {
+            TextCursor line(tc, starts[n_vertices + i]);
+            const int corners = (int)line.number();
+            double f[3];
+            line.vec3_bare(f);
+            const int ia = (int)f[0], ib = (int)f[1], ic = (int)f[2];
+            if (line.position() > line_end(starts[n_vertices + i]) || corners != 3 || ia < 0 || ib < 0 || ic < 0 ||
+                (uint32_t)ia >= n_vertices || (uint32_t)ib >= n_vertices || (uint32_t)ic >= n_vertices) {
+                clean = false;
+                break;
+            }
+            scene_object_t obj = record;      // as emit_triangle: the record's material, a triangle in the union
+            obj.type = OT_TRIANGLE;
+            obj.triangle.p1 = place.apply(vertices[ia]);
+            obj.triangle.p2 = place.apply(vertices[ib]);
+            obj.triangle.p3 = place.apply(vertices[ic]);
+            std::memcpy(&slots[i], &obj, sizeof obj);
+        }
+    });
+    if (!clean) return false;                              // (slots beyond objectStack.index are not part of the scene)
+    scene->objectStack.index += (int)n_faces;
+    scene->triangleLookup.triangleCount += (int)n_faces;
+    if (timing)
+        std::fprintf(stderr, "ply body on %u threads: line index %.1f ms, %u vertices %.1f ms, %u faces %.1f ms\n", n_threads,
+                     ms(t0, t1), n_vertices, ms(t1, t2), n_faces, ms(t2, now()));
+    return true;
+}
+
 // objectLoader.cpp:142-202 -- ASCII PLY: "element vertex N", "element face M",
 // first three numbers of each vertex line, "3 i j k" face lines.
 void import_ply(const scene_object_t &record, scene_t *scene) {
@@ -115,6 +228,9 @@ void import_ply(const scene_object_t &record, scene_t *scene) {
         }
     }
 
+    const Placement place(record.import.position, record.import.rotation, record.import.scale);
+    if (import_ply_body_parallel(tc, record, place, scene, n_vertices, n_faces)) return;
+
     std::vector<v3_t> vertices(n_vertices);
     for (uint32_t i = 0; i < n_vertices && !tc.at_end(); i++) {
         double v[3];
@@ -123,7 +239,6 @@ void import_ply(const scene_object_t &record, scene_t *scene) {
         tc.skip_line();
     }
 
-    const Placement place(record.import.position, record.import.rotation, record.import.scale);
     for (uint32_t i = 0; i < n_faces && !tc.at_end(); i++) {
         const int corners = (int)tc.number();
         if (corners != 3) tc.fatal("only triangular faces are supported");

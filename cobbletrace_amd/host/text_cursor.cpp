@@ -9,7 +9,8 @@ namespace ct {
 
 static const size_t kRefWindow = 4096;   // FB_BUFFER_SZ, fileBuffer.h:9
 
-TextCursor::TextCursor(const std::string &path) : path_(path) {
+TextCursor::TextCursor(const std::string &path) : path_(path), data_(std::make_shared<std::vector<char>>()) {
+    std::vector<char> &data_ = *this->data_;
     FILE *f = std::fopen(path.c_str(), "rb");
     if (!f) return;
     std::fseek(f, 0, SEEK_END);
@@ -29,6 +30,7 @@ void TextCursor::fatal(const std::string &what) const {
 }
 
 char TextCursor::peek() const {
+    const std::vector<char> &data_ = *this->data_;
     const size_t n = data_.size();
     if (pos_ < n) return data_[pos_];
     // One position past the end is still "not EOF" in the reference; its window

@@ -14,6 +14,7 @@
 #define CT_TEXT_CURSOR_H
 
 #include <cstddef>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -24,9 +25,17 @@ public:
     // Loads the whole file; on failure ok() is false.
     explicit TextCursor(const std::string &path);
 
+    // A second cursor over the SAME bytes (shared, not copied), starting at `position`: what the parallel
+    // mesh import gives each worker.
+    TextCursor(const TextCursor &whole, size_t position) : path_(whole.path_), data_(whole.data_), pos_(position), ok_(whole.ok_) {}
+
     bool ok() const { return ok_; }
+    size_t position() const { return pos_; }
+    size_t size() const { return data_->size(); }
+    const char *bytes() const { return data_->data(); }
+    static bool is_space(char c) { return c == '\n' || c == '\r' || c == ' ' || c == '\t'; }
     const std::string &path() const { return path_; }
-    bool at_end() const { return pos_ > data_.size(); }
+    bool at_end() const { return pos_ > data_->size(); }
 
     void skip_space();
     void skip_line();                    // to end of line, then over white space
@@ -45,10 +54,9 @@ public:
 private:
     char peek() const;
     void advance() { ++pos_; }
-    static bool is_space(char c) { return c == '\n' || c == '\r' || c == ' ' || c == '\t'; }
 
     std::string path_;
-    std::vector<char> data_;
+    std::shared_ptr<std::vector<char>> data_;
     size_t pos_ = 0;
     bool ok_ = false;
 };

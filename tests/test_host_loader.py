@@ -199,3 +199,58 @@ def test_shipped_scenes_load(scenes):
         s = scenes(name)
         assert s.desc.n_triangles == tris and s.desc.n_lights == 3
         assert s.settings["supersampling"] is True and s.settings["subsampling"] is False
+
+
+def _grid_ply(n, split_record=None, blank_lines=False):
+    """An ASCII PLY of an n x n vertex grid (2 (n-1)^2 faces), extra properties after the coordinates.
+    split_record: a (kind, index) whose numbers are broken over two lines -- legal for the reference's
+    record-by-record reader, not line-shaped."""
+    rng = np.random.default_rng(n)
+    xyz = np.c_[np.repeat(np.arange(n), n) / n, np.tile(np.arange(n), n) / n, rng.random(n * n) * 0.1]
+    lines = ["ply", "format ascii 1.0", "element vertex %d" % (n * n), "property float x", "property float y",
+             "property float z", "property float confidence", "element face %d" % (2 * (n - 1) ** 2),
+             "property list uchar int vertex_indices", "end_header"]
+    for i, (x, y, z) in enumerate(xyz):
+        text = "%.6g %.6g %.6g 0.5" % (x, y, z)
+        if split_record == ("vertex", i):
+            text = text.replace(" ", "\n", 1)
+        lines.append(text)
+        if blank_lines and i % 97 == 0:
+            lines.append("   ")
+    k = 0
+    for r in range(n - 1):
+        for c in range(n - 1):
+            a = r * n + c
+            for face in ((a, a + 1, a + n + 1), (a, a + n + 1, a + n)):
+                text = "3 %d %d %d" % face
+                if split_record == ("face", k):
+                    text = text.replace(" ", "\r\n", 2)
+                lines.append(text)
+                k += 1
+    return "\n".join(lines) + "\n"
+
+
+@pytest.mark.parametrize("shape", ["plain", "blank lines", "split vertex", "split face"])
+def test_parallel_ply_import_equals_the_serial_reader(shape, tmp_path, monkeypatch):
+    """Large PLY bodies are parsed on several threads, record = line (mesh_import.cpp).  Same triangles, bit for
+    bit, as the record-by-record reader (CT_LOAD_THREADS=1, the reference's way, objectLoader.cpp:160-191) --
+    also for files whose records are NOT line-shaped, where the parallel path must notice and stand aside."""
+    (tmp_path / "models").mkdir()
+    n = 120                                            # 14,400 vertices + 28,322 faces: above the parallel threshold
+    split = {"split vertex": ("vertex", 5000), "split face": ("face", 20001)}.get(shape)
+    (tmp_path / "models" / "grid.ply").write_text(_grid_ply(n, split, blank_lines=(shape == "blank lines")))
+    obj = {"type": "import", "format": "ply", "filename": "models/grid.ply", "position": [0.1, 0.2, 3.0],
+           "rotation": [0.3, 0.2, 0.1], "scale": [2.0, 2.0, 2.0], "color": [200, 100, 50], "specular": 10, "reflection": 0}
+    path = write_scene(tmp_path, [obj])
+    monkeypatch.setenv("CT_LOAD_THREADS", "1")
+    serial = ca.HostScene(path)
+    want = serial.vertices().copy()
+    assert serial.desc.n_triangles == 2 * (n - 1) ** 2
+    for threads in ("2", "5"):
+        monkeypatch.setenv("CT_LOAD_THREADS", threads)
+        parallel = ca.HostScene(path)
+        assert parallel.desc.n_triangles == serial.desc.n_triangles
+        assert (parallel.vertices().view(np.uint64) == want.view(np.uint64)).all()
+        assert parallel.lib.cth_node_hash(parallel.handle) == serial.lib.cth_node_hash(serial.handle)
+        parallel.close()
+    serial.close()
