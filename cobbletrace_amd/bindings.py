@@ -103,6 +103,8 @@ _GPU_SYMBOLS = {
     "ctgpu_destroy": (None, [C.c_void_p]),
     "ctgpu_upload_scene": (C.c_int, [C.c_void_p, C.POINTER(SceneDesc)]),
     "ctgpu_render": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.c_void_p, C.POINTER(Stats)]),
+    "ctgpu_render_begin": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.c_void_p]),
+    "ctgpu_render_poll": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(Stats)]),
     "ctgpu_render_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(FrameDesc), C.c_void_p, C.POINTER(Stats)]),
     "ctgpu_partition_pixels": (C.c_int, [C.POINTER(FrameDesc), C.POINTER(Partition), C.POINTER(C.c_uint64)]),
     "ctgpu_render_partition": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.POINTER(Partition), C.c_void_p, C.c_void_p]),
@@ -140,6 +142,11 @@ _HOST_SYMBOLS = {
     "cth_index_hash": (C.c_uint64, [C.c_void_p]),
     "cth_fnv1a64": (C.c_uint64, [C.c_void_p, C.c_uint64]),
     "cth_assemble_tiles": (C.c_int, [C.POINTER(FrameDesc), C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "cth_raythread_options_async": (None, [C.c_int, C.c_uint64, C.c_int, C.c_int]),
+    "cth_app_loop": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]),
+    "cth_blit_count": (C.c_uint64, []),
+    "cth_frames_finished": (C.c_uint64, []),
+    "cth_blit": (None, [C.c_void_p, C.c_int, C.c_int]),
     "cth_raythread_options": (None, [C.c_int, C.c_uint64, C.c_int, C.c_int]),
     "cth_raythread_reset": (None, []),
     "cth_raythread_frames": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_char_p]),
@@ -306,6 +313,19 @@ class GpuContext:
         contexts[0]._check(contexts[0].lib.ctgpu_render_multi(handles, len(contexts), C.byref(frame), fb.ctypes.data,
                                                               C.byref(st)))
         return fb, st
+
+    def render_begin(self, frame, fb=None):
+        """Queue a whole frame into fb (allocated if omitted) and return at once; see render_poll."""
+        if fb is None:
+            fb = np.zeros((frame.height, frame.width), dtype=np.uint32)
+        self._check(self.lib.ctgpu_render_begin(self.handle, C.byref(frame), fb.ctypes.data))
+        return fb
+
+    def render_poll(self, wait=False):
+        """(done, stats) of the frame in flight."""
+        done, st = C.c_int(0), Stats()
+        self._check(self.lib.ctgpu_render_poll(self.handle, 1 if wait else 0, C.byref(done), C.byref(st)))
+        return bool(done.value), st
 
     def count_work(self, frame):
         st = Stats()

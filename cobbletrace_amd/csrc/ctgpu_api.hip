@@ -113,8 +113,16 @@ struct ctgpu_ctx {
     std::vector<void *> multi_comms;            // ctgpu_render_multi: one communicator per device, kept by the root context
     std::vector<int> multi_devices;
 
+    struct Pending {                            // ctgpu_render_begin .. ctgpu_render_poll
+        bool active = false;
+        std::chrono::steady_clock::time_point t0;
+        uint64_t pixels = 0;
+    } pending;
+    uint32_t *pinned_fb = nullptr;              // the caller's framebuffer, page-locked for the asynchronous copy
+    size_t pinned_bytes = 0;
+
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr;
     int thresh[3] = {40, 20, 12};
 };
 
@@ -187,6 +195,7 @@ static int create_resources(ctgpu_ctx *ctx) {
     HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
     HIP_TRY(hipEventCreate(&ctx->ev0));
     HIP_TRY(hipEventCreate(&ctx->ev1));
+    HIP_TRY(hipEventCreate(&ctx->ev_done));
     HIP_TRY(ctx->counters.resize(kCounterWords));
     HIP_TRY(ctx->overflow.resize(1));
     HIP_TRY(hipMemset(ctx->counters.ptr, 0, kCounterWords * sizeof(unsigned long long)));
@@ -241,6 +250,8 @@ extern "C" void ctgpu_destroy(ctgpu_ctx *ctx) {
     for (hipEvent_t e : ctx->marks) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
+    if (ctx->pinned_fb) (void)hipHostUnregister(ctx->pinned_fb);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -739,12 +750,18 @@ extern "C" int ctgpu_read_counters(ctgpu_ctx *ctx, ctgpu_stats *stats) {
 }
 
 // ------------------------------------------------------------------ whole frame on one GPU
-extern "C" int ctgpu_render(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, uint32_t *host_fb, ctgpu_stats *stats) {
+// begin: queue the whole frame -- trace, assemble, copy of the written rectangle into the caller's framebuffer -- on
+// the context's stream and return; poll: has it finished (or wait for it), then the counters.  ctgpu_render is the
+// two back to back.  The reference's RayThread is non-blocking the same way: it dispatches its workers and looks
+// at their status on later calls (raythread.cpp:546-593).
+namespace {
+int begin_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, uint32_t *host_fb, bool pin) {
     if (!ctx || !host_fb) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_render: null argument");
     if (!ctx->has_scene) return ctgpu_fail(CTGPU_ERR_NO_SCENE, "no scene uploaded");
+    if (ctx->pending.active) return ctgpu_fail(CTGPU_ERR_ARG, "a frame is already in flight on this context (ctgpu_render_poll)");
     int rc = check_frame(frame); if (rc) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
-    const auto t0 = std::chrono::steady_clock::now();
+    ctx->pending.t0 = std::chrono::steady_clock::now();
 
     const ctgpu_partition whole = {8, 0, 1};
     const Geometry g = geometry(frame);
@@ -753,6 +770,16 @@ extern "C" int ctgpu_render(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, uint3
     HIP_TRY(ctx->tiles.resize((size_t)P.local_rows * P.square));
     HIP_TRY(ctx->fb.resize((size_t)frame->width * frame->height));
     P.out = ctx->tiles.ptr;
+
+    // an asynchronous copy needs page-locked memory: the caller's framebuffer is registered once and stays so
+    const size_t fb_bytes = (size_t)frame->width * frame->height * sizeof(uint32_t);
+    if (pin && (ctx->pinned_fb != host_fb || ctx->pinned_bytes != fb_bytes)) {
+        if (ctx->pinned_fb) (void)hipHostUnregister(ctx->pinned_fb);
+        ctx->pinned_fb = nullptr;
+        HIP_TRY(hipHostRegister(host_fb, fb_bytes, hipHostRegisterDefault));
+        ctx->pinned_fb = host_fb;
+        ctx->pinned_bytes = fb_bytes;
+    }
 
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
     rc = launch_frame(ctx, frame, P, ctx->stream); if (rc) return rc;
@@ -771,20 +798,51 @@ extern "C" int ctgpu_render(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, uint3
         HIP_TRY(hipMemcpy2DAsync(host_fb + off, (size_t)frame->width * 4, ctx->fb.ptr + off, (size_t)frame->width * 4,
                                  (size_t)(c1 - c0 + 1) * 4, (size_t)(r1 - r0 + 1), hipMemcpyDeviceToHost, ctx->stream));
     }
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    const auto t1 = std::chrono::steady_clock::now();
+    HIP_TRY(hipEventRecord(ctx->ev_done, ctx->stream));
+    ctx->pending.pixels = (r1 >= r0 && c1 >= c0) ? (uint64_t)(r1 - r0 + 1) * (uint64_t)(c1 - c0 + 1) : 0;
+    ctx->pending.active = true;
+    return CTGPU_OK;
+}
 
+int finish_frame(ctgpu_ctx *ctx, bool wait, int *done, ctgpu_stats *stats) {
+    if (!ctx->pending.active) return ctgpu_fail(CTGPU_ERR_ARG, "no frame is in flight on this context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (wait) {
+        HIP_TRY(hipEventSynchronize(ctx->ev_done));
+    } else {
+        const hipError_t q = hipEventQuery(ctx->ev_done);
+        if (q == hipErrorNotReady) { if (done) *done = 0; return CTGPU_OK; }
+        if (q != hipSuccess) return ctgpu_fail(CTGPU_ERR_HIP, "hipEventQuery: %s", hipGetErrorString(q));
+    }
+    const auto t1 = std::chrono::steady_clock::now();
+    ctx->pending.active = false;
+    if (done) *done = 1;
     ctgpu_stats st;
     std::memset(&st, 0, sizeof st);
-    rc = read_counters(ctx, &st); if (rc) return rc;
+    int rc = read_counters(ctx, &st); if (rc) return rc;
     rc = check_overflow(ctx); if (rc) return rc;
     float ms = 0.0f;
     HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
     st.kernel_ms = ms;
-    st.total_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
-    st.pixels_written = (r1 >= r0 && c1 >= c0) ? (uint64_t)(r1 - r0 + 1) * (uint64_t)(c1 - c0 + 1) : 0;
+    st.total_ms = std::chrono::duration<double, std::milli>(t1 - ctx->pending.t0).count();
+    st.pixels_written = ctx->pending.pixels;
     if (stats) *stats = st;
     return CTGPU_OK;
+}
+}  // namespace
+
+extern "C" int ctgpu_render(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, uint32_t *host_fb, ctgpu_stats *stats) {
+    int rc = begin_frame(ctx, frame, host_fb, false); if (rc) return rc;
+    return finish_frame(ctx, true, nullptr, stats);
+}
+
+extern "C" int ctgpu_render_begin(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, uint32_t *host_fb) {
+    return begin_frame(ctx, frame, host_fb, true);
+}
+
+extern "C" int ctgpu_render_poll(ctgpu_ctx *ctx, int wait, int *done, ctgpu_stats *stats) {
+    if (!ctx) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_render_poll: null argument");
+    return finish_frame(ctx, wait != 0, done, stats);
 }
 
 // ------------------------------------------------------------------ whole frame on several GPUs, one process

@@ -126,8 +126,52 @@ uint64_t cth_index_hash(void *p) {
 
 // ---- RayThread driven from the harness: the caller's buffer becomes env->bitmap->memory
 void cth_raythread_options(int rng_mode, uint64_t seed, int device, int n_devices) {
-    const ct_raythread_options o{rng_mode, seed, device, n_devices};
+    const ct_raythread_options o{rng_mode, seed, device, n_devices, 0};
     RayThreadSetOptions(&o);
+}
+
+void cth_raythread_options_async(int rng_mode, uint64_t seed, int device, int async) {
+    const ct_raythread_options o{rng_mode, seed, device, 1, async};
+    RayThreadSetOptions(&o);
+}
+
+// The application loop of cobbletrace.cpp:90-120 without the window: per iteration deliver at most one key,
+// call RayThread, show the bitmap to Blit, until every key has been delivered and no frame is in flight.
+// Returns the number of iterations; *polls = iterations in which RayThread found its frame still in flight.
+int cth_app_loop(void *p, int width, int height, uint32_t *fb, const char *keys, int *polls) {
+    Handle *h = H(p);
+    h->bitmap = bitmapSettings_t{fb, width, height, nullptr};
+    h->events.assign(64, event_t{});
+    std::memset(&h->env, 0, sizeof h->env);
+    h->env.bitmap = &h->bitmap;
+    h->env.clientWidth = width * 2;
+    h->env.clientHeight = height * 2;
+    h->env.events.queue = h->events.data();
+    h->env.events.capacity = (uint32_t)h->events.size();
+    int iterations = 0, waiting = 0;
+    const char *k = keys;
+    for (;;) {
+        const bool was_busy = RayThreadBusy();
+        if (!was_busy && iterations > 0 && k && *k) AddEvent(&h->env.events, event_t{ET_KEY_DOWN, EM_NONE, v2_t{0, 0}, (uint32_t)(unsigned char)*k++});
+        RayThread(&h->env, &h->scene);
+        Blit(&h->env);
+        iterations++;
+        if (was_busy && RayThreadBusy()) waiting++;
+        if (!RayThreadBusy() && !(k && *k) && iterations > 1) break;
+        if (iterations > 100000000) break;
+    }
+    if (polls) *polls = waiting;
+    return iterations;
+}
+
+uint64_t cth_blit_count(void) { return BlitFrameCount(); }
+uint64_t cth_frames_finished(void) { return RayThreadFramesFinished(); }
+
+void cth_blit(uint32_t *fb, int width, int height) {
+    bitmapSettings_t bitmap{fb, width, height, nullptr};
+    environment_t env{};
+    env.bitmap = &bitmap;
+    Blit(&env);
 }
 
 void cth_raythread_reset(void) { RayThreadReset(); }

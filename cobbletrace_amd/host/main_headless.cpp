@@ -14,7 +14,7 @@
 static void usage() {
     std::fprintf(stderr,
                  "cobbletrace_headless scenefile [--width W] [--height H] [--out image.ppm]\n"
-                 "                     [--rng hash|libc] [--seed N] [--device N] [--gpus N] [--keys wasd...]\n\n"
+                 "                     [--rng hash|libc] [--seed N] [--device N] [--gpus N] [--keys wasd...] [--async]\n\n"
                  "To run cobbletrace provide a scene file.  See assets/scene_file_1.json for an example.\n");
     std::exit(0);
 }
@@ -23,7 +23,7 @@ int main(int argc, char **argv) {
     if (argc < 2) usage();
     int width = 640, height = 640;
     std::string out = "cobbletrace.ppm", keys;
-    ct_raythread_options opt{CTGPU_RNG_HASH, 0, 0, 1};
+    ct_raythread_options opt{CTGPU_RNG_HASH, 0, 0, 1, 0};
     for (int i = 2; i < argc; i++) {
         const std::string a = argv[i];
         auto need = [&](const char *name) -> const char * {
@@ -38,6 +38,7 @@ int main(int argc, char **argv) {
         else if (a == "--device") opt.device = std::atoi(need("--device"));
         else if (a == "--gpus") opt.n_devices = std::atoi(need("--gpus"));
         else if (a == "--keys") keys = need("--keys");
+        else if (a == "--async") opt.async = 1;
         else usage();
     }
 
@@ -61,11 +62,19 @@ int main(int argc, char **argv) {
     env.events.capacity = (uint32_t)ring.size();
 
     RayThreadSetOptions(&opt);
-    RayThread(&env, &scene);                                    // first frame
-    for (char k : keys) {                                       // one frame per key, like one SDL_KEYDOWN each
-        AddEvent(&env.events, event_t{ET_KEY_DOWN, EM_NONE, v2_t{0, 0}, (uint32_t)k});
+    // the main loop of cobbletrace.cpp:90-120: key-downs in, RayThread, Blit.  With --async RayThread only queues
+    // a frame and the loop keeps turning until it has arrived (no 33 ms sleep here: nobody is watching)
+    size_t next_key = 0;
+    unsigned long iterations = 0;
+    for (;;) {
+        if (iterations > 0 && !RayThreadBusy() && next_key < keys.size())     // one frame per key, like one SDL_KEYDOWN each
+            AddEvent(&env.events, event_t{ET_KEY_DOWN, EM_NONE, v2_t{0, 0}, (uint32_t)keys[next_key++]});
         RayThread(&env, &scene);
+        Blit(&env);
+        iterations++;
+        if (!RayThreadBusy() && next_key >= keys.size()) break;
     }
+    std::fprintf(stderr, "%lu loop iterations, %llu frames\n", iterations, (unsigned long long)RayThreadFramesFinished());
 
     FILE *f = std::fopen(out.c_str(), "wb");
     if (!f) { std::perror(out.c_str()); return 1; }

@@ -167,8 +167,9 @@ bool import_ply_body_parallel(const TextCursor &tc, const scene_object_t &record
     std::vector<v3_t> vertices(n_vertices);
     run_threads(n_threads, [&](unsigned t) {
         const size_t lo = (size_t)n_vertices * t / n_threads, hi = (size_t)n_vertices * (t + 1) / n_threads;
+        TextCursor line(tc, 0);                 // one view per worker (sharing the bytes), moved from record to record
         for (size_t i = lo; i < hi && clean.load(std::memory_order_relaxed); i++) {
-            TextCursor line(tc, starts[i]);
+            line.seek(starts[i]);
             double v[3];
             line.vec3_bare(v);
             if (line.position() > line_end(starts[i])) { clean = false; break; }
@@ -180,8 +181,9 @@ bool import_ply_body_parallel(const TextCursor &tc, const scene_object_t &record
     scene_object_t *slots = scene->objectStack.objects + scene->objectStack.index;
     run_threads(n_threads, [&](unsigned t) {
         const size_t lo = (size_t)n_faces * t / n_threads, hi = (size_t)n_faces * (t + 1) / n_threads;
+        TextCursor line(tc, 0);
         for (size_t i = lo; i < hi && clean.load(std::memory_order_relaxed); i++) {
-            TextCursor line(tc, starts[n_vertices + i]);
+            line.seek(starts[n_vertices + i]);
             const int corners = (int)line.number();
             double f[3];
             line.vec3_bare(f);

@@ -5,9 +5,12 @@
 // Kept from the reference's boss: lazy one-time set-up on the first call (triangle
 // gather + BVH build, raythread.cpp:647-654), keyboard camera control (:388-434), the
 // "re-render only when something changed" rule (:546-562), the yaw/pitch/roll matrix in
-// binary32 (:564-572), and always returning true.  Replaced: the worker pool and its
-// status polling -- a frame is one synchronous GPU dispatch, so a call that has work to
-// do returns with the pixels already in env->bitmap->memory.
+// binary32 (:564-572), and always returning true.  Replaced: the worker pool.  By default a
+// frame is one synchronous GPU dispatch, so a call that has work to do returns with the
+// pixels already in env->bitmap->memory; with ct_raythread_options.async the call only
+// QUEUES the frame (ctgpu_render_begin) and later calls look whether it has finished
+// (ctgpu_render_poll), the way the reference's boss looks at its workers' status
+// (raythread.cpp:557-562) -- the caller's loop (event pump, Blit, 33 ms sleep) never waits.
 #include "cobbletrace_host.h"
 #include "ctgpu.h"
 #include "scene_pack.h"
@@ -34,6 +37,8 @@ struct GpuApi {
     decltype(&ctgpu_upload_scene) upload_scene = nullptr;
     decltype(&ctgpu_render) render = nullptr;
     decltype(&ctgpu_render_multi) render_multi = nullptr;
+    decltype(&ctgpu_render_begin) render_begin = nullptr;
+    decltype(&ctgpu_render_poll) render_poll = nullptr;
     decltype(&ctgpu_device_count) device_count = nullptr;
 };
 
@@ -68,6 +73,8 @@ GpuApi &gpu() {
     RESOLVE(upload_scene, "ctgpu_upload_scene");
     RESOLVE(render, "ctgpu_render");
     RESOLVE(render_multi, "ctgpu_render_multi");
+    RESOLVE(render_begin, "ctgpu_render_begin");
+    RESOLVE(render_poll, "ctgpu_render_poll");
     RESOLVE(device_count, "ctgpu_device_count");
 #undef RESOLVE
     if (api.abi_version() != CTGPU_ABI_VERSION) die("libctgpu.so ABI mismatch", path.c_str());
@@ -81,8 +88,10 @@ struct BossState {
     ct::PackedScene *packed = nullptr;
     std::vector<ctgpu_ctx *> ctxs;        // one per GPU the frame is split over
     uint64_t rand_consumed = 0;           // LIBC jitter mode: rand() calls used by earlier frames
-    ct_raythread_options options{CTGPU_RNG_HASH, 0, 0, 1};
+    ct_raythread_options options{CTGPU_RNG_HASH, 0, 0, 1, 0};
     ctgpu_stats last_stats{};
+    bool in_flight = false;               // async: a frame has been queued and not yet seen finished
+    uint64_t frames_finished = 0;
 };
 
 BossState &boss() {
@@ -143,6 +152,7 @@ void RayThreadSetOptions(const ct_raythread_options *opt) {
 
 void RayThreadReset(void) {
     BossState &b = boss();
+    if (b.in_flight && !b.ctxs.empty()) (void)gpu().render_poll(b.ctxs[0], 1, nullptr, nullptr);
     for (ctgpu_ctx *c : b.ctxs) gpu().destroy(c);
     delete b.packed;
     const ct_raythread_options keep = b.options;
@@ -151,6 +161,9 @@ void RayThreadReset(void) {
 }
 
 extern "C" void cth_last_frame_stats(ctgpu_stats *out) { if (out) *out = boss().last_stats; }
+
+bool RayThreadBusy(void) { return boss().in_flight; }
+uint64_t RayThreadFramesFinished(void) { return boss().frames_finished; }
 
 bool RayThread(environment_t *env, scene_t *scene) {
     BossState &b = boss();
@@ -175,8 +188,18 @@ bool RayThread(environment_t *env, scene_t *scene) {
         b.initialised = true;
     }
 
-    // HandleUpdates (raythread.cpp:546-593)
+    // HandleUpdates (raythread.cpp:546-593): keys are drained on every call; a new frame is dispatched only
+    // when the previous one has finished AND something changed
     b.changes_pending = drain_keyboard(env, b, &scene->camera.position) || b.changes_pending;
+    if (b.in_flight) {
+        int done = 0;
+        ctgpu_stats stats;
+        if (api.render_poll(b.ctxs[0], 0, &done, &stats) != CTGPU_OK) die("ctgpu_render_poll", api.last_error());
+        if (!done) return true;
+        b.in_flight = false;
+        b.last_stats = stats;
+        b.frames_finished++;
+    }
     if (!b.changes_pending) return true;
     b.changes_pending = false;
     camera_matrix(b, &scene->camera.rotation);
@@ -197,10 +220,17 @@ bool RayThread(environment_t *env, scene_t *scene) {
     frame.rng_offset = b.rand_consumed;
     frame.max_depth = 10;                 // TraceRay(..., 10, ...) raythread.cpp:474,508
 
-    ctgpu_stats stats;
-    if (api.render_multi(b.ctxs.data(), (int)b.ctxs.size(), &frame, (uint32_t *)env->bitmap->memory, &stats) != CTGPU_OK)
-        die("ctgpu_render_multi", api.last_error());
-    b.last_stats = stats;
+    if (b.options.async && b.ctxs.size() == 1) {
+        if (api.render_begin(b.ctxs[0], &frame, (uint32_t *)env->bitmap->memory) != CTGPU_OK)
+            die("ctgpu_render_begin", api.last_error());
+        b.in_flight = true;
+    } else {
+        ctgpu_stats stats;
+        if (api.render_multi(b.ctxs.data(), (int)b.ctxs.size(), &frame, (uint32_t *)env->bitmap->memory, &stats) != CTGPU_OK)
+            die("ctgpu_render_multi", api.last_error());
+        b.last_stats = stats;
+        b.frames_finished++;
+    }
     if (scene->settings.supersampling) {
         // one worker's rand() calls per frame: every column of the square x every traced row
         // (the off-bitmap row included) x 16 samples x (rx, ry)   raythread.cpp:455-471

@@ -31,6 +31,7 @@ public:
 
     bool ok() const { return ok_; }
     size_t position() const { return pos_; }
+    void seek(size_t position) { pos_ = position; }
     size_t size() const { return data_->size(); }
     const char *bytes() const { return data_->data(); }
     static bool is_space(char c) { return c == '\n' || c == '\r' || c == ' ' || c == '\t'; }

@@ -154,11 +154,25 @@ struct ct_raythread_options {
     int      rng_mode;     /* CTGPU_RNG_* from ctgpu.h; default CTGPU_RNG_HASH     */
     uint64_t rng_seed;     /* hash-mode seed, default 0                             */
     int      device;       /* first HIP device ordinal, default 0                   */
-    int      n_devices;    /* GPUs to split every frame over (row tiles, peer-to-peer gather);
+    int      n_devices;    /* GPUs to split every frame over (row tiles, RCCL gather);
                               0 or 1 = one GPU.  Ordinals wrap around the visible devices, so a
                               larger count than GPUs present still works (contexts share a GPU). */
+    int      async;        /* 0: a call that renders returns with the pixels in the bitmap.
+                              1: it only queues the frame; later calls find out that it has finished, as
+                              the reference's boss polls its workers (one GPU only; the bitmap must stay
+                              where it is while a frame is in flight) */
 };
 void RayThreadSetOptions(const ct_raythread_options *opt);
+bool RayThreadBusy(void);                 /* async: a queued frame has not been seen finished yet */
+uint64_t RayThreadFramesFinished(void);   /* frames whose pixels have reached the bitmap */
+
+/* The frame's consumer, draw2d.h:22-64: hands env->bitmap to the display.  Built with SDL2 (make SDL=1, or when
+ * sdl2-config is found) it is the reference's sequence -- SDL_CreateRGBSurfaceFrom(memory, W, H, 32, 4*W,
+ * R=0xff, G=0xff00, B=0xff0000, A=0) -> texture -> SDL_RenderCopy to {0,0,W,H} -> SDL_RenderPresent, surface and
+ * texture destroyed each frame.  Without SDL2, or with env->renderer == NULL, it is a frame sink: it counts the
+ * frames it was shown and, when CT_BLIT_PPM names a file, writes the bitmap there as a binary PPM. */
+void Blit(environment_t *environment);
+uint64_t BlitFrameCount(void);
 /* Releases device buffers and the function-local state so that a new scene can
  * be rendered in the same process (the reference never frees, raythread.cpp:643). */
 void RayThreadReset(void);

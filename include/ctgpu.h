@@ -149,6 +149,9 @@ int  ctgpu_device_count(int *count);
  *   CTGPU_BLOCKS_PER_CU  persistent waves per CU of the traversal launches (0 = what fits; fewer
  *                        is better when several contexts keep frames in flight on one GPU)
  *   CTGPU_CHUNK          ray ids a wave reserves per queue atomic (multiple of 64; 0 = by frame size)
+ *   CTGPU_CHUNK_SHADOW   the same for the shadow walk alone (default: CTGPU_CHUNK's value)
+ *   CTGPU_KEEP_SHADOW_RAYS   1: trace also the shadow rays whose answer cannot change a pixel (ct_light_gate)
+ *   CTGPU_RCCL_LIBRARY   path of the librccl to bind (default: one the process already holds, else ROCm's)
  *   CTGPU_PACKET         0: per-lane walk over the binary tree instead of the shared (packet) walk
  *   CTGPU_PACKET_LDS_LEVELS, CTGPU_LDS_DEPTH   stack levels kept in LDS (deeper ones go to HBM)
  *   CTGPU_FORCE_MEGAKERNEL   1: the general path (one kernel, reflection capable) for every frame */
@@ -161,11 +164,19 @@ int  ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *scene);
  * (width*height uint32).  Synchronous.  stats may be NULL. */
 int  ctgpu_render(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, uint32_t *host_fb, ctgpu_stats *stats);
 
-/* The same frame split over several contexts of THIS process (one per GPU; contexts on the same
- * device are allowed and behave like separate GPUs): interleaved row tiles, peer-to-peer gather to
- * the first context's device, assembly there.  All contexts must hold the same scene.  This is
- * what RayThread uses when it is given more than one device (raythread.cpp:574-618 had one
- * worker thread per band). */
+/* The same frame without blocking the caller (raythread.cpp:546-593: the reference's RayThread dispatches its
+ * workers and looks at their status on later calls).  begin queues trace + assemble + the copy into host_fb on
+ * the context's stream (host_fb is page-locked on first use and must stay valid until the frame is done; one
+ * frame in flight per context); poll says whether it has finished -- or waits for it when `wait` is non-zero --
+ * and then fills `stats`. */
+int  ctgpu_render_begin(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, uint32_t *host_fb);
+int  ctgpu_render_poll(ctgpu_ctx *ctx, int wait, int *done, ctgpu_stats *stats);
+
+/* The same frame split over several contexts of THIS process (one per GPU): interleaved row tiles, an RCCL
+ * gather (one communicator per device, ncclGather in one group) to the first context's device, assembly
+ * there.  All contexts must hold the same scene.  Contexts that share a device are allowed (RCCL cannot
+ * address a device twice: their tiles travel as plain device copies instead).  This is what RayThread uses when
+ * it is given more than one device (raythread.cpp:574-618 had one worker thread per band). */
 int  ctgpu_render_multi(ctgpu_ctx *const *ctxs, int n_ctx, const ctgpu_frame_desc *frame, uint32_t *host_fb,
                         ctgpu_stats *stats);
 

@@ -132,3 +132,61 @@ def test_render_multi_matches_single(scenes, gpu_ctx):
     finally:
         for c in ctxs:
             c.close()
+
+
+def test_raythread_asynchronous_loop(assets):
+    """The application loop of cobbletrace.cpp:90-120 (key-downs in, RayThread, Blit) with RayThread only QUEUEING
+    frames (ct_raythread_options.async -> ctgpu_render_begin / ctgpu_render_poll), the way the reference's boss
+    dispatches workers and polls their status: the loop turns while a frame is in flight, keys pressed meanwhile are
+    drained but wait for the frame to finish, every finished frame is the frame the synchronous path renders."""
+    import ctypes as C
+    host = ca.host_library()
+    scene_path = os.path.join(assets, "scene_import_bunny.json")
+    w, h = 640, 400
+    images = {}
+    for mode in (0, 1):
+        host.cth_raythread_reset()
+        host.cth_raythread_options_async(ca.RNG_HASH, 3, 0, mode)
+        scene = ca.HostScene(scene_path)
+        fb = np.zeros((h, w), dtype=np.uint32)
+        polls = C.c_int(-1)
+        before_frames, before_blits = host.cth_frames_finished(), host.cth_blit_count()
+        iterations = host.cth_app_loop(scene.handle, w, h, fb.ctypes.data, b"wdy", C.byref(polls))
+        finished = host.cth_frames_finished() - before_frames
+        assert finished == 4                                  # the first frame + one per key
+        assert host.cth_blit_count() - before_blits == iterations
+        if mode == 0:
+            assert iterations == 4 and polls.value == 0       # every call rendered
+        else:
+            assert iterations >= 8                            # dispatch and completion are different calls
+        images[mode] = fb.copy()
+        pos = (C.c_double * 3)()
+        host.cth_get_camera(scene.handle, pos)
+        assert abs(pos[1] - (17 + 0.1)) < 1e-6 and abs(pos[0] - (5 + 0.1)) < 1e-6      # 'w', 'd' moved the camera
+        scene.close()
+    host.cth_raythread_reset()
+    host.cth_raythread_options(ca.RNG_HASH, 0, 0, 1)
+    assert (images[0] == images[1]).all() and (images[0] != 0).any()
+
+
+def test_render_begin_poll(scenes, gpu_ctx):
+    """ctgpu_render_begin / ctgpu_render_poll: the frame arrives in the caller's buffer without the caller waiting;
+    one frame in flight per context."""
+    scene, ctx = scenes("bunny"), gpu_ctx("bunny")
+    frame = scene.frame(1920, 1080, rng_seed=2)
+    want, sw = ctx.render(frame)
+    fb = ctx.render_begin(frame)
+    with pytest.raises(RuntimeError, match="already in flight"):
+        ctx.render_begin(frame)
+    polls = 0
+    while True:
+        done, st = ctx.render_poll()
+        if done:
+            break
+        polls += 1
+    assert (fb == want).all() and st.rays == sw.rays and st.pixels_written == sw.pixels_written
+    with pytest.raises(RuntimeError, match="no frame is in flight"):
+        ctx.render_poll()
+    fb2 = ctx.render_begin(frame)
+    done, _ = ctx.render_poll(wait=True)
+    assert done and (fb2 == want).all()

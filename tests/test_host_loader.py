@@ -254,3 +254,20 @@ def test_parallel_ply_import_equals_the_serial_reader(shape, tmp_path, monkeypat
         assert parallel.lib.cth_node_hash(parallel.handle) == serial.lib.cth_node_hash(serial.handle)
         parallel.close()
     serial.close()
+
+
+def test_blit_is_a_frame_sink_without_sdl(tmp_path, monkeypatch):
+    """Blit (draw2d.h:22-64) without SDL2 / without a renderer: counts frames and, with CT_BLIT_PPM, leaves the bitmap
+    as a PPM -- bytes R, G, B of every 0x00BBGGRR word, row-major, top-down (what the SDL surface masks select)."""
+    host = ca.host_library()
+    fb = np.arange(6 * 4, dtype=np.uint32).reshape(4, 6) * 0x010203 + 0x112233
+    before = host.cth_blit_count()
+    host.cth_blit(fb.ctypes.data, 6, 4)
+    assert host.cth_blit_count() == before + 1
+    out = tmp_path / "frame.ppm"
+    monkeypatch.setenv("CT_BLIT_PPM", str(out))
+    host.cth_blit(fb.ctypes.data, 6, 4)
+    data = out.read_bytes()
+    assert data.startswith(b"P6\n6 4\n255\n")
+    rgb = np.frombuffer(data[len(b"P6\n6 4\n255\n"):], dtype=np.uint8).reshape(4, 6, 3)
+    assert (rgb[..., 0] == (fb & 0xff)).all() and (rgb[..., 1] == ((fb >> 8) & 0xff)).all() and (rgb[..., 2] == ((fb >> 16) & 0xff)).all()
