@@ -14,7 +14,7 @@ try:  # plumbing only: nothing in this package computes with torch
 except Exception:  # pragma: no cover - torch-less installs use the system runtime
     torch = None
 
-F_SUPERSAMPLE, F_SUBSAMPLE = 1, 2
+F_SUPERSAMPLE, F_SUBSAMPLE, F_SPHERES, F_REFLECT_FIX = 1, 2, 4, 8
 RNG_HASH, RNG_LIBC = 0, 1
 
 
@@ -41,10 +41,17 @@ class Light(C.Structure):
                 ("direction", C.c_double * 3)]
 
 
+class Sphere(C.Structure):
+    _fields_ = [("center", C.c_double * 3), ("radius", C.c_float), ("pad_", C.c_uint32), ("material", Material),
+                ("pad2_", C.c_uint32)]
+
+
 class SceneDesc(C.Structure):
     _fields_ = [("n_triangles", C.c_uint32), ("n_nodes", C.c_uint32), ("n_lights", C.c_uint32),
                 ("pad_", C.c_uint32), ("vertices", C.POINTER(C.c_double)), ("materials", C.POINTER(Material)),
-                ("nodes", C.POINTER(Node)), ("indexes", C.POINTER(C.c_uint32)), ("lights", C.POINTER(Light))]
+                ("nodes", C.POINTER(Node)), ("indexes", C.POINTER(C.c_uint32)), ("lights", C.POINTER(Light)),
+                ("n_spheres", C.c_uint32), ("n_sphere_nodes", C.c_uint32), ("spheres", C.POINTER(Sphere)),
+                ("sphere_nodes", C.POINTER(Node)), ("sphere_indexes", C.POINTER(C.c_uint32))]
 
 
 class FrameDesc(C.Structure):
@@ -143,6 +150,7 @@ _HOST_SYMBOLS = {
     "cth_fnv1a64": (C.c_uint64, [C.c_void_p, C.c_uint64]),
     "cth_assemble_tiles": (C.c_int, [C.POINTER(FrameDesc), C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "cth_raythread_options_async": (None, [C.c_int, C.c_uint64, C.c_int, C.c_int]),
+    "cth_raythread_options_ex": (None, [C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_uint]),
     "cth_app_loop": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]),
     "cth_blit_count": (C.c_uint64, []),
     "cth_frames_finished": (C.c_uint64, []),
@@ -239,7 +247,7 @@ class HostScene:
         return tuple(p)
 
     def frame(self, width, height, threads=None, supersampling=None, subsampling=None, rng_mode=RNG_HASH,
-              rng_seed=0, rng_offset=0, rotation=None, max_depth=10):
+              rng_seed=0, rng_offset=0, rotation=None, max_depth=10, spheres=False, reflect_fix=False):
         """FrameDesc for this scene's camera; unspecified settings come from the scene file."""
         s = self.settings
         f = FrameDesc()
@@ -247,7 +255,8 @@ class HostScene:
         f.num_threads = s["numberOfThreads"] if threads is None else threads
         ss = s["supersampling"] if supersampling is None else supersampling
         sub = s["subsampling"] if subsampling is None else subsampling
-        f.flags = (F_SUPERSAMPLE if ss else 0) | (F_SUBSAMPLE if sub else 0)
+        f.flags = ((F_SUPERSAMPLE if ss else 0) | (F_SUBSAMPLE if sub else 0) | (F_SPHERES if spheres else 0) |
+                   (F_REFLECT_FIX if reflect_fix else 0))
         f.cam_pos = (C.c_double * 3)(*self.camera)
         f.cam_rot = rotation if rotation is not None else identity_rotation()
         f.rng_mode, f.rng_seed, f.rng_offset, f.max_depth = rng_mode, rng_seed, rng_offset, max_depth

@@ -185,6 +185,55 @@ __device__ __forceinline__ void step_leaf(LaneRay &r, const TriRecord *__restric
     }
 }
 
+// ---- spheres (CTGPU_F_SPHERES; the reference parses them but has not rendered them since it got its BVH,
+// raythread.cpp:207 "TODO add sphere's to the bvh").  IntersectRaySphere as written (raythread.cpp:158-174): float
+// coefficients of double dot products; a negative discriminant falls through to the square root, whose NaN no
+// comparison accepts.
+__device__ __forceinline__ void sphere_roots(const d3 &o, const d3 &d, const ctgpu_sphere &s, float &t1, float &t2) {
+    const float radius = s.radius;
+    const d3 co = o - load_d3(s.center);
+    const float a = dotf(d, d);
+    const float b = 2 * dotf(co, d);
+    const float c = dotf(co, co) - (radius * radius);
+    const float discriminant = b * b - 4 * a * c;
+    t1 = (-b + __builtin_sqrtf(discriminant)) / (2 * a);
+    t2 = (-b - __builtin_sqrtf(discriminant)) / (2 * a);
+}
+
+// The spheres' tree, depth first, left before right, leaf entries in index order; a box is entered when the slab
+// test of bvh.cpp:165-179 passes against the closest distance so far (tmin <= it).  A root is accepted by the rule
+// of the reference's own pre-BVH loop (the commented block raythread.cpp:230-246): tmin <= t <= tmax and
+// t <= tclosest, t1 before t2.  Small scenes only: one lane, one private stack, the reference's divisions.
+__device__ __noinline__ void walk_spheres(const FrameParams &P, const d3 &o, const d3 &d, float t_min, float t_max,
+                                          float &tclosest, int &sphere) {
+    uint32_t pending[CTGPU_MAX_TREE_DEPTH + 1];
+    int sp = 0;
+    uint32_t node_id = 0;
+    for (;;) {
+        const ctgpu_node *n = P.sphere_nodes + node_id;
+        float lo, hi;
+        slab(o, d, n->bmin, n->bmax, lo, hi);
+        bool descend = hi >= lo && lo <= tclosest && hi > 0;
+        if (descend && n->count) {
+            for (uint32_t k = 0; k < n->count; k++) {
+                const uint32_t id = P.sphere_indexes[n->first + k];
+                float t1, t2;
+                sphere_roots(o, d, P.spheres[id], t1, t2);
+                if (t_min <= t1 && t1 <= t_max && t1 <= tclosest) { tclosest = t1; sphere = (int)id; }
+                if (t_min <= t2 && t2 <= t_max && t2 <= tclosest) { tclosest = t2; sphere = (int)id; }
+            }
+            descend = false;
+        }
+        if (descend) {
+            pending[sp++] = n->left + 1;
+            node_id = n->left;
+            continue;
+        }
+        if (sp == 0) return;
+        node_id = pending[--sp];
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------
@@ -316,18 +365,29 @@ __global__ __launch_bounds__(kWave) void ct_trace_tiles(const FrameParams P) {
             bool go_lights = false;
 
             if (phase == PH_CLOSEST) {
-                if (r.t != kNoHit) {
-                    // closestScene = objects[lookup[closestIndex]] (raythread.cpp:211): slot of
-                    // triangle 0 when nothing was recorded
-                    const uint32_t slot = (r.slot == kNoNode) ? P.slot_of_triangle0 : r.slot;
-                    const TriRecord *rec = P.tris + slot;
-                    const d3 e1 = load_d3(rec->e1), e2 = load_d3(rec->e2);
-                    const Material m = P.materials[rec->triangle];
-                    mat_color = m.color; mat_specular = m.specular; mat_reflection = m.reflection;
+                int sphere = -1;
+                if (P.n_spheres)      // camera rays: TraceRay(.., 1, FINF, ..); reflected ones: (.., 0.001, FINF, ..)   raythread.cpp:480, 373
+                    walk_spheres(P, r.o, r.d, n_pending > 0 ? 0.001f : 1.0f, kFarAway, r.tclosest, sphere);
+                if (r.t != kNoHit || sphere >= 0) {
                     const d3 position = r.o + scale((double)r.tclosest, r.d);
-                    d3 n = cross(e1, e2);                                 // raythread.cpp:337-345
-                    if (!(dotf(n, r.d) < 0)) n = -n;
-                    normal = n;
+                    if (sphere >= 0) {
+                        // NormalOfSceneObject, OT_SPHERE (raythread.cpp:331-334): n / Magnitude(n) = (1.0f / (D)F|n|) * n
+                        const ctgpu_sphere &s = P.spheres[sphere];
+                        mat_color = s.material.color; mat_specular = s.material.specular; mat_reflection = s.material.reflection;
+                        const d3 n = position - load_d3(s.center);
+                        normal = scale((double)1.0f / (double)lengthf(n), n);
+                    } else {
+                        // closestScene = objects[lookup[closestIndex]] (raythread.cpp:211): slot of
+                        // triangle 0 when nothing was recorded
+                        const uint32_t slot = (r.slot == kNoNode) ? P.slot_of_triangle0 : r.slot;
+                        const TriRecord *rec = P.tris + slot;
+                        const d3 e1 = load_d3(rec->e1), e2 = load_d3(rec->e2);
+                        const Material m = P.materials[rec->triangle];
+                        mat_color = m.color; mat_specular = m.specular; mat_reflection = m.reflection;
+                        d3 n = cross(e1, e2);                                 // raythread.cpp:337-345
+                        if (!(dotf(n, r.d) < 0)) n = -n;
+                        normal = n;
+                    }
                     view = -r.d;
                     r.o = position;                                       // origin of every follow-up ray
                     intensity = 0.0f;
@@ -337,7 +397,14 @@ __global__ __launch_bounds__(kWave) void ct_trace_tiles(const FrameParams P) {
                     color_ready = true;                                   // miss: background
                 }
             } else {   // PH_SHADOW came back
-                if (r.t == kNoHit) {
+                bool lit = r.t == kNoHit;
+                if (lit && P.n_spheres) {      // ClosestIntersection(.., 0.001, tMax, ..): tMax = 1 towards a point light (raythread.cpp:289-307)
+                    int sphere = -1;
+                    float nearest = kFarAway;
+                    walk_spheres(P, r.o, r.d, 0.001f, P.lights[light].type == CTGPU_LIGHT_POINT ? 1.0f : kFarAway, nearest, sphere);
+                    lit = sphere < 0;
+                }
+                if (lit) {
                     // light reaches the point: diffuse + specular (raythread.cpp:309-324)
                     const Light L = P.lights[light];
                     const d3 to_light = r.d;
@@ -385,7 +452,7 @@ __global__ __launch_bounds__(kWave) void ct_trace_tiles(const FrameParams P) {
                         n_pending += 1;
                         const double ni = (double)dotf(normal, view);
                         r.d = scale(ni, scale(2.0, normal)) - view;
-                        r.t = 0.0f;
+                        r.t = P.reflect_fix ? kNoHit : 0.0f;
                         start_traversal(r, P);
                         if (COUNT) cnt.visits += 1;
                         phase = PH_CLOSEST;

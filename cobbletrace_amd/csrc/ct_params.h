@@ -28,6 +28,13 @@ struct FrameParams {
     const Material  *materials;
     const Light     *lights;
     uint32_t n_lights;
+    // spheres (CTGPU_F_SPHERES, general path only): the scene's sphere objects, the tree over their bounding cubes in
+    // the C ABI's own node format, leaf slot -> sphere; n_spheres = 0 when the frame does not ask for them
+    const ctgpu_sphere *spheres;
+    const ctgpu_node   *sphere_nodes;
+    const uint32_t     *sphere_indexes;
+    uint32_t n_spheres;
+    uint32_t reflect_fix;         // CTGPU_F_REFLECT_FIX: reflected rays start at ray.t = 1e30f, not 0
     uint32_t root_ref;            // WideNode index, or kLeafBit|0 when the whole tree is one leaf
     uint32_t slot_of_triangle0;   // TriRecord slot holding scene triangle 0
     uint32_t stack_depth;         // LDS stack entries per lane

@@ -21,7 +21,7 @@ using namespace ctd;
 
 // sizes the bindings (cobbletrace_amd/bindings.py) rely on
 static_assert(sizeof(ctgpu_node) == 64 && sizeof(ctgpu_light) == 56 && sizeof(ctgpu_material) == 12, "scene records");
-static_assert(sizeof(ctgpu_scene_desc) == 56 && sizeof(ctgpu_frame_desc) == 136 && sizeof(ctgpu_stats) == 72, "descriptors");
+static_assert(sizeof(ctgpu_scene_desc) == 88 && sizeof(ctgpu_sphere) == 48 && sizeof(ctgpu_frame_desc) == 136 && sizeof(ctgpu_stats) == 72, "descriptors");
 static_assert(sizeof(ctgpu_ray) == 56 && sizeof(ctgpu_hit) == 16 && sizeof(ctgpu_partition) == 12, "test-hook records");
 
 // ------------------------------------------------------------------ error plumbing
@@ -75,6 +75,10 @@ struct ctgpu_ctx {
     DeviceArray<TriRecord> tris;
     DeviceArray<Material> materials;
     DeviceArray<Light> lights;
+    DeviceArray<ctgpu_sphere> spheres;          // CTGPU_F_SPHERES
+    DeviceArray<ctgpu_node> sphere_nodes;
+    DeviceArray<uint32_t> sphere_indexes;
+    uint32_t n_spheres = 0, sphere_tree_depth = 0;
 
     DeviceArray<uint32_t> tiles;       // compact tile buffer of a whole-frame render
     DeviceArray<uint32_t> fb;          // device framebuffer of ctgpu_render
@@ -247,6 +251,7 @@ extern "C" void ctgpu_destroy(ctgpu_ctx *ctx) {
     ctx->rand_table.release(); ctx->row_ordinal.release();
     ctx->coords.release(); ctx->hits.release(); ctx->shadow.release(); ctx->queue.release(); ctx->spill.release();
     ctx->shadow_lights.release(); ctx->walk_work.release();
+    ctx->spheres.release(); ctx->sphere_nodes.release(); ctx->sphere_indexes.release();
     for (hipEvent_t e : ctx->marks) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -458,6 +463,44 @@ extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
         HIP_TRY(hipMemcpy(ctx->shadow_lights.ptr, shadow_lights.data(), shadow_lights.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     ctx->n_shadow_lights = (uint32_t)shadow_lights.size();
 
+    // ---- spheres and their tree (optional; validated like the triangle tree)
+    ctx->n_spheres = 0;
+    ctx->sphere_tree_depth = 0;
+    if (s->n_spheres) {
+        if (!s->spheres || !s->sphere_nodes || !s->sphere_indexes || s->n_sphere_nodes == 0 || s->n_sphere_nodes > 2u * s->n_spheres)
+            return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_upload_scene: sphere arrays missing or inconsistent");
+        for (uint32_t i = 0; i < s->n_sphere_nodes; i++) {
+            const ctgpu_node &n = s->sphere_nodes[i];
+            if (n.count == 0) {
+                if (n.left == 0 || (uint64_t)n.left + 1 >= s->n_sphere_nodes) return ctgpu_fail(CTGPU_ERR_ARG, "sphere node %u: child link out of range", i);
+            } else if ((uint64_t)n.first + n.count > s->n_spheres) {
+                return ctgpu_fail(CTGPU_ERR_ARG, "sphere node %u: leaf range out of range", i);
+            }
+        }
+        for (uint32_t i = 0; i < s->n_spheres; i++)
+            if (s->sphere_indexes[i] >= s->n_spheres) return ctgpu_fail(CTGPU_ERR_ARG, "sphere_indexes[%u] out of range", i);
+        std::vector<std::pair<uint32_t, uint32_t>> todo{{0u, 1u}};
+        size_t visited = 0;
+        uint32_t sphere_depth = 0;
+        while (!todo.empty()) {
+            const auto [id, d] = todo.back();
+            todo.pop_back();
+            if (++visited > s->n_sphere_nodes) return ctgpu_fail(CTGPU_ERR_ARG, "sphere node links form a cycle");
+            sphere_depth = std::max(sphere_depth, d);
+            if (s->sphere_nodes[id].count == 0) { todo.push_back({s->sphere_nodes[id].left, d + 1}); todo.push_back({s->sphere_nodes[id].left + 1, d + 1}); }
+        }
+        if (sphere_depth > CTGPU_MAX_TREE_DEPTH) return ctgpu_fail(CTGPU_ERR_STACK, "sphere tree depth %u exceeds %d", sphere_depth, CTGPU_MAX_TREE_DEPTH);
+        HIP_TRY(ctx->spheres.resize(s->n_spheres));
+        HIP_TRY(ctx->sphere_nodes.resize(s->n_sphere_nodes));
+        HIP_TRY(ctx->sphere_indexes.resize(s->n_spheres));
+        HIP_TRY(hipMemcpy(ctx->spheres.ptr, s->spheres, (size_t)s->n_spheres * sizeof(ctgpu_sphere), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ctx->sphere_nodes.ptr, s->sphere_nodes, (size_t)s->n_sphere_nodes * sizeof(ctgpu_node), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(ctx->sphere_indexes.ptr, s->sphere_indexes, (size_t)s->n_spheres * sizeof(uint32_t), hipMemcpyHostToDevice));
+        ctx->n_spheres = s->n_spheres;
+        ctx->sphere_tree_depth = sphere_depth;
+        for (uint32_t i = 0; i < s->n_spheres; i++) reflective = reflective || (s->spheres[i].material.reflection > 0);
+    }
+
     ctx->n_triangles = N;
     ctx->n_lights = s->n_lights;
     ctx->tree_depth = depth;
@@ -531,6 +574,11 @@ int fill_params(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, const ctgpu_partition
     P.nodes = ctx->nodes.ptr; P.quads = ctx->quads.ptr; P.quad_source = ctx->quad_source.ptr; P.quad_root = ctx->quad_root;
     P.quads_flat = ctx->quads_flat.ptr; P.quad_source_flat = ctx->quad_source_flat.ptr; P.quad_root_flat = ctx->quad_root_flat; P.tris = ctx->tris.ptr; P.materials = ctx->materials.ptr; P.lights = ctx->lights.ptr;
     P.n_lights = ctx->n_lights;
+    if ((f->flags & CTGPU_F_SPHERES) && ctx->n_spheres) {
+        P.spheres = ctx->spheres.ptr; P.sphere_nodes = ctx->sphere_nodes.ptr; P.sphere_indexes = ctx->sphere_indexes.ptr;
+        P.n_spheres = ctx->n_spheres;
+    }
+    P.reflect_fix = (f->flags & CTGPU_F_REFLECT_FIX) ? 1u : 0u;
     P.root_ref = ctx->root_ref;
     P.slot_of_triangle0 = ctx->slot_of_triangle0;
     // pending right siblings never exceed the tree depth; COUNT mode also parks rejected ones
@@ -630,6 +678,7 @@ namespace {
 bool pipeline_eligible(const ctgpu_ctx *ctx, const ctgpu_frame_desc *f) {
     if (ctx->force_megakernel) return false;
     if (ctx->has_reflection && f->max_depth > 0) return false;
+    if ((f->flags & CTGPU_F_SPHERES) && ctx->n_spheres) return false;       // spheres are rendered by the general path
     return ctx->n_shadow_lights <= 32;
 }
 

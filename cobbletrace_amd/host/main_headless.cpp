@@ -14,7 +14,7 @@
 static void usage() {
     std::fprintf(stderr,
                  "cobbletrace_headless scenefile [--width W] [--height H] [--out image.ppm]\n"
-                 "                     [--rng hash|libc] [--seed N] [--device N] [--gpus N] [--keys wasd...] [--async]\n\n"
+                 "                     [--rng hash|libc] [--seed N] [--device N] [--gpus N] [--keys wasd...] [--async] [--spheres] [--reflect-fix]\n\n"
                  "To run cobbletrace provide a scene file.  See assets/scene_file_1.json for an example.\n");
     std::exit(0);
 }
@@ -23,7 +23,7 @@ int main(int argc, char **argv) {
     if (argc < 2) usage();
     int width = 640, height = 640;
     std::string out = "cobbletrace.ppm", keys;
-    ct_raythread_options opt{CTGPU_RNG_HASH, 0, 0, 1, 0};
+    ct_raythread_options opt{CTGPU_RNG_HASH, 0, 0, 1, 0, 0u};
     for (int i = 2; i < argc; i++) {
         const std::string a = argv[i];
         auto need = [&](const char *name) -> const char * {
@@ -39,6 +39,8 @@ int main(int argc, char **argv) {
         else if (a == "--gpus") opt.n_devices = std::atoi(need("--gpus"));
         else if (a == "--keys") keys = need("--keys");
         else if (a == "--async") opt.async = 1;
+        else if (a == "--spheres") opt.frame_flags |= CTGPU_F_SPHERES;
+        else if (a == "--reflect-fix") opt.frame_flags |= CTGPU_F_REFLECT_FIX;
         else usage();
     }
 

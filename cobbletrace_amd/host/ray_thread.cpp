@@ -88,7 +88,7 @@ struct BossState {
     ct::PackedScene *packed = nullptr;
     std::vector<ctgpu_ctx *> ctxs;        // one per GPU the frame is split over
     uint64_t rand_consumed = 0;           // LIBC jitter mode: rand() calls used by earlier frames
-    ct_raythread_options options{CTGPU_RNG_HASH, 0, 0, 1, 0};
+    ct_raythread_options options{CTGPU_RNG_HASH, 0, 0, 1, 0, 0u};
     ctgpu_stats last_stats{};
     bool in_flight = false;               // async: a frame has been queued and not yet seen finished
     uint64_t frames_finished = 0;
@@ -210,7 +210,8 @@ bool RayThread(environment_t *env, scene_t *scene) {
     frame.height = env->bitmap->height;
     frame.num_threads = scene->settings.numberOfThreads;
     frame.flags = (scene->settings.supersampling ? CTGPU_F_SUPERSAMPLE : 0u) |
-                  (scene->settings.subsampling ? CTGPU_F_SUBSAMPLE : 0u);
+                  (scene->settings.subsampling ? CTGPU_F_SUBSAMPLE : 0u) |
+                  (b.options.frame_flags & (CTGPU_F_SPHERES | CTGPU_F_REFLECT_FIX));
     frame.cam_pos[0] = scene->camera.position.x;
     frame.cam_pos[1] = scene->camera.position.y;
     frame.cam_pos[2] = scene->camera.position.z;

@@ -18,6 +18,29 @@ namespace ct {
 PackedScene::~PackedScene() {
     std::free(bvh.bvhNodes);
     std::free(bvh.triangles.indexes);
+    std::free(sphere_bvh.bvhNodes);
+    std::free(sphere_bvh.triangles.indexes);
+}
+
+// The sphere tree is the triangle builder's work on stand-ins: per sphere a "triangle" whose corners are the two
+// opposite corners of its bounding cube and its centre, so that BuildBVH's own bounds, centroids (of the three
+// corners, x 0.3333f as always) and midpoint splits apply unchanged (bvh.cpp:16-121).
+static void build_sphere_tree(PackedScene &p) {
+    std::free(p.sphere_bvh.bvhNodes);
+    std::free(p.sphere_bvh.triangles.indexes);
+    p.sphere_bvh = bvh_state_t{};
+    p.sphere_proxies.clear();
+    if (p.spheres.empty()) return;
+    for (const ctgpu_sphere &s : p.spheres) {
+        const double r = (double)s.radius;
+        triangle_t t{};
+        t.p1 = v3_t{s.center[0] - r, s.center[1] - r, s.center[2] - r};
+        t.p2 = v3_t{s.center[0] + r, s.center[1] + r, s.center[2] + r};
+        t.p3 = v3_t{s.center[0], s.center[1], s.center[2]};
+        p.sphere_proxies.push_back(t);
+    }
+    p.sphere_bvh = InitializeBVHState(p.sphere_proxies.data(), (int)p.sphere_proxies.size());
+    BuildBVH(&p.sphere_bvh);
 }
 
 static void flatten(PackedScene &p) {
@@ -39,8 +62,17 @@ void PackedScene::build_from(const scene_t *scene) {
     triangles.clear();
     materials.clear();
     lights.clear();
+    spheres.clear();
     for (int i = 0; i < scene->objectStack.index; i++) {
         const scene_object_t &o = scene->objectStack.objects[i];
+        if (o.type == OT_SPHERE) {
+            ctgpu_sphere s;
+            std::memset(&s, 0, sizeof s);
+            s.center[0] = o.sphere.center.x; s.center[1] = o.sphere.center.y; s.center[2] = o.sphere.center.z;
+            s.radius = o.sphere.radius;
+            s.material = ctgpu_material{o.material.color, o.material.specular, o.material.reflection};
+            spheres.push_back(s);
+        }
         if (o.type != OT_TRIANGLE) continue;
         triangles.push_back(o.triangle);
         materials.push_back(ctgpu_material{o.material.color, o.material.specular, o.material.reflection});
@@ -55,6 +87,7 @@ void PackedScene::build_from(const scene_t *scene) {
         g.direction[0] = l.direction.x; g.direction[1] = l.direction.y; g.direction[2] = l.direction.z;
         lights.push_back(g);
     }
+    build_sphere_tree(*this);
     flatten(*this);
 }
 
@@ -62,6 +95,8 @@ void PackedScene::build_from_vertices(const double *verts, uint32_t n) {
     triangles.assign(n, triangle_t{});
     materials.assign(n, ctgpu_material{0x00ffffffu, -1, 0.0f});
     lights.clear();
+    spheres.clear();
+    build_sphere_tree(*this);
     for (uint32_t i = 0; i < n; i++) {
         const double *v = verts + (size_t)i * 9;
         triangles[i].p1 = v3_t{v[0], v[1], v[2]};
@@ -82,6 +117,13 @@ ctgpu_scene_desc PackedScene::desc() const {
     d.nodes = reinterpret_cast<const ctgpu_node *>(bvh.bvhNodes);
     d.indexes = bvh.triangles.indexes;
     d.lights = lights.data();
+    if (!spheres.empty()) {
+        d.n_spheres = (uint32_t)spheres.size();
+        d.n_sphere_nodes = sphere_bvh.nodesUsed;
+        d.spheres = spheres.data();
+        d.sphere_nodes = reinterpret_cast<const ctgpu_node *>(sphere_bvh.bvhNodes);
+        d.sphere_indexes = sphere_bvh.triangles.indexes;
+    }
     return d;
 }
 

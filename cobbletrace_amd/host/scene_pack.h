@@ -18,6 +18,10 @@ struct PackedScene {
     std::vector<double>         vertices;    // [n][9]
     std::vector<ctgpu_material> materials;   // [n]
     std::vector<ctgpu_light>    lights;
+    // the scene's OT_SPHERE objects in stack order, and a tree over their bounding cubes (CTGPU_F_SPHERES)
+    std::vector<ctgpu_sphere>   spheres;
+    std::vector<triangle_t>     sphere_proxies;
+    bvh_state_t                 sphere_bvh{};
     bool                        built = false;
 
     ~PackedScene();

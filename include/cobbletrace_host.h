@@ -161,6 +161,8 @@ struct ct_raythread_options {
                               1: it only queues the frame; later calls find out that it has finished, as
                               the reference's boss polls its workers (one GPU only; the bitmap must stay
                               where it is while a frame is in flight) */
+    unsigned frame_flags;  /* extra CTGPU_F_* bits for every frame: CTGPU_F_SPHERES, CTGPU_F_REFLECT_FIX (what the
+                              reference's source has but its pictures do not; default 0 = the reference's frame) */
 };
 void RayThreadSetOptions(const ct_raythread_options *opt);
 bool RayThreadBusy(void);                 /* async: a queued frame has not been seen finished yet */

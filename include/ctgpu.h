@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define CTGPU_ABI_VERSION 2
+#define CTGPU_ABI_VERSION 3
 
 typedef struct ctgpu_ctx ctgpu_ctx;
 
@@ -82,6 +82,17 @@ typedef struct ctgpu_light {         /* scenefile.h:61-66, 56 bytes */
     double  direction[3];
 } ctgpu_light;
 
+/* A sphere object of the scene file (scenefile.h:31-34, scenefile.cpp:58-71).  The reference parses spheres
+ * but no longer renders them ("TODO add sphere's to the bvh", raythread.cpp:207; README.md:20); this build can,
+ * on request (CTGPU_F_SPHERES), from a second tree over them. */
+typedef struct ctgpu_sphere {
+    double center[3];
+    float  radius;
+    uint32_t pad_;
+    ctgpu_material material;
+    uint32_t pad2_;
+} ctgpu_sphere;                      /* 48 bytes */
+
 typedef struct ctgpu_scene_desc {
     uint32_t n_triangles;
     uint32_t n_nodes;                /* nodesUsed */
@@ -92,11 +103,29 @@ typedef struct ctgpu_scene_desc {
     const ctgpu_node     *nodes;     /* [n_nodes], node 0 = root */
     const uint32_t       *indexes;   /* [n_triangles] leaf slot -> triangle */
     const ctgpu_light    *lights;    /* [n_lights], file order */
+    /* optional (all zero / NULL: none): the scene's spheres in object order and a tree over them in the
+     * same node format (leaf slots index sphere_indexes[]), built like the triangle tree (bvh.cpp:16-121) over
+     * each sphere's bounding cube */
+    uint32_t n_spheres, n_sphere_nodes;
+    const ctgpu_sphere   *spheres;
+    const ctgpu_node     *sphere_nodes;
+    const uint32_t       *sphere_indexes;
 } ctgpu_scene_desc;
 
 /* ---- frame ---- */
 #define CTGPU_F_SUPERSAMPLE 1u       /* settings.supersampling, raythread.cpp:460-505 */
 #define CTGPU_F_SUBSAMPLE   2u       /* settings.subsampling,   raythread.cpp:512-531 */
+/* Two things the reference has in its source but not in its pictures; both off unless asked for, so that
+ * the default frame stays the reference's:
+ * SPHERES: render the scene's sphere objects too -- IntersectRaySphere (raythread.cpp:158-174) under the
+ *   acceptance rule of the reference's own pre-BVH loop (the commented block raythread.cpp:230-246:
+ *   tmin <= t && t <= tmax && t <= tclosest for t1, then t2), tmin / tmax as TraceRay and ComputeLighting
+ *   pass them (1 / 0.001 .. FINF, shadows 0.001 .. 1 for a point light), the sphere normal of
+ *   NormalOfSceneObject (raythread.cpp:331-334); spheres are visited after the triangles, through their tree.
+ * REFLECT_FIX: a reflected ray starts with ray.t = 1e30f like every other ray instead of the 0 of
+ *   raythread.cpp:373, which makes IntersectBVHClosest reject everything in front of it. */
+#define CTGPU_F_SPHERES      4u
+#define CTGPU_F_REFLECT_FIX  8u
 
 #define CTGPU_RNG_HASH 0             /* counter-based jitter, independent of thread count */
 #define CTGPU_RNG_LIBC 1             /* glibc rand() stream in the call order of ONE worker */

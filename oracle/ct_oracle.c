@@ -185,6 +185,8 @@ typedef struct {
     uint64_t rays_primary, rays_shadow, rays_reflect;
     int count_work;
     int shadow_early_exit;
+    int spheres;        /* CTGPU_F_SPHERES: the scene's sphere objects are rendered too */
+    int reflect_fix;    /* CTGPU_F_REFLECT_FIX: reflected rays start at ray.t = 1e30f instead of 0 */
 } tracer;
 
 /* bvh.cpp:165-179: six D quotients stored to F, F min/max macros */
@@ -261,12 +263,74 @@ static int walk_closest(tracer *tr, ray *r, uint32_t node_id, float *tclosest, u
     return walk_closest(tr, r, node->left + 1, tclosest, closest, any_hit_exit);
 }
 
-/* raythread.cpp:197-228 */
-static int closest_intersection(tracer *tr, ray r, float *tclosest, uint32_t *closest, int any_hit_exit) {
+/* ---- spheres (CTGPU_F_SPHERES; off = the reference's pictures, which have none: README.md:20) ----
+ * IntersectRaySphere, raythread.cpp:158-174, as written: the quadratic's coefficients are floats of double dot
+ * products; a negative discriminant sets both roots to FINF and then FALLS THROUGH to the square root, whose NaN
+ * replaces them (and no comparison below accepts a NaN). */
+static void sphere_roots(const ray *r, const ctgpu_sphere *s, float *t1, float *t2) {
+    const float radius = s->radius;
+    const v3 co = v3_sub(r->origin, v3_load(s->center));
+    const float a = v3_dot(r->direction, r->direction);
+    const float b = 2 * v3_dot(co, r->direction);
+    const float c = v3_dot(co, co) - (radius * radius);
+    const float discriminant = b * b - 4 * a * c;
+    if (discriminant < 0) { *t1 = kFarAway; *t2 = kFarAway; }
+    /* sqrt of a float picks C++'s float overload; the sum and the quotient are float operations */
+    *t1 = (-b + sqrtf(discriminant)) / (2 * a);
+    *t2 = (-b - sqrtf(discriminant)) / (2 * a);
+}
+
+/* The spheres' tree, walked like the triangles' (left subtree first, leaf entries in index order); a box is
+ * entered when the slab test of bvh.cpp:165-179 passes against the closest distance so far (tmin <= it: a sphere
+ * at the very same distance still replaces the holder, as the rule below lets it).  Acceptance is the reference's
+ * own, from its pre-BVH loop (the commented block raythread.cpp:230-246). */
+static void walk_spheres(tracer *tr, const ray *r, uint32_t node_id, float tmin, float tmax, float *tclosest, int *sphere) {
+    const ctgpu_scene_desc *sc = tr->scene;
+    const ctgpu_node *node = &sc->sphere_nodes[node_id];
+    {
+        /* slab parameters as slab_test computes them, compared against *tclosest with <= */
+        const float tx1 = (float)((node->bmin[0] - r->origin.x) / r->direction.x);
+        const float tx2 = (float)((node->bmax[0] - r->origin.x) / r->direction.x);
+        float lo = LESSER(tx1, tx2), hi = GREATER(tx1, tx2);
+        const float ty1 = (float)((node->bmin[1] - r->origin.y) / r->direction.y);
+        const float ty2 = (float)((node->bmax[1] - r->origin.y) / r->direction.y);
+        lo = GREATER(lo, LESSER(ty1, ty2));
+        hi = LESSER(hi, GREATER(ty1, ty2));
+        const float tz1 = (float)((node->bmin[2] - r->origin.z) / r->direction.z);
+        const float tz2 = (float)((node->bmax[2] - r->origin.z) / r->direction.z);
+        lo = GREATER(lo, LESSER(tz1, tz2));
+        hi = LESSER(hi, GREATER(tz1, tz2));
+        if (!(hi >= lo && lo <= *tclosest && hi > 0)) return;
+    }
+    if (node->count > 0) {
+        for (uint32_t k = 0; k < node->count; k++) {
+            const uint32_t id = sc->sphere_indexes[node->first + k];
+            float t1, t2;
+            sphere_roots(r, &sc->spheres[id], &t1, &t2);
+            if (tmin <= t1 && t1 <= tmax && t1 <= *tclosest) { *tclosest = t1; *sphere = (int)id; }
+            if (tmin <= t2 && t2 <= tmax && t2 <= *tclosest) { *tclosest = t2; *sphere = (int)id; }
+        }
+        return;
+    }
+    walk_spheres(tr, r, node->left, tmin, tmax, tclosest, sphere);
+    walk_spheres(tr, r, node->left + 1, tmin, tmax, tclosest, sphere);
+}
+
+/* raythread.cpp:197-228; *sphere >= 0 when a sphere holds the closest distance (spheres enabled only).
+ * tmin / tmax: what the caller passes to ClosestIntersection -- the reference ignores them for triangles
+ *  and so does this; they bound the sphere roots. */
+static int closest_intersection(tracer *tr, ray r, float tmin, float tmax, float *tclosest, uint32_t *closest, int *sphere,
+                                int any_hit_exit) {
     *tclosest = kFarAway;
     *closest = 0;
+    *sphere = -1;
     walk_closest(tr, &r, 0, tclosest, closest, any_hit_exit);
-    return r.t != kNoHit;
+    int found = r.t != kNoHit;
+    if (tr->spheres && tr->scene->n_spheres && !(any_hit_exit && found)) {
+        walk_spheres(tr, &r, 0, tmin, tmax, tclosest, sphere);
+        found = found || *sphere >= 0;
+    }
+    return found;
 }
 
 /* ------------------------------------------------------------------ shading */
@@ -288,11 +352,13 @@ static float compute_lighting(tracer *tr, v3 position, v3 normal, v3 view, int s
             continue;
         }
 
-        /* shadow ray: full traversal from the surface point, no distance limit */
-        float tclosest; uint32_t closest;
+        /* shadow ray: full traversal from the surface point, no distance limit for triangles (tMax is
+         * computed and ignored, raythread.cpp:289-307); 0.001 .. tMax bound a sphere's roots */
+        float tclosest; uint32_t closest; int sphere;
         ray shadow = {position, to_light, kNoHit};
+        const float t_max = (light->type == CTGPU_LIGHT_POINT) ? 1.0f : kFarAway;
         tr->rays_shadow++;
-        if (closest_intersection(tr, shadow, &tclosest, &closest, tr->shadow_early_exit)) continue;
+        if (closest_intersection(tr, shadow, 0.001f, t_max, &tclosest, &closest, &sphere, tr->shadow_early_exit)) continue;
 
         const float n_dot_l = v3_dot(normal, to_light);
         if (n_dot_l > 0)
@@ -315,18 +381,26 @@ static float compute_lighting(tracer *tr, v3 position, v3 normal, v3 view, int s
 
 /* raythread.cpp:353-386 (+ NormalOfSceneObject :329-350) */
 static uint32_t trace_ray(tracer *tr, ray r, int depth, int is_reflection) {
-    float tclosest; uint32_t closest;
+    float tclosest; uint32_t closest; int sphere;
     if (is_reflection) tr->rays_reflect++; else tr->rays_primary++;
-    if (!closest_intersection(tr, r, &tclosest, &closest, 0)) return kBackground;
+    /* TraceRay(.., 1, FINF, ..) for camera rays, (.., 0.001, FINF, ..) for reflected ones (raythread.cpp:480, 373) */
+    if (!closest_intersection(tr, r, is_reflection ? 0.001f : 1.0f, kFarAway, &tclosest, &closest, &sphere, 0)) return kBackground;
 
     const ctgpu_scene_desc *sc = tr->scene;
     const double *tri = sc->vertices + (size_t)closest * 9;
-    const ctgpu_material *mat = &sc->materials[closest];
+    const ctgpu_material *mat = sphere >= 0 ? &sc->spheres[sphere].material : &sc->materials[closest];
 
     const v3 position = v3_add(r.origin, v3_scale((double)tclosest, r.direction));
-    const v3 p1 = v3_load(tri), p2 = v3_load(tri + 3), p3 = v3_load(tri + 6);
-    v3 normal = v3_cross(v3_sub(p2, p1), v3_sub(p3, p1));
-    if (!(v3_dot(normal, r.direction) < 0)) normal = v3_neg(normal);
+    v3 normal;
+    if (sphere >= 0) {
+        /* NormalOfSceneObject, OT_SPHERE (raythread.cpp:331-334): n = P - C; n / Magnitude(n) = (1.0f / (D)F|n|) * n */
+        const v3 n = v3_sub(position, v3_load(sc->spheres[sphere].center));
+        normal = v3_scale((double)1.0f / (double)v3_length(n), n);
+    } else {
+        const v3 p1 = v3_load(tri), p2 = v3_load(tri + 3), p3 = v3_load(tri + 6);
+        normal = v3_cross(v3_sub(p2, p1), v3_sub(p3, p1));
+        if (!(v3_dot(normal, r.direction) < 0)) normal = v3_neg(normal);
+    }
 
     const float value = compute_lighting(tr, position, normal, v3_neg(r.direction), mat->specular);
     const uint32_t local = cto_shade_value(mat->color, value);
@@ -336,7 +410,7 @@ static uint32_t trace_ray(tracer *tr, ray r, int depth, int is_reflection) {
     /* ReflectRay(-dir, N); the reflected ray starts with t = 0 (sic, raythread.cpp:373) */
     const v3 incoming = v3_neg(r.direction);
     const double ni = (double)v3_dot(normal, incoming);
-    ray bounce = {position, v3_sub(v3_scale(ni, v3_scale(2.0, normal)), incoming), 0.0f};
+    ray bounce = {position, v3_sub(v3_scale(ni, v3_scale(2.0, normal)), incoming), tr->reflect_fix ? kNoHit : 0.0f};
     const uint32_t reflected = trace_ray(tr, bounce, depth - 1, 1);
     return cto_mix_reflection(local, reflected, mat->reflection);
 }
@@ -464,6 +538,8 @@ static void *worker_main(void *arg) {
     tr.scene = job->scene;
     tr.count_work = job->opt->count_work;
     tr.shadow_early_exit = job->opt->shadow_early_exit;
+    tr.spheres = (job->frame->flags & CTGPU_F_SPHERES) != 0;
+    tr.reflect_fix = (job->frame->flags & CTGPU_F_REFLECT_FIX) != 0;
     uint64_t written = 0;
     for (;;) {
         pthread_mutex_lock(&job->lock);

@@ -30,11 +30,11 @@ def test_every_declared_symbol_is_exported():
 
 def test_abi_version_and_structs():
     lib = ca.gpu_library()
-    assert lib.ctgpu_abi_version() == 2
+    assert lib.ctgpu_abi_version() == 3
     # struct sizes the header promises
     assert C.sizeof(ca.Node) == 64 and C.sizeof(ca.Light) == 56 and C.sizeof(ca.Material) == 12
     assert C.sizeof(ca.Ray) == 56 and C.sizeof(ca.Hit) == 16
-    assert C.sizeof(ca.FrameDesc) == 136 and C.sizeof(ca.SceneDesc) == 56 and C.sizeof(ca.Stats) == 72
+    assert C.sizeof(ca.FrameDesc) == 136 and C.sizeof(ca.SceneDesc) == 88 and C.sizeof(ca.Stats) == 72
 
 
 def test_no_gpu_means_errors_not_fallbacks():

@@ -872,3 +872,50 @@ def test_degenerate_inputs(tmp_path):
                     _compare(gpu_fb, cpu_fb, "%s packet=%s ss=%d" % (name, packet, ss))
             finally:
                 del os.environ["CTGPU_PACKET"]
+
+
+@pytest.mark.parametrize("spheres,reflect_fix", [(True, False), (False, True), (True, True)])
+def test_spheres_and_reflection_fix(spheres, reflect_fix, scenes, gpu_ctx, tmp_path):
+    """SURVEY.md 8f rank 4.  CTGPU_F_SPHERES: the scene's sphere objects rendered through their own tree
+    (IntersectRaySphere raythread.cpp:158-174, acceptance rule of raythread.cpp:230-246, sphere normal :331-334);
+    CTGPU_F_REFLECT_FIX: reflected rays start at ray.t = 1e30f instead of the 0 of raythread.cpp:373.  Both off by
+    default (the reference's pictures); on, the GPU's general path against the oracle's restatement."""
+    scene, ctx = scenes("cube"), gpu_ctx("cube")               # 37 triangles, 109 spheres, reflective materials
+    for ss, w, h in ((False, 640, 480), (True, 320, 240)):
+        frame = scene.frame(w, h, supersampling=ss, rng_seed=2, spheres=spheres, reflect_fix=reflect_fix)
+        plain = scene.frame(w, h, supersampling=ss, rng_seed=2)
+        got, st = ctx.render(frame)
+        want, cst = _oracle().render(scene.desc, frame, os_threads=8)
+        _compare(got, want, "cube spheres=%d reflect_fix=%d ss=%d" % (spheres, reflect_fix, ss))
+        assert ((got == 0) == (want == 0)).all()
+        default, _ = ctx.render(plain)
+        assert (default != got).sum() > 200                    # the flags really change the picture
+        assert st.rays_primary == cst.rays_primary - (2 * (h // 2)) * (16 if ss else 1)
+    # a scene with spheres in front of everything, lit by a point light (shadow rays stop at tMax = 1 for spheres)
+    import json
+    objs = [{"type": "sphere", "center": [0, -1, 3], "radius": 1, "color": [255, 0, 0], "specular": 500, "reflection": 0.2},
+            {"type": "sphere", "center": [2, 0, 4], "radius": 1, "color": [0, 0, 255], "specular": 500, "reflection": 0.3},
+            {"type": "sphere", "center": [-2, 0, 4], "radius": 1, "color": [0, 255, 0], "specular": 10, "reflection": 0.4},
+            {"type": "sphere", "center": [0, -5001, 0], "radius": 5000, "color": [255, 255, 0], "specular": 1000, "reflection": 0.5},
+            {"type": "sphere", "center": [0.5, 0.8, 2.2], "radius": 0.3, "color": [200, 200, 200], "specular": -1, "reflection": 0},
+            {"type": "triangle", "p1": [-3, -1, 6], "p2": [3, -1, 6], "p3": [0, 3, 6], "color": [255, 0, 255], "specular": 50,
+             "reflection": 0.1}]
+    lights = [{"type": "ambient", "intensity": 0.2}, {"type": "point", "intensity": 0.6, "position": [2, 1, 0]},
+              {"type": "directional", "intensity": 0.2, "direction": [1, 4, 4]}]
+    path = tmp_path / "spheres.json"
+    path.write_text(json.dumps({"objects": objs, "lights": lights, "camera": {"position": [0, 0, -1]},
+                                "settings": {"numberOfThreads": 4, "subsampling": False, "wireframe": False, "supersampling": True}}))
+    own = ca.HostScene(str(path))
+    assert own.desc.n_spheres == 5
+    c = ca.GpuContext(0)
+    c.upload(own.desc)
+    try:
+        for ss in (False, True):
+            frame = own.frame(400, 300, supersampling=ss, rng_seed=5, spheres=spheres, reflect_fix=reflect_fix)
+            got, _ = c.render(frame)
+            want, _ = _oracle().render(own.desc, frame, os_threads=4)
+            _compare(got, want, "five spheres spheres=%d reflect_fix=%d ss=%d" % (spheres, reflect_fix, ss))
+            if spheres:
+                assert ((got & 0xff) > 150).sum() > 2000           # the red one is in the picture
+    finally:
+        c.close()

@@ -129,3 +129,58 @@ def test_frame_geometry_quirks(scenes):
     assert (fb[1:4] == 0).all() and (fb[5] != 0).any()           # rows beyond T*(H/T) stay untouched
     assert (fb[:, :18] == 0).all() and (fb[:, 82:] == 0).all()   # only the centred H x H square
     assert st.rays_primary == 64 * 60
+
+
+def test_sphere_extension_of_the_oracle(scenes):
+    """CTGPU_F_SPHERES: the reference parses spheres but has not rendered them since it got
+    its BVH (raythread.cpp:207, README.md:20).  Rendered on request -- IntersectRaySphere (raythread.cpp:158-174)
+    under the acceptance rule of the reference's own pre-BVH loop (raythread.cpp:230-246) -- they show; the
+    default frame is untouched by their presence in the scene description."""
+    import cobbletrace_amd as ca
+    from oracle import oracle
+    scene = scenes("cube")                                     # 37 triangles and 109 spheres
+    d = scene.desc
+    assert d.n_spheres == 109 and 1 <= d.n_sphere_nodes <= 2 * 109
+    seen = sorted(d.sphere_indexes[i] for i in range(d.n_spheres))
+    assert seen == list(range(109))                            # the tree's leaves hold every sphere once
+    plain = scene.frame(640, 480, threads=8, supersampling=False)
+    with_spheres = scene.frame(640, 480, threads=8, supersampling=False, spheres=True)
+    a, sa = oracle.render(d, plain, os_threads=4)
+    b, sb = oracle.render(d, with_spheres, os_threads=4)
+    # (108 of them are 0.04 across, at the corners of the lattice; the big one is hidden behind the backdrop)
+    assert (a != b).sum() > 500 and sb.rays_primary == sa.rays_primary
+    # and the reflected rays that start at 1e30f instead of 0 see the scene (CTGPU_F_REFLECT_FIX): a third of the frame changes
+    fixed, _ = oracle.render(d, scene.frame(640, 480, threads=8, supersampling=False, reflect_fix=True), os_threads=4)
+    assert (fixed != a).sum() > 100_000
+    # without the sphere arrays in the description the flag has nothing to add
+    bare = ca.SceneDesc(d.n_triangles, d.n_nodes, d.n_lights, 0, d.vertices, d.materials, d.nodes, d.indexes, d.lights)
+    c, _ = oracle.render(bare, with_spheres, os_threads=2)
+    assert (c == a).all()
+
+
+def test_a_single_sphere_is_where_geometry_says(tmp_path):
+    """One sphere of radius 1 at z = 4 seen from the origin along +z: the silhouette is the disc of canvas radius
+    h * tan(asin(1/4)) pixels around the centre; hits are at distance 3 on the axis."""
+    import json
+    import cobbletrace_amd as ca
+    from oracle import oracle
+    scene_json = {"objects": [{"type": "sphere", "center": [0, 0, 4], "radius": 1, "color": [255, 0, 0], "specular": -1, "reflection": 0},
+                              {"type": "triangle", "p1": [50, 50, 60], "p2": [51, 50, 60], "p3": [50, 51, 60], "color": [0, 255, 0],
+                               "specular": -1, "reflection": 0}],
+                  "lights": [{"type": "ambient", "intensity": 1.0}], "camera": {"position": [0, 0, 0]},
+                  "settings": {"numberOfThreads": 4, "subsampling": False, "wireframe": False, "supersampling": False}}
+    path = tmp_path / "one_sphere.json"
+    path.write_text(json.dumps(scene_json))
+    scene = ca.HostScene(str(path))
+    assert scene.desc.n_spheres == 1 and scene.desc.n_triangles == 1
+    h = 200
+    frame = scene.frame(h, h, threads=4, supersampling=False, spheres=True)
+    fb, _ = oracle.render(scene.desc, frame, os_threads=1)
+    red = (fb == 0x0000ff)
+    ys, xs = np.nonzero(red)
+    radius_px = h * np.tan(np.arcsin(1 / 4.0))
+    assert abs(red.sum() - np.pi * radius_px ** 2) < 0.03 * np.pi * radius_px ** 2
+    assert abs(xs.mean() - h / 2) < 1.0 and abs(ys.mean() - h / 2) < 1.0
+    assert abs((xs.max() - xs.min() + 1) / 2 - radius_px) < 1.5
+    off, _ = oracle.render(scene.desc, scene.frame(h, h, threads=4, supersampling=False), os_threads=1)
+    assert not (off == 0x0000ff).any()                         # the reference's own picture: no sphere
