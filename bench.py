@@ -146,6 +146,11 @@ def cpu_baseline(ca, scene, frame, gpu_host_fb, budget_s):
 
 def main():
     args = parse_args()
+    # stdout carries exactly ONE line, the JSON record: everything else that may write to file descriptor 1 on the
+    # way (RCCL prints a version banner there when a communicator comes up) goes to stderr instead
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -162,7 +167,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: no HIP device is visible")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # (CT_BENCH_FORCE_DIST=1 under torch.distributed.run with ONE rank rehearses every collective of the N-rank
+    # path on a one-GPU box; RCCL will not put two ranks on one device)
+    use_dist = world > 1 or (bool(os.environ.get("CT_BENCH_FORCE_DIST")) and "RANK" in os.environ)
+    if use_dist:
         dist.init_process_group("nccl", device_id=device)
 
     # every rank needs the assets and the native libraries; rank 0 prepares, the others wait
@@ -173,7 +181,7 @@ def main():
         if not all(os.path.exists(p) for p in libs):
             entry.build()
         entry.prepare_assets(need_dragon=(args.scene == "dragon"))
-    if world > 1:
+    if use_dist:
         dist.barrier()
 
     scene = ca.HostScene(os.path.join(ROOT, "assets", SCENE_FILES[args.scene]))
@@ -194,7 +202,7 @@ def main():
         os.environ.setdefault("CTGPU_BLOCKS_PER_CU", "12")
         os.environ.setdefault("CTGPU_CHUNK", "128")
 
-    use_comm = world > 1 or args.force_collective
+    use_comm = use_dist or args.force_collective
     collective = "none"
     slots = []
     for i in range(inflight):
@@ -209,13 +217,17 @@ def main():
                 "native": False}
         if use_comm and args.collective == "native":
             # rank 0 makes the RCCL unique id, torch.distributed carries its 128 bytes to the other ranks
+            # (one communicator per rank, shared by the slots: RCCL then orders the in-flight frames' gathers itself)
             try:
-                uid = torch.zeros(128, dtype=torch.uint8, device=device)
-                if rank == 0:
-                    uid.copy_(torch.frombuffer(bytearray(ca.GpuContext.comm_unique_id()), dtype=torch.uint8))
-                if world > 1:
-                    dist.broadcast(uid, src=0)
-                ctx.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
+                if i == 0:
+                    uid = torch.zeros(128, dtype=torch.uint8, device=device)
+                    if rank == 0:
+                        uid.copy_(torch.frombuffer(bytearray(ca.GpuContext.comm_unique_id()), dtype=torch.uint8))
+                    if use_dist:
+                        dist.broadcast(uid, src=0)
+                    ctx.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
+                else:
+                    ctx.comm_share(slots[0]["ctx"])
                 slot["native"] = True
             except RuntimeError as e:                      # stay measurable: the same collective through torch.distributed
                 if rank == 0:
@@ -223,7 +235,7 @@ def main():
         slots.append(slot)
     if use_comm:
         native_everywhere = torch.tensor([1.0 if all(s["native"] for s in slots) else 0.0], device=device)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(native_everywhere, op=dist.ReduceOp.MIN)
         if native_everywhere.item() < 1.0:
             for s in slots:
@@ -233,7 +245,7 @@ def main():
 
     def sync_all():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -247,7 +259,7 @@ def main():
                 s["ctx"].render_sharded(frame, tile_rows, s["fb"].data_ptr() if rank == 0 else 0, stream.cuda_stream)
             else:
                 s["ctx"].render_partition(frame, s["part"], s["tiles"].data_ptr(), stream.cuda_stream)
-                gathered = s["tiles"] if world == 1 else multi_gpu.gather_to_root(s["tiles"], world, rank)
+                gathered = s["tiles"] if not use_dist else multi_gpu.gather_to_root(s["tiles"], world, rank)
                 if rank == 0:
                     s["ctx"].assemble(frame, s["part"], gathered.data_ptr(), s["fb"].data_ptr(), stream.cuda_stream)
             if rank == 0 and to_host:
@@ -281,7 +293,7 @@ def main():
     my_rays = float(sum(c.rays for c in counted))
     my_elided = float(sum(c.rays_shadow_elided for c in counted))
     totals = torch.tensor([my_rays, my_elided, elapsed], dtype=torch.float64, device=device)
-    if world > 1:
+    if use_dist:
         sums = totals[:2].clone()
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
         time_max = totals[2:].clone()
@@ -295,7 +307,7 @@ def main():
 
     # ---- outside the timed region: the same K frames left on the device (no host copy), and one frame alone
     elapsed_device = timed(args.steps, to_host=False)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed_device], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed_device = float(t.item())
@@ -408,10 +420,11 @@ def main():
             last = slots[(args.steps - 1) % inflight]["host_fb"].numpy().view(np.uint32).reshape(frame.height, frame.width)
             out["cpu_baseline"], out["parity"] = cpu_baseline(ca, scene, frame, last, args.cpu_seconds)
             out["speedup_vs_cpu_ms_per_frame"] = round(out["cpu_baseline"]["ms_per_frame"] / ms_per_step, 1)
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     for s in slots:
         s["ctx"].close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

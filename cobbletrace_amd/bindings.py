@@ -118,6 +118,7 @@ _GPU_SYMBOLS = {
     "ctgpu_assemble": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.POINTER(Partition), C.c_void_p, C.c_void_p, C.c_void_p]),
     "ctgpu_comm_unique_id": (C.c_int, [C.c_void_p]),
     "ctgpu_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "ctgpu_comm_share": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ctgpu_comm_rank": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ctgpu_comm_destroy": (C.c_int, [C.c_void_p]),
     "ctgpu_gather_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p]),
@@ -394,6 +395,9 @@ class GpuContext:
     def comm_init(self, unique_id, rank, world):
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
         self._check(self.lib.ctgpu_comm_init(self.handle, buf, rank, world))
+
+    def comm_share(self, owner):
+        self._check(self.lib.ctgpu_comm_share(self.handle, owner.handle))
 
     def gather_tiles(self, d_tiles_ptr, n, d_all_ptr, root=0, stream_ptr=None):
         self._check(self.lib.ctgpu_gather_tiles(self.handle, C.c_void_p(d_tiles_ptr), n, C.c_void_p(d_all_ptr or 0), root,

@@ -90,6 +90,8 @@ int rccl_ready() {
 struct ctgpu_comm_state {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
+    int device = 0;
+    int users = 1;              // contexts holding this communicator (ctgpu_comm_share)
 };
 
 static_assert(CTGPU_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "ctgpu.h promises room for an ncclUniqueId");
@@ -115,7 +117,22 @@ extern "C" int ctgpu_comm_init(ctgpu_ctx *ctx, const void *id, int rank, int wor
     ncclComm_t comm = nullptr;
     RCCL_TRY(rccl().comm_init_rank(&comm, world, uid, rank));
     slot = new ctgpu_comm_state();
-    slot->comm = comm; slot->rank = rank; slot->world = world;
+    slot->comm = comm; slot->rank = rank; slot->world = world; slot->device = ctgpu_device_of(ctx);
+    return CTGPU_OK;
+}
+
+// Several contexts of one process on one device (frames in flight) gather through ONE communicator: RCCL orders
+// the collectives of a communicator among themselves, whichever streams they were queued on, so every rank runs
+// them in the same order -- with a communicator each, two gathers could wait for each other across ranks.
+extern "C" int ctgpu_comm_share(ctgpu_ctx *ctx, ctgpu_ctx *owner) {
+    if (!ctx || !owner) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_comm_share: null argument");
+    ctgpu_comm_state *&slot = ctgpu_comm_slot(ctx);
+    ctgpu_comm_state *theirs = ctgpu_comm_slot(owner);
+    if (slot) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_comm_share: this context already has a communicator");
+    if (!theirs) return ctgpu_fail(CTGPU_ERR_COMM, "ctgpu_comm_share: the other context has no communicator");
+    if (theirs->device != ctgpu_device_of(ctx)) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_comm_share: the contexts sit on different devices");
+    theirs->users += 1;
+    slot = theirs;
     return CTGPU_OK;
 }
 
@@ -123,8 +140,10 @@ extern "C" int ctgpu_comm_destroy(ctgpu_ctx *ctx) {
     if (!ctx) return CTGPU_OK;
     ctgpu_comm_state *&slot = ctgpu_comm_slot(ctx);
     if (!slot) return CTGPU_OK;
-    if (slot->comm && rccl().lib) (void)rccl().comm_destroy(slot->comm);
-    delete slot;
+    if (--slot->users == 0) {
+        if (slot->comm && rccl().lib) (void)rccl().comm_destroy(slot->comm);
+        delete slot;
+    }
     slot = nullptr;
     return CTGPU_OK;
 }

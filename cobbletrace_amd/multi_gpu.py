@@ -26,7 +26,7 @@ def partition_of(rank, world, tile_rows=DEFAULT_TILE_ROWS):
 
 def gather_to_root(local, world, rank, root=0):
     """All ranks' equally sized tile buffers, back to back on `root` (None elsewhere)."""
-    if world == 1:
+    if world == 1 and not dist.is_initialized():
         return local
     if rank == root:
         everything = torch.empty(world * local.numel(), dtype=local.dtype, device=local.device)

@@ -227,12 +227,15 @@ int  ctgpu_assemble(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, const ctgpu_p
  * ctgpu_comm_unique_id: rank 0 makes the id (ncclGetUniqueId) and hands its CTGPU_COMM_ID_BYTES bytes to the
  *   other ranks by whatever channel the host application has (bench.py: a torch.distributed broadcast).
  * ctgpu_comm_init: every rank, collectively (ncclCommInitRank on the context's device).
+ * ctgpu_comm_share: another context of this process on the same device (a second frame in flight) uses `owner`'s
+ *   communicator instead of one of its own; RCCL then runs all the process's gathers in the order they were issued.
  * ctgpu_gather_tiles: n uint32 from every rank, back to back into d_all on `root` (d_all ignored elsewhere).
  * ctgpu_render_sharded: this rank's share of one frame -- trace my tiles, gather to rank 0, assemble there into
  *   d_fb (rank 0's device framebuffer, width*height uint32) -- all queued on `stream`, nothing synchronises. */
 #define CTGPU_COMM_ID_BYTES 128
 int  ctgpu_comm_unique_id(void *id);
 int  ctgpu_comm_init(ctgpu_ctx *ctx, const void *id, int rank, int world);
+int  ctgpu_comm_share(ctgpu_ctx *ctx, ctgpu_ctx *owner);
 int  ctgpu_comm_rank(ctgpu_ctx *ctx, int *rank, int *world);
 int  ctgpu_comm_destroy(ctgpu_ctx *ctx);
 int  ctgpu_gather_tiles(ctgpu_ctx *ctx, const void *d_tiles, uint64_t n, void *d_all, int root, void *stream);

@@ -218,6 +218,34 @@ def test_native_rccl_frame_on_a_world_of_one(scenes, gpu_ctx):
             assert (fb.cpu().numpy().view(np.uint32).reshape(frame.height, frame.width) == want).all()
     finally:
         ctx.close()
+    # two contexts of one process (frames in flight) gather through ONE communicator (ctgpu_comm_share)
+    a, b = ca.GpuContext(0), ca.GpuContext(0)
+    try:
+        for c in (a, b):
+            c.upload(scene.desc)
+        a.comm_init(ca.GpuContext.comm_unique_id(), 0, 1)
+        b.comm_share(a)
+        with pytest.raises(RuntimeError, match="already has a communicator"):
+            b.comm_share(a)
+        frame = scene.frame(640, 360, threads=8, supersampling=True, rng_seed=9)
+        want, _ = gpu_ctx("bunny").render(frame)
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        fbs = [torch.zeros(frame.height * frame.width, dtype=torch.int32, device="cuda") for _ in range(2)]
+        torch.cuda.synchronize()
+        for rounds in range(3):
+            for c, st_, fb in zip((a, b), streams, fbs):
+                c.render_sharded(frame, 8, fb.data_ptr(), st_.cuda_stream)
+        torch.cuda.synchronize()
+        for c, fb in zip((a, b), fbs):
+            c.read_counters()
+            assert (fb.cpu().numpy().view(np.uint32).reshape(frame.height, frame.width) == want).all()
+        a.close()                                  # the owner goes first: the communicator lives on with b
+        b.render_sharded(frame, 8, fbs[1].data_ptr(), streams[1].cuda_stream)
+        torch.cuda.synchronize()
+        b.read_counters()
+    finally:
+        a.close()
+        b.close()
     # no communicator: the sharded entry points say so instead of falling back to anything
     with pytest.raises(RuntimeError, match="no communicator"):
         gpu_ctx("bunny").render_sharded(scene.frame(64, 64, threads=1), 8, 0)
