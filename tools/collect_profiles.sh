@@ -20,3 +20,8 @@ rocprofv3 --kernel-trace --pmc SQC_DCACHE_REQ SQC_DCACHE_HITS SQC_DCACHE_MISSES 
 rm -rf $R/gpurun_out/${tag}_sq2
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM --output-format csv -d $R/gpurun_out/${tag}_sq2 -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --inflight 1 > $R/gpurun_out/${tag}_sq2.log 2>&1
 cd $R && python3 tools/summarise_profiles.py $tag
+# the default command itself (three frames in flight): bench.py's event timings of the timed region must agree with these
+cd /tmp
+rm -rf $R/gpurun_out/${tag}_stats_default
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_stats_default -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/${tag}_stats_default.log 2>&1
+cd $R && { echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline   (the default command: 3 frames in flight)"; echo; echo '```'; python3 tools/kstats.py gpurun_out/${tag}_stats_default "kernel stats"; echo '```'; echo; echo "bench line of that run:"; echo; echo '```'; grep '^{' gpurun_out/${tag}_stats_default.log; echo '```'; } > gpurun_out/${tag}_stats_default.md
