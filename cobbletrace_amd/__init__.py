@@ -15,5 +15,5 @@ from .bindings import (  # noqa: F401
     FrameDesc, Hit, Light, Material, Node, Partition, Ray, SceneDesc, Sphere, Stats, WalkWork, KernelTimes,
     GpuContext, HostScene, NativeLibraryMissing,
     F_SUPERSAMPLE, F_SUBSAMPLE, F_SPHERES, F_REFLECT_FIX, RNG_HASH, RNG_LIBC,
-    gpu_library, host_library, identity_rotation, repo_root,
+    build_bvh_on_device, gpu_library, host_library, identity_rotation, repo_root,
 )

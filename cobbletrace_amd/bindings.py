@@ -126,6 +126,7 @@ _GPU_SYMBOLS = {
     "ctgpu_read_counters": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "ctgpu_trace_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "ctgpu_trace_rays_packet": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
+    "ctgpu_build_bvh": (C.c_int, [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]),
     "ctgpu_read_walk_work": (C.c_int, [C.c_void_p, C.POINTER(WalkWork)]),
     "ctgpu_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "ctgpu_read_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(KernelTimes)]),
@@ -275,6 +276,20 @@ class HostScene:
     def vertices(self):
         d = self.desc
         return np.ctypeslib.as_array(d.vertices, shape=(d.n_triangles, 9))
+
+
+def build_bvh_on_device(vertices, device=0):
+    """ctgpu_build_bvh: (nodes [m] as raw 64-byte records, indexes [n], device milliseconds) for [n][9] vertices."""
+    lib = gpu_library()
+    v = np.ascontiguousarray(vertices, dtype=np.float64).reshape(-1, 9)
+    n = v.shape[0]
+    nodes = np.zeros((max(2 * n - 1, 1), 64), dtype=np.uint8)
+    indexes = np.zeros(n, dtype=np.uint32)
+    used, ms = C.c_uint32(0), C.c_double(0.0)
+    rc = lib.ctgpu_build_bvh(device, v.ctypes.data, n, nodes.ctypes.data, indexes.ctypes.data, C.byref(used), C.byref(ms))
+    if rc != 0:
+        raise RuntimeError("ctgpu error %d: %s" % (rc, lib.ctgpu_last_error().decode()))
+    return nodes[:used.value], indexes, ms.value
 
 
 # ------------------------------------------------------------------ GPU context

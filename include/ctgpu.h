@@ -25,6 +25,7 @@
  *   ctgpu_trace_rays /          ClosestIntersection on caller-supplied rays (test / KAT hook),
  *   ctgpu_trace_rays_packet     through the general kernel / through the frame kernel
  *                               raythread.cpp:197-228, 303-307
+ *   ctgpu_build_bvh             InitializeBVHState + BuildBVH (bvh.cpp:16-121) on the device, identical arrays
  *   ctgpu_count_work            instrumented run returning node-visit / triangle-test counts
  *                               (the reference has gprof only)
  *
@@ -258,6 +259,15 @@ int  ctgpu_trace_rays_packet(ctgpu_ctx *ctx, const ctgpu_ray *rays, uint64_t n, 
 /* Instrumented render of the same frame (slower; no framebuffer): fills node_visits and
  * triangle_tests besides the ray counts.  These are the V_r / Q_r sums of the roofline model. */
 int  ctgpu_count_work(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, ctgpu_stats *stats);
+
+/* BuildBVH on the device (bvh.cpp:16-121): the node and index arrays the reference's recursion produces for these
+ * triangles -- same boxes (the a<b?a:b folds included), same split planes (binary32 midpoints), same index
+ * permutation (the swap loop of bvh.cpp:82-93, in closed form), same node numbering (children allocated when their
+ * parent is subdivided, depth first).  vertices: [n][9] doubles, p1 p2 p3 per triangle in scene-triangle order;
+ * nodes_out: room for 2n - 1 nodes; indexes_out: n entries.  *device_ms (may be NULL): the build itself, copies
+ * excluded.  The arrays go straight into ctgpu_scene_desc.nodes / .indexes. */
+int  ctgpu_build_bvh(int device, const double *vertices, uint32_t n, ctgpu_node *nodes_out, uint32_t *indexes_out,
+                     uint32_t *n_nodes_out, double *device_ms);
 
 /* ---- measurement hooks (bench.py's roofline object; no effect on pixels) ----
  * ctgpu_read_walk_work: what the two traversal launches (the shared "packet" walk of the fast path) asked the

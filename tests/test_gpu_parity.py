@@ -947,3 +947,48 @@ def test_spheres_and_reflection_fix(spheres, reflect_fix, scenes, gpu_ctx, tmp_p
                 assert ((got & 0xff) > 150).sum() > 2000           # the red one is in the picture
     finally:
         c.close()
+
+
+def _same_tree(scene):
+    nodes, indexes, ms = ca.build_bvh_on_device(scene.vertices())
+    want_nodes = scene.nodes()
+    want_nodes = want_nodes.reshape(-1, 64)[:, :60]            # bvh_node_t without its 4 bytes of padding
+    assert len(nodes) == scene.desc.n_nodes
+    assert (indexes == scene.indexes()).all()
+    assert (nodes[:, :60] == want_nodes).all()
+    return ms
+
+
+@pytest.mark.parametrize("name", ["cube", "import", "bunny", "dragon"])
+def test_device_bvh_build_is_the_reference_tree(name, scenes):
+    """ctgpu_build_bvh (ct_build.hip): BuildBVH (bvh.cpp:16-121) level by level on the GPU.  Byte for byte the arrays
+    the host builder returns -- itself pinned to the reference's node / leaf counts and depth (test_oracle_kat) --
+    boxes, child links, leaf ranges and the index permutation the reference's swap loop leaves."""
+    ms = _same_tree(scenes(name))
+    print("%s: device build %.2f ms" % (name, ms))
+
+
+def test_device_bvh_build_on_awkward_inputs():
+    """Coincident centroids (a side stays empty: the node remains a leaf but its indexes were permuted all the
+    same), triangles in a plane (zero extent on an axis), -0.0 against +0.0 corners (the a<b?a:b fold keeps the
+    LATER of equals), one- and two-triangle trees, a deep chain, random soups of many sizes."""
+    rng = np.random.default_rng(5)
+    cases = {
+        "one": rng.random((1, 9)), "two": rng.random((2, 9)), "three": rng.random((3, 9)),
+        "same": np.tile(rng.random((1, 9)), (40, 1)),
+        "same centroid, different boxes": np.array([[-k, -k, 0, k, -k, 0, 0, 2 * k, 0.0] for k in range(1, 30)]),
+        "flat": np.c_[rng.random((500, 2)), np.zeros(500), rng.random((500, 2)), np.zeros(500), rng.random((500, 2)), np.zeros(500)],
+        "chain": np.array([[x, -1.0, 4.0, 1.6 * x + 0.01, -1.0, 4.0, 1.3 * x, 1.0, 4.0] for x in 2.2 ** np.arange(56) * 0.02]),
+    }
+    zeros = rng.random((300, 9)) - 0.5
+    zeros[rng.random((300, 9)) < 0.3] = 0.0
+    zeros[rng.random((300, 9)) < 0.15] = -0.0                      # sign of zero: which corner comes later decides
+    cases["signed zeros"] = zeros
+    for n in (7, 64, 65, 1000, 4097, 50_000):
+        cases["soup %d" % n] = rng.normal(size=(n, 9)) * np.array([3, 1, 0.2] * 3) + np.repeat(rng.normal(size=(n, 3)) * 4, 3, axis=1).reshape(n, 9)
+    for name, verts in cases.items():
+        scene = ca.HostScene(vertices=np.ascontiguousarray(verts, dtype=np.float64))
+        nodes, indexes, _ = ca.build_bvh_on_device(scene.vertices())
+        assert len(nodes) == scene.desc.n_nodes, name
+        assert (indexes == scene.indexes()).all(), name
+        assert (nodes[:, :60] == scene.nodes().reshape(-1, 64)[:, :60]).all(), name
