@@ -36,6 +36,7 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr uint32_t kSmallSegment = 48;        // boxes of nodes up to this many triangles: one thread each
+constexpr uint32_t kHugeSegment = 4096;       // above this: 256 blocks fold a node's triangles, one more combines them
 
 #define HIP_TRY(expr)                                                                                  \
     do {                                                                                               \
@@ -65,8 +66,9 @@ struct BuildArrays {
     float *a_plane;
     uint32_t *a_left_count, *a_pairs;          // nL, M
     // work lists of the boxes to fit
-    uint32_t *box_small, *box_big;
-    uint32_t *counters;        // [0] nodes used, [1] next level's active nodes, [2] small boxes, [3] big boxes
+    uint32_t *box_small, *box_big, *box_huge;
+    double *huge_runs;         // [huge nodes][256][6] partial boxes
+    uint32_t *counters;        // [0] nodes used, [1] next level's active nodes, [2] small, [3] big, [4] huge boxes
     uint32_t n;
 };
 
@@ -225,28 +227,58 @@ __global__ void k_scatter(BuildArrays A) {
 }
 
 // ---- per active node: children (bvh.cpp:95-104), the next level's active list, the boxes to fit
+// One atomic per wave and counter instead of one per lane: an atomic on a single word takes ~11 ns, and the deep
+// levels have hundreds of thousands of nodes asking.  Returns this lane's first slot (meaningful where `amount` > 0).
+__device__ __forceinline__ uint32_t wave_reserve(uint32_t *counter, uint32_t amount) {
+    uint32_t before = amount;                                   // inclusive prefix over the wave
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t v = __shfl_up(before, off);
+        if ((int)(threadIdx.x & 63) >= off) before += v;
+    }
+    const uint32_t total = __shfl(before, 63);
+    uint32_t base = 0;
+    if ((threadIdx.x & 63) == 63 && total) base = atomicAdd(counter, total);
+    base = __shfl(base, 63);
+    return base + before - amount;
+}
+
 __global__ void k_children(BuildArrays A, uint32_t n_active) {
     const uint32_t s = blockIdx.x * kBlock + threadIdx.x;
-    if (s >= n_active) return;
-    const uint32_t a = A.a_node[s], first = A.t_first[a], count = A.t_count[a];
-    const uint32_t n_left = A.a_left_count[s];
-    if (n_left == 0 || n_left == count) { A.t_left[a] = 0; return; }      // stays a leaf (its indexes were permuted all the same)
-    const uint32_t left = atomicAdd(&A.counters[0], 2u);
+    const bool live = s < n_active;
+    uint32_t a = 0, first = 0, count = 0, n_left = 0;
+    if (live) {
+        a = A.a_node[s]; first = A.t_first[a]; count = A.t_count[a];
+        n_left = A.a_left_count[s];
+    }
+    // a side stayed empty: the node remains a leaf (its indexes were permuted all the same)
+    const bool splits = live && !(n_left == 0 || n_left == count);
+    if (live && !splits) A.t_left[a] = 0;
+    const uint32_t counts[2] = {n_left, count - n_left}, firsts[2] = {first, first + n_left};
+    const uint32_t left = wave_reserve(&A.counters[0], splits ? 2u : 0u);
+    uint32_t n_next = 0, n_small = 0, n_big = 0, n_huge = 0;
+    for (int c = 0; c < 2; c++) {
+        if (!splits) break;
+        n_next += counts[c] > 2u ? 1u : 0u;                                    // bvh.cpp:53: two or fewer stay a leaf
+        if (counts[c] <= kSmallSegment) n_small += 1; else if (counts[c] <= kHugeSegment) n_big += 1; else n_huge += 1;
+    }
+    uint32_t slot_next = wave_reserve(&A.counters[1], n_next), slot_small = wave_reserve(&A.counters[2], n_small),
+             slot_big = wave_reserve(&A.counters[3], n_big), slot_huge = wave_reserve(&A.counters[4], n_huge);
+    if (!splits) return;
     A.t_left[a] = left;
-    const uint32_t firsts[2] = {first, first + n_left}, counts[2] = {n_left, count - n_left};
     for (int c = 0; c < 2; c++) {
         const uint32_t child = left + c;
         A.t_first[child] = firsts[c];
         A.t_count[child] = counts[c];
         A.t_left[child] = 0;
         int32_t slot = -1;
-        if (counts[c] > 2u) {                                              // bvh.cpp:53: two or fewer stay a leaf
-            slot = (int32_t)atomicAdd(&A.counters[1], 1u);
+        if (counts[c] > 2u) {
+            slot = (int32_t)slot_next++;
             A.a_node_next[slot] = child;
         }
         A.t_slot[child] = slot;
-        if (counts[c] <= kSmallSegment) A.box_small[atomicAdd(&A.counters[2], 1u)] = child;
-        else A.box_big[atomicAdd(&A.counters[3], 1u)] = child;
+        if (counts[c] <= kSmallSegment) A.box_small[slot_small++] = child;
+        else if (counts[c] <= kHugeSegment) A.box_big[slot_big++] = child;
+        else A.box_huge[slot_huge++] = child;
     }
 }
 
@@ -311,6 +343,41 @@ __global__ void k_boxes_big(BuildArrays A, const uint32_t *idx) {               
         __syncthreads();
     }
     if (threadIdx.x == 0) box_store(A, node, runs[0]);
+}
+
+// nodes of many triangles: 256 blocks fold consecutive stretches, one block puts their results together in order
+__global__ void k_boxes_huge_runs(BuildArrays A, const uint32_t *idx) {           // grid (256, huge nodes)
+    __shared__ Box runs[kBlock];
+    const uint32_t node = A.box_huge[blockIdx.y], first = A.t_first[node], count = A.t_count[node];
+    const uint32_t per_block = (count + 255u) / 256u;
+    const uint32_t b_lo = blockIdx.x * per_block, b_hi = (b_lo + per_block < count) ? b_lo + per_block : count;
+    const uint32_t span = b_hi > b_lo ? b_hi - b_lo : 0u;
+    const uint32_t per_thread = (span + kBlock - 1) / kBlock;
+    const uint32_t lo = b_lo + threadIdx.x * per_thread, hi = (lo + per_thread < b_hi) ? lo + per_thread : b_hi;
+    Box b;
+    box_start(b);
+    for (uint32_t k = lo; k < hi; k++) box_add_triangle(b, A.verts + (size_t)idx[first + k] * 9);
+    runs[threadIdx.x] = b;
+    __syncthreads();
+    for (int width = 1; width < kBlock; width <<= 1) {
+        if ((threadIdx.x % (2 * width)) == 0 && threadIdx.x + width < kBlock) box_append(runs[threadIdx.x], runs[threadIdx.x + width]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        double *out = A.huge_runs + ((size_t)blockIdx.y * 256u + blockIdx.x) * 6u;
+        for (int c = 0; c < 3; c++) { out[c] = runs[0].lo[c]; out[3 + c] = runs[0].hi[c]; }
+    }
+}
+__global__ void k_boxes_huge_join(BuildArrays A) {                                // one block of 256 per huge node
+    __shared__ Box runs[kBlock];
+    const double *in = A.huge_runs + ((size_t)blockIdx.x * 256u + threadIdx.x) * 6u;
+    for (int c = 0; c < 3; c++) { runs[threadIdx.x].lo[c] = in[c]; runs[threadIdx.x].hi[c] = in[3 + c]; }
+    __syncthreads();
+    for (int width = 1; width < kBlock; width <<= 1) {
+        if ((threadIdx.x % (2 * width)) == 0 && threadIdx.x + width < kBlock) box_append(runs[threadIdx.x], runs[threadIdx.x + width]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) box_store(A, A.box_huge[blockIdx.x], runs[0]);
 }
 
 // ---- numbering: inner nodes below (bottom-up), pre-order rank and final slot (top-down), then the nodes themselves
@@ -393,7 +460,10 @@ extern "C" int ctgpu_build_bvh(int device, const double *vertices, uint32_t n, c
     HIP_TRY(device_alloc(A.a_axis, n, owned));      HIP_TRY(device_alloc(A.a_plane, n, owned));
     HIP_TRY(device_alloc(A.a_left_count, n, owned)); HIP_TRY(device_alloc(A.a_pairs, n, owned));
     HIP_TRY(device_alloc(A.box_small, max_nodes, owned)); HIP_TRY(device_alloc(A.box_big, max_nodes, owned));
-    HIP_TRY(device_alloc(A.counters, 4, owned));
+    const size_t max_huge = (size_t)n / kHugeSegment + 2;
+    HIP_TRY(device_alloc(A.box_huge, max_huge, owned));
+    HIP_TRY(device_alloc(A.huge_runs, max_huge * 256 * 6, owned));
+    HIP_TRY(device_alloc(A.counters, 8, owned));
     HIP_TRY(device_alloc(d_out, max_nodes, owned));
     A.verts = d_verts;
     HIP_TRY(hipMemcpy(d_verts, vertices, (size_t)n * 9 * sizeof(double), hipMemcpyHostToDevice));
@@ -409,9 +479,10 @@ extern "C" int ctgpu_build_bvh(int device, const double *vertices, uint32_t n, c
     HIP_TRY(hipMemcpy(A.t_count, &root_setup[1], 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(A.t_left, &root_setup[2], 4, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(A.a_node, &root_setup[0], 4, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(A.box_big, &root_setup[0], 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(A.box_huge, &root_setup[0], 4, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(k_centroids, dim3(blocks_for(n)), dim3(kBlock), 0, nullptr, A);
-    hipLaunchKernelGGL(k_boxes_big, dim3(1), dim3(kBlock), 0, nullptr, A, (const uint32_t *)A.idx_in);
+    hipLaunchKernelGGL(k_boxes_huge_runs, dim3(256, 1), dim3(kBlock), 0, nullptr, A, (const uint32_t *)A.idx_in);
+    hipLaunchKernelGGL(k_boxes_huge_join, dim3(1), dim3(kBlock), 0, nullptr, A);
 
     std::vector<uint32_t> level_begin{0u};          // temporary ids of the nodes created at each depth
     uint32_t nodes_used = 1, n_active = (n > 2) ? 1u : 0u;
@@ -419,7 +490,7 @@ extern "C" int ctgpu_build_bvh(int device, const double *vertices, uint32_t n, c
         level_begin.push_back(nodes_used);
         if (level_begin.size() > CTGPU_MAX_TREE_DEPTH + 1)
             return ctgpu_fail(CTGPU_ERR_STACK, "ctgpu_build_bvh: the tree is deeper than %d", CTGPU_MAX_TREE_DEPTH);
-        const uint32_t counters[4] = {nodes_used, 0u, 0u, 0u};
+        const uint32_t counters[5] = {nodes_used, 0u, 0u, 0u, 0u};
         HIP_TRY(hipMemcpy(A.counters, counters, sizeof counters, hipMemcpyHostToDevice));
         hipLaunchKernelGGL(k_plan, dim3(blocks_for(n_active)), dim3(kBlock), 0, nullptr, A, n_active);
         hipLaunchKernelGGL(k_classify, dim3(blocks_for(n)), dim3(kBlock), 0, nullptr, A);
@@ -431,10 +502,14 @@ extern "C" int ctgpu_build_bvh(int device, const double *vertices, uint32_t n, c
         hipLaunchKernelGGL(k_scatter, dim3(blocks_for(n)), dim3(kBlock), 0, nullptr, A);
         hipLaunchKernelGGL(k_children, dim3(blocks_for(n_active)), dim3(kBlock), 0, nullptr, A, n_active);
         hipLaunchKernelGGL(k_next_segments, dim3(blocks_for(n)), dim3(kBlock), 0, nullptr, A);
-        uint32_t after[4];
+        uint32_t after[5];
         HIP_TRY(hipMemcpy(after, A.counters, sizeof after, hipMemcpyDeviceToHost));
         if (after[2]) hipLaunchKernelGGL(k_boxes_small, dim3(blocks_for(after[2])), dim3(kBlock), 0, nullptr, A, after[2], (const uint32_t *)A.idx_out);
         if (after[3]) hipLaunchKernelGGL(k_boxes_big, dim3(after[3]), dim3(kBlock), 0, nullptr, A, (const uint32_t *)A.idx_out);
+        if (after[4]) {
+            hipLaunchKernelGGL(k_boxes_huge_runs, dim3(256, after[4]), dim3(kBlock), 0, nullptr, A, (const uint32_t *)A.idx_out);
+            hipLaunchKernelGGL(k_boxes_huge_join, dim3(after[4]), dim3(kBlock), 0, nullptr, A);
+        }
         HIP_TRY(hipGetLastError());
         nodes_used = after[0];
         n_active = after[1];

@@ -24,5 +24,10 @@ struct Fnv64 {
 
 extern std::string g_scene_dir;
 
+// BuildBVH through libctgpu.so's ctgpu_build_bvh (ray_thread.cpp): fills `nodes` (room for 2n - 1) and `indexes`
+// (n) with the arrays the host builder would produce and returns the number of nodes; exits like every other
+// fatal GPU condition when the library or a device is missing.
+uint32_t build_bvh_on_device(int device, const double *vertices, uint32_t n, void *nodes, uint32_t *indexes);
+
 }  // namespace ct
 #endif

@@ -14,6 +14,7 @@
 #include "cobbletrace_host.h"
 #include "ctgpu.h"
 #include "scene_pack.h"
+#include "host_internal.h"
 
 #include <dlfcn.h>
 
@@ -40,6 +41,7 @@ struct GpuApi {
     decltype(&ctgpu_render_begin) render_begin = nullptr;
     decltype(&ctgpu_render_poll) render_poll = nullptr;
     decltype(&ctgpu_device_count) device_count = nullptr;
+    decltype(&ctgpu_build_bvh) build_bvh = nullptr;
 };
 
 [[noreturn]] void die(const char *what, const char *detail) {
@@ -76,6 +78,7 @@ GpuApi &gpu() {
     RESOLVE(render_begin, "ctgpu_render_begin");
     RESOLVE(render_poll, "ctgpu_render_poll");
     RESOLVE(device_count, "ctgpu_device_count");
+    RESOLVE(build_bvh, "ctgpu_build_bvh");
 #undef RESOLVE
     if (api.abi_version() != CTGPU_ABI_VERSION) die("libctgpu.so ABI mismatch", path.c_str());
     return api;
@@ -146,6 +149,13 @@ void camera_matrix(const BossState &b, m3x3_t *m) {
 
 }  // namespace
 
+uint32_t ct::build_bvh_on_device(int device, const double *vertices, uint32_t n, void *nodes, uint32_t *indexes) {
+    uint32_t used = 0;
+    if (gpu().build_bvh(device, vertices, n, (ctgpu_node *)nodes, indexes, &used, nullptr) != CTGPU_OK)
+        die("ctgpu_build_bvh", gpu().last_error());
+    return used;
+}
+
 void RayThreadSetOptions(const ct_raythread_options *opt) {
     if (opt) boss().options = *opt;
 }
@@ -171,7 +181,10 @@ bool RayThread(environment_t *env, scene_t *scene) {
 
     if (!b.initialised) {
         b.packed = new ct::PackedScene();
-        b.packed->build_from(scene);
+        // the tree comes from the GPU that will walk it (ctgpu_build_bvh: the reference's arrays, a few milliseconds for
+        // the dragon instead of the host's 60-150); CT_BVH_DEVICE=0 keeps the host builder
+        const char *where = std::getenv("CT_BVH_DEVICE");
+        b.packed->build_from(scene, !(where && std::atoi(where) == 0), b.options.device);
         // one context per GPU, the scene replicated on each (it is small against 288 GB): the GPUs
         // take the place of the reference's worker threads (raythread.cpp:596-618)
         int visible = 0;

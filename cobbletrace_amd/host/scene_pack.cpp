@@ -1,4 +1,5 @@
 #include "scene_pack.h"
+#include "host_internal.h"
 
 #include <cstddef>
 #include <cstdlib>
@@ -43,7 +44,7 @@ static void build_sphere_tree(PackedScene &p) {
     BuildBVH(&p.sphere_bvh);
 }
 
-static void flatten(PackedScene &p) {
+static void flatten(PackedScene &p, bool on_device = false, int device = 0) {
     const size_t n = p.triangles.size();
     p.vertices.resize(n * 9);
     for (size_t i = 0; i < n; i++) {
@@ -54,11 +55,16 @@ static void flatten(PackedScene &p) {
     std::free(p.bvh.bvhNodes);
     std::free(p.bvh.triangles.indexes);
     p.bvh = InitializeBVHState(p.triangles.data(), (int)n);
-    BuildBVH(&p.bvh);
+    if (on_device && n > 0) {
+        // (BuildBVH also leaves each triangle's centroid in the caller's array, bvh.cpp:110-112: nothing reads it afterwards)
+        p.bvh.nodesUsed = build_bvh_on_device(device, p.vertices.data(), (uint32_t)n, p.bvh.bvhNodes, p.bvh.triangles.indexes);
+    } else {
+        BuildBVH(&p.bvh);
+    }
     p.built = true;
 }
 
-void PackedScene::build_from(const scene_t *scene) {
+void PackedScene::build_from(const scene_t *scene, bool on_device, int device) {
     triangles.clear();
     materials.clear();
     lights.clear();
@@ -88,7 +94,7 @@ void PackedScene::build_from(const scene_t *scene) {
         lights.push_back(g);
     }
     build_sphere_tree(*this);
-    flatten(*this);
+    flatten(*this, on_device, device);
 }
 
 void PackedScene::build_from_vertices(const double *verts, uint32_t n) {

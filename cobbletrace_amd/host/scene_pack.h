@@ -29,8 +29,9 @@ struct PackedScene {
     PackedScene(const PackedScene &) = delete;
     PackedScene &operator=(const PackedScene &) = delete;
 
-    // Gathers the OT_TRIANGLE objects in stack order, builds the BVH, fills the arrays.
-    void build_from(const scene_t *scene);
+    // Gathers the OT_TRIANGLE objects in stack order, builds the BVH, fills the arrays.  on_device: BuildBVH runs
+    // on that GPU (ctgpu_build_bvh, the same arrays) instead of on the host.
+    void build_from(const scene_t *scene, bool on_device = false, int device = 0);
     // Same from bare vertices (n x 9 doubles), default material; used by the BvhTest KAT.
     void build_from_vertices(const double *verts, uint32_t n);
     ctgpu_scene_desc desc() const;

@@ -190,3 +190,15 @@ def test_render_begin_poll(scenes, gpu_ctx):
     fb2 = ctx.render_begin(frame)
     done, _ = ctx.render_poll(wait=True)
     assert done and (fb2 == want).all()
+
+
+def test_host_layer_builds_its_tree_on_the_device(assets, monkeypatch):
+    """CT_BVH_DEVICE=1: the host layer's BuildBVH runs on the GPU (ctgpu_build_bvh) -- same node and index hashes as
+    the host builder's tree (which RayThread does by default: the frame tests above render from a device-built tree)."""
+    path = os.path.join(assets, "scene_import_bunny.json")
+    host_built = ca.HostScene(path)
+    want = (host_built.lib.cth_node_hash(host_built.handle), host_built.lib.cth_index_hash(host_built.handle), host_built.desc.n_nodes)
+    monkeypatch.setenv("CT_BVH_DEVICE", "1")
+    device_built = ca.HostScene(path)
+    got = (device_built.lib.cth_node_hash(device_built.handle), device_built.lib.cth_index_hash(device_built.handle), device_built.desc.n_nodes)
+    assert got == want
