@@ -123,6 +123,7 @@ _GPU_SYMBOLS = {
     "ctgpu_comm_destroy": (C.c_int, [C.c_void_p]),
     "ctgpu_gather_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p]),
     "ctgpu_render_sharded": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.c_int, C.c_void_p, C.c_void_p]),
+    "ctgpu_download_frame": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.c_void_p, C.c_void_p, C.c_void_p]),
     "ctgpu_read_counters": (C.c_int, [C.c_void_p, C.POINTER(Stats)]),
     "ctgpu_trace_rays": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]),
     "ctgpu_trace_rays_packet": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
@@ -420,6 +421,10 @@ class GpuContext:
 
     def render_sharded(self, frame, tile_rows, d_fb_ptr, stream_ptr=None):
         self._check(self.lib.ctgpu_render_sharded(self.handle, C.byref(frame), tile_rows, C.c_void_p(d_fb_ptr or 0),
+                                                  C.c_void_p(stream_ptr or 0)))
+
+    def download_frame(self, frame, d_fb_ptr, host_fb_ptr, stream_ptr=None):
+        self._check(self.lib.ctgpu_download_frame(self.handle, C.byref(frame), C.c_void_p(d_fb_ptr), C.c_void_p(host_fb_ptr),
                                                   C.c_void_p(stream_ptr or 0)))
 
     def read_counters(self):

@@ -789,6 +789,23 @@ extern "C" int ctgpu_assemble(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, con
     return CTGPU_OK;
 }
 
+// the rectangle of the bitmap the reference writes (rendered rows x square columns, clipped: raythread.cpp:176-184,
+// draw2d.h:8-20), device framebuffer -> host framebuffer, asynchronous on `stream`
+extern "C" int ctgpu_download_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, const void *d_fb, uint32_t *host_fb, void *stream) {
+    if (!ctx || !d_fb || !host_fb) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_download_frame: null argument");
+    int rc = check_frame(frame); if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const Geometry g = geometry(frame);
+    const int row_hi = frame->height / 2 + g.half, row_lo = row_hi - (int)g.rendered_rows + 1;
+    const int r0 = std::max(row_lo, 0), r1 = std::min(row_hi, frame->height - 1);
+    const int c0 = std::max(frame->width / 2 - g.half, 0), c1 = std::min(frame->width / 2 + g.half - 1, frame->width - 1);
+    if (r1 < r0 || c1 < c0) return CTGPU_OK;
+    const size_t off = (size_t)r0 * frame->width + c0;
+    HIP_TRY(hipMemcpy2DAsync(host_fb + off, (size_t)frame->width * 4, (const uint32_t *)d_fb + off, (size_t)frame->width * 4,
+                             (size_t)(c1 - c0 + 1) * 4, (size_t)(r1 - r0 + 1), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return CTGPU_OK;
+}
+
 extern "C" int ctgpu_read_counters(ctgpu_ctx *ctx, ctgpu_stats *stats) {
     if (!ctx || !stats) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_read_counters: null argument");
     HIP_TRY(hipSetDevice(ctx->device));

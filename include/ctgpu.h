@@ -242,6 +242,11 @@ int  ctgpu_comm_destroy(ctgpu_ctx *ctx);
 int  ctgpu_gather_tiles(ctgpu_ctx *ctx, const void *d_tiles, uint64_t n, void *d_all, int root, void *stream);
 int  ctgpu_render_sharded(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, int tile_rows, void *d_fb, void *stream);
 
+/* ctgpu_download_frame: the part of the device framebuffer d_fb the reference ever writes (rendered rows x the
+ *   centred square, clipped to the bitmap) -> the same pixels of the caller's host framebuffer, asynchronous on
+ *   `stream` (truly so when host_fb is page-locked).  What ctgpu_render does after assembling. */
+int  ctgpu_download_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, const void *d_fb, uint32_t *host_fb, void *stream);
+
 /* Ray counters accumulated by render calls since the last read (resets them). Synchronises. */
 int  ctgpu_read_counters(ctgpu_ctx *ctx, ctgpu_stats *stats);
 

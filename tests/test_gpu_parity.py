@@ -216,6 +216,17 @@ def test_native_rccl_frame_on_a_world_of_one(scenes, gpu_ctx):
             stream.synchronize()
             ctx.read_counters()
             assert (fb.cpu().numpy().view(np.uint32).reshape(frame.height, frame.width) == want).all()
+            # ctgpu_download_frame: exactly the pixels the reference writes reach the (pinned) host framebuffer
+            host = torch.full((frame.height * frame.width,), 0x55AA55, dtype=torch.int32).pin_memory()
+            ctx.download_frame(frame, fb.data_ptr(), host.data_ptr(), stream.cuda_stream)
+            stream.synchronize()
+            got = host.numpy().view(np.uint32).reshape(frame.height, frame.width)
+            written = want != 0
+            assert (got[written] == want[written]).all()
+            rows, cols = np.nonzero(written)
+            box = np.zeros_like(written)
+            box[rows.min():rows.max() + 1, cols.min():cols.max() + 1] = True
+            assert (got[~box] == 0x55AA55).all()                   # nothing outside the rectangle was touched
     finally:
         ctx.close()
     # two contexts of one process (frames in flight) gather through ONE communicator (ctgpu_comm_share)
