@@ -842,9 +842,14 @@ int begin_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, uint32_t *host_fb
     if (pin && (ctx->pinned_fb != host_fb || ctx->pinned_bytes != fb_bytes)) {
         if (ctx->pinned_fb) (void)hipHostUnregister(ctx->pinned_fb);
         ctx->pinned_fb = nullptr;
-        HIP_TRY(hipHostRegister(host_fb, fb_bytes, hipHostRegisterDefault));
-        ctx->pinned_fb = host_fb;
-        ctx->pinned_bytes = fb_bytes;
+        hipPointerAttribute_t known;
+        const bool already_pinned = hipPointerGetAttributes(&known, host_fb) == hipSuccess && known.type == hipMemoryTypeHost;
+        (void)hipGetLastError();                     // (plain pageable memory makes the query fail: that is the answer)
+        if (!already_pinned) {                       // else the caller page-locked it: nothing to do, nothing to undo later
+            HIP_TRY(hipHostRegister(host_fb, fb_bytes, hipHostRegisterDefault));
+            ctx->pinned_fb = host_fb;
+            ctx->pinned_bytes = fb_bytes;
+        }
     }
 
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));

@@ -190,6 +190,12 @@ def test_render_begin_poll(scenes, gpu_ctx):
     fb2 = ctx.render_begin(frame)
     done, _ = ctx.render_poll(wait=True)
     assert done and (fb2 == want).all()
+    # a framebuffer the caller has page-locked already is taken as it is
+    torch = pytest.importorskip("torch")
+    pinned = torch.zeros(frame.height, frame.width, dtype=torch.int32).pin_memory()
+    fb3 = ctx.render_begin(frame, pinned.numpy().view(np.uint32))
+    done, _ = ctx.render_poll(wait=True)
+    assert done and (fb3 == want).all()
 
 
 def test_host_layer_builds_its_tree_on_the_device(assets, monkeypatch):
