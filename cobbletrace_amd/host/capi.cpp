@@ -230,6 +230,25 @@ int cth_assemble_tiles(const ctgpu_frame_desc *frame, int tile_rows, int part_co
     return 0;
 }
 
+// The same script of ring operations tests run on the reference's eventQueue.cpp (oracle/ref_headers_driver.cpp):
+// op >= 0 -> AddEvent of a key-down with that value; op == -1 -> ReadEvent, value (0xffffffff for NULL) appended.
+uint32_t cth_event_queue_script(uint32_t capacity, const int32_t *ops, uint32_t n, uint32_t *out) {
+    std::vector<event_t> ring(capacity);
+    eventManager_t em{};
+    em.queue = ring.data();
+    em.capacity = capacity;
+    uint32_t written = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        if (ops[i] >= 0) {
+            AddEvent(&em, event_t{ET_KEY_DOWN, EM_NONE, v2_t{0, 0}, (uint32_t)ops[i]});
+        } else {
+            event_t *e = ReadEvent(&em);
+            out[written++] = e ? e->value : 0xffffffffu;
+        }
+    }
+    return written;
+}
+
 void cth_get_rotation(void *p, double rot[9]) { std::memcpy(rot, H(p)->scene.camera.rotation.data, 72); }
 
 uint64_t cth_fnv1a64(const void *data, uint64_t n) {

@@ -16,8 +16,8 @@
  * raythread.cpp:119 is a hard error on g++ 11.  So no oracle/_ref build of the renderer
  * exists, and the reference holds no tests, fixtures or golden vectors of its own.
  * What pins this oracle:
- *   (1) the parts of the reference that DO compile from their own files -- mymath.h and
- *       color.h -- built in place by oracle/Makefile into oracle/_ref/ and compared
+ *   (1) the parts of the reference that DO compile from their own files -- mymath.h,
+ *       color.h (and eventQueue.cpp, against the host layer's event ring) -- built in place by oracle/Makefile into oracle/_ref/ and compared
  *       function by function (tests/test_oracle_vs_ref_headers.py), 5,500 of those
  *       input/output vectors frozen in tests/golden/color_vectors.json;
  *   (2) the countable known answers of the compiled reference that the survey recorded

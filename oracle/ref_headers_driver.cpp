@@ -7,7 +7,9 @@
 // proper does not (see ct_oracle.h).  Output goes to oracle/_ref/ (git-ignored).
 #include <cstdint>
 #include <cmath>
+#include <vector>     // (before the reference's headers: mymath.h defines min / max as macros)
 #include "color.h"      // from -I/root/reference; pulls in mymath.h
+#include "eventQueue.h" // the key-event ring RayThread drains; eventQueue.cpp is compiled in place beside this file
 
 extern "C" {
 
@@ -61,4 +63,24 @@ uint32_t ref_blend_sample(uint32_t color, uint32_t tempColor) {
     return RgbToColor(rgb);
 }
 
+
+// A script of operations on the reference's event ring (eventQueue.cpp:5-24): op >= 0 -> AddEvent of a key-down
+// with that value; op == -1 -> ReadEvent, whose value (0xffffffff for NULL) is appended to out.  Returns the
+// number of values written.
+uint32_t ref_event_queue_script(uint32_t capacity, const int32_t *ops, uint32_t n, uint32_t *out) {
+    std::vector<event_t> ring(capacity);
+    eventManager_t em{};
+    em.queue = ring.data();
+    em.capacity = capacity;
+    uint32_t written = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        if (ops[i] >= 0) {
+            AddEvent(&em, event_t{ET_KEY_DOWN, EM_NONE, v2_t{0, 0}, (uint32_t)ops[i]});
+        } else {
+            event_t *e = ReadEvent(&em);
+            out[written++] = e ? e->value : 0xffffffffu;
+        }
+    }
+    return written;
+}
 }

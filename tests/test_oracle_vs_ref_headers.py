@@ -77,3 +77,26 @@ def test_frozen_colour_vectors():
         assert orc.cto_blend_sample(int(a, 16), int(b, 16)) == int(want, 16)
     for a, b, r, want in data["mix_reflection"]:
         assert orc.cto_mix_reflection(int(a, 16), int(b, 16), r) == int(want, 16)
+
+
+def test_event_ring_against_the_reference_queue():
+    """AddEvent / ReadEvent of the host layer (host/event_queue.cpp) against the reference's eventQueue.cpp compiled in
+    place: random scripts of key-downs and reads on small rings, overflowing ones included (the reference has no
+    overflow protection: a full ring overwrites its oldest entries and `active` keeps counting)."""
+    import cobbletrace_amd as ca
+    ref = _ref()
+    host = ca.host_library()
+    rng = np.random.default_rng(12)
+    for trial in range(300):
+        capacity = int(rng.integers(1, 9))
+        n = int(rng.integers(1, 60))
+        # reads are frequent enough that `active` rarely exceeds the capacity by much, but it does happen
+        ops = np.where(rng.random(n) < 0.55, rng.integers(0, 1000, n), -1).astype(np.int32)
+        # the reference reads slots that were never written when `active` overran a wrapped ring; both sides start
+        # from zeroed storage, so those reads agree as well
+        out_ref = np.zeros(n, dtype=np.uint32)
+        out_host = np.zeros(n, dtype=np.uint32)
+        k_ref = ref.ref_event_queue_script(capacity, ops.ctypes.data_as(C.c_void_p), n, out_ref.ctypes.data_as(C.c_void_p))
+        k_host = host.cth_event_queue_script(capacity, ops.ctypes.data, n, out_host.ctypes.data)
+        assert k_ref == k_host == int((ops < 0).sum())
+        assert (out_ref[:k_ref] == out_host[:k_host]).all(), (capacity, ops.tolist())
