@@ -93,3 +93,22 @@ def test_product_never_touches_the_oracle():
                     if re.search(r"#include\s*[\"<][^\">]*oracle|\bimport\s+oracle|\bfrom\s+oracle|libctoracle|\bcto_[a-z]", text):
                         offenders.append(os.path.join(dirpath, name))
     assert not offenders, offenders
+
+
+def test_host_library_exports_the_reference_boundary():
+    """libcthost.so carries every entry point include/cobbletrace_host.h declares, with the reference's C++
+    signatures (mangled names), so that the reference's own main() links against it."""
+    import subprocess
+    header = open(os.path.join(ROOT, "include", "cobbletrace_host.h")).read()
+    header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    declared = set(re.findall(r"^(?:bool|void|uint64_t|bvh_state_t|event_t \*)\s*\*?([A-Z][A-Za-z]+)\(", header, flags=re.M))
+    assert {"RayThread", "InitSceneData", "ParseSceneFile", "ImportObject", "InitializeBVHState", "BuildBVH", "ReadEvent",
+            "AddEvent", "Blit", "RayThreadSetOptions", "RayThreadReset", "RayThreadBusy"} <= declared
+    out = subprocess.run(["nm", "-D", "--defined-only", "--demangle", bindings.host_library_path()], capture_output=True,
+                         text=True, check=True).stdout
+    exported = set(re.findall(r" T ([A-Za-z_]+)\(", out))
+    assert declared <= exported, sorted(declared - exported)
+    # the signatures the reference calls with
+    for signature in ("RayThread(environment_t*, scene_t*)", "ParseSceneFile(char*, scene_t*)", "Blit(environment_t*)",
+                      "AddEvent(eventManager_t*, event_t)", "BuildBVH(bvh_state_t*)"):
+        assert signature in out, signature
