@@ -30,6 +30,12 @@ while time.time() < t_end:
         tris.append({"type": "triangle", "p1": [float("%.6g" % v) for v in p[0]], "p2": [float("%.6g" % v) for v in p[1]],
                      "p3": [float("%.6g" % v) for v in p[2]], "color": [int(v) for v in rng.integers(0, 256, 3)],
                      "specular": int(rng.choice([-1, 1, 10, 100, 1000])), "reflection": float(rng.choice([0, 0, 0, 0.3]))})
+    use_spheres = rng.random() < 0.3
+    if use_spheres:
+        for _ in range(int(rng.integers(1, 6))):
+            tris.append({"type": "sphere", "center": [float("%.6g" % v) for v in rng.normal(size=3) * scale],
+                         "radius": float("%.4g" % (scale * rng.choice([0.05, 0.4, 1.5]))), "color": [int(v) for v in rng.integers(0, 256, 3)],
+                         "specular": int(rng.choice([-1, 10, 500])), "reflection": float(rng.choice([0, 0.4]))})
     lights = [{"type": "ambient", "intensity": float("%.3g" % rng.uniform(0, 0.5))}]
     for _ in range(int(rng.integers(0, 4))):
         if rng.random() < 0.5:
@@ -51,7 +57,10 @@ while time.time() < t_end:
     ctx.upload(scene.desc)
     angles = [np.float32(a) for a in rng.uniform(-0.6, 0.6, 3)] if rng.random() < 0.5 else [np.float32(0)] * 3
     w, h = int(rng.choice([64, 97, 160])), int(rng.choice([48, 64, 121]))
-    frame = scene.frame(w, h, rotation=oracle.camera_rotation(*angles), rng_seed=seed)
+    frame = scene.frame(w, h, rotation=oracle.camera_rotation(*angles), rng_seed=seed, spheres=use_spheres,
+                        reflect_fix=bool(rng.random() < 0.3), rng_mode=(ca.RNG_LIBC if rng.random() < 0.2 else ca.RNG_HASH))
+    if frame.rng_mode == ca.RNG_LIBC:
+        frame.rng_seed = int(rng.integers(1, 1000))
     got, st = ctx.render(frame)
     want, _ = oracle.render(scene.desc, frame, os_threads=4)
     shifts = np.array([0, 8, 16])
@@ -79,8 +88,8 @@ while time.time() < t_end:
     n_scenes += 1
     n_frames += 1
     n_rays += 3 * m
-    print("seed %d: %d triangles, scale %g, %dx%d ss=%d sub=%d lights %d: max diff %d, %d px differ, rays %s" %
-          (seed, n, scale, w, h, bool(frame.flags & 1), bool(frame.flags & 2), len(lights), diff, int((got != want).sum()),
+    print("seed %d: %d triangles, scale %g, %dx%d ss=%d sub=%d flags %d rng %d lights %d: max diff %d, %d px differ, rays %s" %
+          (seed, n, scale, w, h, bool(frame.flags & 1), bool(frame.flags & 2), frame.flags >> 2, frame.rng_mode, len(lights), diff, int((got != want).sum()),
            "equal" if ray_ok else "DIFFER"), flush=True)
     if not ok or not ray_ok:
         print("MISMATCH at seed %d (scene kept in %s)" % (seed, path))
