@@ -886,6 +886,9 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                 const bool mine = __builtin_amdgcn_inverse_ballot_w64(mask);
                 PK_T0();
                 uint32_t count = 1;        // the first record says how many the leaf holds
+#ifdef CT_SKIP_LEAF_KIND                   // diagnostic build: the walk alone, no triangle is loaded or tested
+                if (KIND == CT_SKIP_LEAF_KIND) count = 0;
+#endif
                 for (uint32_t k = 0; k < count; k++) {
                     const ScalarTri tr = scalar_load_tri(P.tris + first + k);
                     if (k == 0) {
