@@ -381,7 +381,9 @@ def main():
                                    "(counted by the kernel) + its per-sample / per-ray arrays",
                     "per_launch": {"rays": int(per_launch_shadow if dom == 3 else per_launch_primary),
                                    "packets": int(packets[1 if dom == 3 else 0]), "quad_nodes": int(quads[1 if dom == 3 else 0]),
-                                   "triangle_records": int(records[1 if dom == 3 else 0])},
+                                   "triangle_records": int(records[1 if dom == 3 else 0]),
+                                   "shadow_rays_blocked": int(sum(w.shadow_rays_blocked for w in works) / n_launch),
+                                   "shadow_packets_all_blocked": int(sum(w.shadow_packets_all_blocked for w in works) / n_launch)},
                     "kernels": kernels}
         if work is not None:
             ref_bytes = (work.node_visits * B_NODE + work.triangle_tests * B_TRI + (work.rays_shadow // 2) * B_HIT

@@ -71,7 +71,8 @@ class Stats(C.Structure):
 
 
 class WalkWork(C.Structure):
-    _fields_ = [("packets", C.c_uint64 * 2), ("quad_nodes", C.c_uint64 * 2), ("triangle_records", C.c_uint64 * 2)]
+    _fields_ = [("packets", C.c_uint64 * 2), ("quad_nodes", C.c_uint64 * 2), ("triangle_records", C.c_uint64 * 2),
+                ("shadow_rays_blocked", C.c_uint64), ("shadow_packets_all_blocked", C.c_uint64)]
 
 
 class KernelTimes(C.Structure):

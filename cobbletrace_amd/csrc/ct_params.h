@@ -88,7 +88,8 @@ struct PipelineParams {
     int32_t  thresh_r, thresh_a, thresh_b;
     uint32_t keep_every_shadow_ray;   // 1: ct_light_gate passes every hit sample's shadow rays (CTGPU_KEEP_SHADOW_RAYS)
     unsigned long long *walk_work;    // [64 slots][8]: {packets, QuadNodes fetched, triangle records fetched} of the primary
-                                      // walk in words 0..2, of the shadow walk in words 3..5 (packet walk only)
+                                      // walk in words 0..2, of the shadow walk in words 3..5 (packet walk only); word 6: shadow
+                                      // rays that found a blocker, word 7: shadow packets whose every ray did
     const ctgpu_ray *ray_list;   // ctgpu_trace_rays_packet: the caller's rays (n_samples of them) ...
     ctgpu_hit *ray_hits;         // ... and where their results go
 };

@@ -733,6 +733,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
     // what this wave asked the memory system for: packets walked, QuadNodes (128 B each) and triangle
     // records (80 B each) fetched -- the kernel's own bytes of the roofline (ctgpu_read_walk_work)
     uint32_t n_packets = 0, n_quads = 0, n_records = 0;
+    uint32_t n_blocked = 0, n_all_blocked = 0;     // shadow walk: rays that found a blocker, packets whose every ray did
 #ifdef CT_WALK_STATS
     unsigned long long pk_n[6] = {0, 0, 0, 0, 0, 0}, pk_cyc[3] = {0, 0, 0};
     const unsigned long long pk_begin = __builtin_amdgcn_s_memtime();
@@ -1060,6 +1061,11 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
         }   // passes
 
         // ---------------- retire the packet
+        if (KIND == 1) {
+            const unsigned long long rays = __ballot(has_ray), blocked = __ballot(has_ray && t != kNoHit);
+            n_blocked += (uint32_t)__popcll(blocked);
+            n_all_blocked += (blocked == rays) ? 1u : 0u;
+        }
         if (has_ray) {
             if (LIST) {
                 ctgpu_hit h;
@@ -1088,6 +1094,10 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
         atomicAdd(work + 0, (unsigned long long)n_packets);
         atomicAdd(work + 1, (unsigned long long)n_quads);
         atomicAdd(work + 2, (unsigned long long)n_records);
+        if (KIND == 1) {
+            atomicAdd(W.walk_work + (size_t)(blockIdx.x & 63u) * 8u + 6u, (unsigned long long)n_blocked);
+            atomicAdd(W.walk_work + (size_t)(blockIdx.x & 63u) * 8u + 7u, (unsigned long long)n_all_blocked);
+        }
     }
 }
 #undef RAY_O

@@ -1139,6 +1139,10 @@ extern "C" int ctgpu_read_walk_work(ctgpu_ctx *ctx, ctgpu_walk_work *out) {
             out->quad_nodes[k] += w[slot * 8 + k * 3 + 1];
             out->triangle_records[k] += w[slot * 8 + k * 3 + 2];
         }
+    for (int slot = 0; slot < 64; slot++) {
+        out->shadow_rays_blocked += w[slot * 8 + 6];
+        out->shadow_packets_all_blocked += w[slot * 8 + 7];
+    }
     return CTGPU_OK;
 }
 

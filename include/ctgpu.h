@@ -281,7 +281,10 @@ int  ctgpu_build_bvh(int device, const double *vertices, uint32_t n, ctgpu_node 
  * ctgpu_kernel_timing / ctgpu_read_kernel_times: HIP events on the frame's own stream around every kernel of the
  *   fast path, for every frame rendered while enabled; read = synchronise on them, sum, reset. */
 #define CTGPU_PIPELINE_KERNELS 5       /* ct_sample_grid, primary walk, ct_light_gate, shadow walk, ct_shade */
-typedef struct ctgpu_walk_work { uint64_t packets[2], quad_nodes[2], triangle_records[2]; } ctgpu_walk_work;
+typedef struct ctgpu_walk_work {
+    uint64_t packets[2], quad_nodes[2], triangle_records[2];
+    uint64_t shadow_rays_blocked, shadow_packets_all_blocked;      /* shadow walk: rays that found a blocker; packets whose every ray did */
+} ctgpu_walk_work;
 typedef struct ctgpu_kernel_times { uint64_t launches[CTGPU_PIPELINE_KERNELS]; double total_ms[CTGPU_PIPELINE_KERNELS]; } ctgpu_kernel_times;
 int  ctgpu_read_walk_work(ctgpu_ctx *ctx, ctgpu_walk_work *out);
 int  ctgpu_kernel_timing(ctgpu_ctx *ctx, int enable);
