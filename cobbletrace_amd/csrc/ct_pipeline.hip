@@ -38,7 +38,8 @@ namespace {
 
 constexpr int kWave = 64;
 #ifndef CT_PACKET_WAVES
-#define CT_PACKET_WAVES 6    // the packet walk needs fewer registers: six waves per SIMD (80 VGPRs)
+#define CT_PACKET_WAVES 7    // seven waves per SIMD (72 VGPRs): dragon frame 3.24 -> 3.12 ms in bench.py (A/B, three runs each);
+                             // bunny +1 %, single-sample frames +2 %; 5: +5 %, 8: +2 % (6 was round 1's choice)
 #endif
 #ifndef CT_WALK_WAVES
 #define CT_WALK_WAVES 5      // waves per SIMD the traversal kernel is register-budgeted for
