@@ -198,6 +198,20 @@ __device__ __forceinline__ void slab_approx(const d3 &o, const d3 &inv, const do
     tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx1, tx2), __builtin_fmaxf(ty1, ty2)), __builtin_fmaxf(tz1, tz2));
 }
 
+// The same with ZERO direction components allowed (inv = +-inf there, the sign of the zero): on such an
+// axis (b - o) * inv is the reference's (b - o) / d exactly -- the same infinity -- unless b == o, where both
+// are NaN.  Returns true when one of the six parameters is a NaN: the caller then takes the reference's own
+// operation sequence (the macros' NaN behaviour depends on operand order, slab_in_sequence).
+__device__ __forceinline__ bool slab_approx_checked(const d3 &o, const d3 &inv, const double *bmin, const double *bmax,
+                                                    float &tmin, float &tmax) {
+    const float tx1 = (float)((bmin[0] - o.x) * inv.x), tx2 = (float)((bmax[0] - o.x) * inv.x);
+    const float ty1 = (float)((bmin[1] - o.y) * inv.y), ty2 = (float)((bmax[1] - o.y) * inv.y);
+    const float tz1 = (float)((bmin[2] - o.z) * inv.z), tz2 = (float)((bmax[2] - o.z) * inv.z);
+    tmin = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx1, tx2), __builtin_fminf(ty1, ty2)), __builtin_fminf(tz1, tz2));
+    tmax = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx1, tx2), __builtin_fmaxf(ty1, ty2)), __builtin_fmaxf(tz1, tz2));
+    return __builtin_isunordered(tx1, tx2) | __builtin_isunordered(ty1, ty2) | __builtin_isunordered(tz1, tz2);
+}
+
 // position of a float in the ordered set of floats (-0 and +0 are neighbours; NaNs lie
 // beyond the infinities, where no margin test is ever "close")
 __device__ __forceinline__ int32_t float_ordinal(float x) {
@@ -338,6 +352,15 @@ __device__ __forceinline__ bool direction_allows_fast_slab(const d3 &d) {
     auto ok = [](double c) {
         const uint32_t e = ((uint32_t)__double2hiint(c) >> 20) & 0x7FFu;
         return e > 23u && e < 2023u;                    // |c| in [2^-999, 2^1000): finite, normal, non-zero
+    };
+    return ok(d.x) && ok(d.y) && ok(d.z);
+}
+
+// the same, zero components allowed (slab_approx_checked): every component is zero or finite and normal
+__device__ __forceinline__ bool direction_allows_checked_slab(const d3 &d) {
+    auto ok = [](double c) {
+        const uint32_t e = ((uint32_t)__double2hiint(c) >> 20) & 0x7FFu;
+        return (e > 23u && e < 2023u) || c == 0.0;
     };
     return ok(d.x) && ok(d.y) && ok(d.z);
 }

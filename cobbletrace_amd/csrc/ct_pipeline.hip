@@ -341,10 +341,11 @@ __device__ __forceinline__ void step_exact(Walker &w, const WideNode *__restrict
 // estimate), the result is within a few ulp_D of 1/d -- the bound Appendix A of DESIGN.md needs is
 // merely "far below 2^-24".
 __device__ __forceinline__ double quick_reciprocal(double d) {
-    double x = __builtin_amdgcn_rcp(d);
+    const double seed = __builtin_amdgcn_rcp(d);
+    double x = seed;
     x = __builtin_fma(__builtin_fma(-d, x, 1.0), x, x);     // x + x * (1 - d * x)
     x = __builtin_fma(__builtin_fma(-d, x, 1.0), x, x);
-    return x;
+    return d == 0.0 ? seed : x;                              // 1 / +-0 = +-inf (the Newton step would make it a NaN)
 }
 
 __device__ __forceinline__ void begin_ray(Walker &w, const FrameParams &P) {
@@ -689,6 +690,23 @@ struct PacketStack {
     }
 };
 
+#ifdef CT_PACKET_TRACE
+// diagnostic build (tools/packet_trace.py): one record per walked packet -- who, when, how much
+__device__ unsigned long long ct_packet_trace[5u << 20];
+__device__ unsigned int ct_packet_trace_n;
+extern "C" __attribute__((visibility("default"))) int ctgpu_debug_packet_trace(unsigned long long *out, unsigned int max_records, unsigned int *n) {
+    unsigned int count = 0;
+    if (hipMemcpyFromSymbol(&count, HIP_SYMBOL(ct_packet_trace_n), sizeof count) != hipSuccess) return -2;
+    if (count > (1u << 20)) count = 1u << 20;
+    if (count > max_records) count = max_records;
+    if (count && hipMemcpyFromSymbol(out, HIP_SYMBOL(ct_packet_trace), (size_t)count * 5 * 8) != hipSuccess) return -2;
+    const unsigned int zero = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(ct_packet_trace_n), &zero, sizeof zero) != hipSuccess) return -2;
+    *n = count;
+    return 0;
+}
+#endif
+
 // KIND 0  primary rays of the frame            (closest hit -> hits[])
 // KIND 1  shadow rays of the frame             (any hit     -> shadow bytes)
 // KIND 2  caller's ray list, closest hit       (-> ctgpu_hit; the per-ray test hook ctgpu_trace_rays_packet:
@@ -813,6 +831,11 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
             continue;
         }
         n_packets += 1;
+#ifdef CT_PACKET_TRACE
+        const unsigned long long trace_begin = wall_clock64();
+        const uint32_t trace_quads = n_quads, trace_records = n_records;
+        const uint32_t trace_rays = (uint32_t)__popcll(__ballot(has_ray));
+#endif
         // phase 2 (once per packet, all its lanes together): the rays themselves
         if (has_ray) {
             float t_start = kNoHit;
@@ -846,8 +869,8 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
             if (!positive_t) { rf.inv_z_e2.y = __builtin_inff(); rf.noi_z_e.y = __builtin_inff(); }
             // root box (bvh.cpp:205 at rootNodeIdx)
             float tmin, tmax;
-            slab_approx(RAY_O, inv, P.root_min, P.root_max, tmin, tmax);
-            if (!(box_verdict_positive_t(tmin, tmax, t, root_pass) & direction_allows_fast_slab(d) & positive_t)) {
+            const bool root_nan = slab_approx_checked(RAY_O, inv, P.root_min, P.root_max, tmin, tmax);
+            if (!(box_verdict_positive_t(tmin, tmax, t, root_pass) & direction_allows_checked_slab(d) & positive_t & !root_nan)) {
                 slab(RAY_O, d, P.root_min, P.root_max, tmin, tmax);
                 root_pass = tmax >= tmin && tmin < t && tmax > 0;
             }
@@ -974,7 +997,9 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
 #pragma unroll
                     for (int k = 0; k < 4; k++) todo |= __builtin_amdgcn_inverse_ballot_w64(unsure_of[k]) ? (1u << k) : 0u;
                     if (todo != 0u) {
-                        const bool fast = direction_allows_fast_slab(d) && (!LIST || t > 0.0f);
+                        // (a zero direction component is fine here: its parameters are the reference's own
+                        //  infinities, and the 0 * inf of an origin on a box plane is seen and sent on)
+                        const bool fast = direction_allows_checked_slab(d) && (!LIST || t > 0.0f);
 #pragma nounroll
                         for (uint32_t k = 0; k < n_entries; k++) {
                             if (((todo >> k) & 1u) == 0u) continue;
@@ -983,8 +1008,8 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                             const d3 inv = make_d3(quick_reciprocal(d.x), quick_reciprocal(d.y), quick_reciprocal(d.z));
                             float tmin64, tmax64;
                             bool verdict;
-                            slab_approx(RAY_O, inv, bmin, bmax, tmin64, tmax64);
-                            if (!(box_verdict_positive_t(tmin64, tmax64, t, verdict) & fast)) {
+                            const bool some_nan = slab_approx_checked(RAY_O, inv, bmin, bmax, tmin64, tmax64);
+                            if (!(box_verdict_positive_t(tmin64, tmax64, t, verdict) & fast & !some_nan)) {
                                 const bool nan_parameter = slab_in_sequence(RAY_O, d, bmin, bmax, tmin64, tmax64);
                                 if (walk_pass == 0) redo |= nan_parameter;      // only the folded walk gives rays up
                                 verdict = tmax64 >= tmin64 && tmin64 < t && tmax64 > 0;
@@ -1044,13 +1069,21 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                 if (__builtin_amdgcn_inverse_ballot_w64(pushed)) {
                     const float tmin = st.get_tmin(sp, lane);          // the filter's tmin, good to M(tmin)
                     if (!deferred_verdict_f32(tmin, rf.noi_z_e.y, t, keep)) {
-                        // too close to ray.t to trust: the whole test, exactly
+                        // too close to ray.t to trust (or a ray the filter does not take: e = inf): tmin from
+                        // the binary64 box, one step off at most -- and if that is still too close, the whole
+                        // test exactly
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                         const uint32_t source = quad_source[st.parent[sp]];
                         const double *bmin = P.nodes[source >> 1].lmin + (source & 1u) * 6u;
+                        const d3 inv = make_d3(quick_reciprocal(d.x), quick_reciprocal(d.y), quick_reciprocal(d.z));
                         float etmin, etmax;
-                        (void)slab_in_sequence(RAY_O, d, bmin, bmin + 3, etmin, etmax);      // (a NaN here was seen at push time)
-                        keep = etmax >= etmin && etmin < t && etmax > 0;
+                        const bool some_nan = slab_approx_checked(RAY_O, inv, bmin, bmin + 3, etmin, etmax);
+                        const bool near_t = ordinals_near(__float_as_int(etmin), __float_as_int(t), 2u);
+                        keep = etmin < t;        // (tmax >= tmin and tmax > 0 held when the entry was pushed)
+                        if (some_nan | near_t | !direction_allows_checked_slab(d) | (LIST && !(t > 0.0f))) {
+                            (void)slab_in_sequence(RAY_O, d, bmin, bmin + 3, etmin, etmax);  // (a NaN here was seen at push time)
+                            keep = etmax >= etmin && etmin < t && etmax > 0;
+                        }
                     }
                 }
                 mask = __ballot(keep);
@@ -1062,6 +1095,19 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
         }   // passes
 
         // ---------------- retire the packet
+#ifdef CT_PACKET_TRACE
+        if (lane == 0 && !LIST) {
+            const unsigned int at = atomicAdd(&ct_packet_trace_n, 1u);
+            if (at < (1u << 20)) {
+                unsigned long long *rec = ct_packet_trace + (size_t)at * 5;
+                rec[0] = ((unsigned long long)KIND << 56) | ((unsigned long long)blockIdx.x << 32) | trace_rays;
+                rec[1] = trace_begin;
+                rec[2] = wall_clock64();
+                rec[3] = ((unsigned long long)(n_quads - trace_quads) << 32) | (n_records - trace_records);
+                rec[4] = (KIND == 0) ? packet_base : (unsigned long long)redo;
+            }
+        }
+#endif
         if (KIND == 1) {
             const unsigned long long rays = __ballot(has_ray), blocked = __ballot(has_ray && t != kNoHit);
             n_blocked += (uint32_t)__popcll(blocked);

@@ -830,6 +830,50 @@ def test_closest_hit_exact_through_the_packet_walk(name, scenes, gpu_ctx):
         assert (shadowed["found"] == _oracle().trace_rays(scene.desc, fresh)["found"]).all(), what
 
 
+@pytest.mark.parametrize("name", ["import", "bunny"])
+def test_rays_with_zero_direction_components(name, scenes, gpu_ctx):
+    """Axis-parallel and plane-parallel rays (one or two direction components +0 or -0): the reference's box
+    parameters on such an axis are infinities -- or NaNs when the origin lies exactly on a box plane.  The packet
+    walk decides these from the binary32 planes where it can (origin strictly inside / outside), from the
+    binary64 boxes where the roundings coincide, and by the reference's own divisions for the NaNs.  Origins:
+    random; exactly on vertex coordinates (= planes of leaf boxes: NaNs); one binary64 step beside them (same
+    binary32 value: the filter cannot tell the side); whole packets of them and single ones among ordinary rays."""
+    scene, ctx = scenes(name), gpu_ctx(name)
+    rng = np.random.default_rng(77)
+    v = scene.vertices().reshape(-1, 3)
+    lo, hi = v.min(0), v.max(0)
+    n = 120_000
+    rays = np.zeros(n, dtype=ca.bindings.RAY_DTYPE)
+    origin = lo + rng.random((n, 3)) * (hi - lo)                  # inside the mesh's bound: inside many boxes
+    origin[: n // 3] += rng.normal(size=(n // 3, 3)) * (hi - lo)  # and outside
+    target = lo + rng.random((n, 3)) * (hi - lo)
+    direction = target - origin
+    axes = rng.integers(0, 3, n)
+    zero = np.where(rng.random(n) < 0.5, 0.0, -0.0)
+    direction[np.arange(n), axes] = zero                          # one zero component, +0 or -0
+    second = rng.random(n) < 0.2
+    direction[second, (axes[second] + 1) % 3] = 0.0               # a fifth: two of them
+    # origins on planes: a vertex coordinate on the ray's zero axis (and sometimes on another axis too)
+    on_plane = rng.random(n) < 0.4
+    pick = v[rng.integers(0, len(v), n)]
+    origin[on_plane, axes[on_plane]] = pick[on_plane, axes[on_plane]]
+    beside = on_plane & (rng.random(n) < 0.5)                     # ... or the neighbouring double
+    origin[beside, axes[beside]] = np.nextafter(origin[beside, axes[beside]], np.where(rng.random(beside.sum()) < 0.5, -np.inf, np.inf))
+    ordinary = rng.random(n) < 0.3                                # ordinary rays among them (the tail of the list)
+    ordinary[: n // 2] = False
+    direction[ordinary] = (target - origin)[ordinary]
+    rays["origin"], rays["direction"], rays["t"] = origin, direction, np.float32(1e30)
+    got = ctx.trace_rays_packet(rays)
+    want = _oracle().trace_rays(scene.desc, rays)
+    for field in ("found", "triangle"):
+        assert (got[field] == want[field]).all(), field
+    assert (got["t"].view(np.uint32) == want["t"].view(np.uint32)).all()
+    assert (got["tclosest"].view(np.uint32) == want["tclosest"].view(np.uint32)).all()
+    assert want["found"].sum() > n // 20
+    shadowed = ctx.trace_rays_packet(rays, any_hit=True)
+    assert (shadowed["found"] == want["found"]).all()
+
+
 @pytest.mark.parametrize("name,w,h", [("bunny", 320, 180), ("import", 256, 144)])
 def test_random_views(name, w, h, scenes, gpu_ctx):
     """Many camera orientations and positions (every direction component non-zero, so the binary32
