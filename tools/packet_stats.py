@@ -10,7 +10,7 @@ A = os.path.join(os.path.dirname(__file__), "..", "assets")
 for name in (sys.argv[1:] or ["dragon"]):
     scene = ca.HostScene(os.path.join(A, "scene_import_%s.json" % name))
     ctx = ca.GpuContext(0); ctx.upload(scene.desc)
-    f = scene.frame(1920, 1080, supersampling=os.environ.get("SS", "1") != "0")
+    f = scene.frame(int(os.environ.get("W", 1920)), int(os.environ.get("H", 1080)), supersampling=os.environ.get("SS", "1") != "0")
     fb, st = ctx.render(f)
     print("%s rays %d kernel %.2f ms" % (name, st.rays, st.kernel_ms))
     ctx.close()
