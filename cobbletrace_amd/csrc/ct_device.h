@@ -36,8 +36,8 @@ static_assert(sizeof(WideNode) == 128, "WideNode must be one 128-byte line");
 // in the reference's arithmetic, ray.t only shrinks, and hence g passes => c passed; g's own test
 // is the one the reference makes on entering g.  Half as many dependent fetches per ray.
 // Planes are rounded to binary32 -- they only FILTER: a verdict taken from them carries an error
-// bound (box_verdict_f32 below) and anything inside the bound is redone from the WideNode the
-// entry came from (quad_source[]).
+// bound (box_verdict_f32 below) and anything inside the bound is redone from the entry's binary64 box
+// (quad_boxes[]: the six doubles of the reference's node, 48 bytes per entry, one dependent fetch).
 struct alignas(128) QuadNode {
     float plane[4][3][2];         // [entry][axis]{min, max}: one packed fma serves both planes of an axis
     uint32_t ref[4];              // entry: kLeafBit | first TriRecord slot, or a QuadNode index

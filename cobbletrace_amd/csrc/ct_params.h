@@ -19,10 +19,10 @@ struct FrameParams {
     // scene (device pointers)
     const WideNode  *nodes;
     const QuadNode  *quads;       // the tree folded to four-wide nodes, binary32 planes (packet walk)
-    const uint32_t  *quad_source; // [quad][entry] WideNode index * 2 + side: where that entry's binary64 box is
+    const double    *quad_boxes;  // [quad][entry][6] the entries' binary64 boxes (min xyz, max xyz): levels 1 and 2
     uint32_t quad_root;           // root reference of the folded tree (a leaf reference for a one-leaf tree)
     const QuadNode  *quads_flat;  // the same tree with nothing folded (two entries per node): second pass of
-    const uint32_t  *quad_source_flat;   // the packet walk, for rays folding is not proven for
+    const double    *quad_boxes_flat;    // the packet walk, for rays folding is not proven for
     uint32_t quad_root_flat;
     const TriRecord *tris;
     const Material  *materials;

@@ -884,7 +884,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
         // over the same tree UNFOLDED (two entries per node, the reference's own structure).
         for (int walk_pass = 0; walk_pass < 2; walk_pass++) {
         const QuadNode *quads = walk_pass == 0 ? P.quads : P.quads_flat;
-        const uint32_t *quad_source = walk_pass == 0 ? P.quad_source : P.quad_source_flat;
+        const double *quad_boxes = walk_pass == 0 ? P.quad_boxes : P.quad_boxes_flat;
         if (walk_pass == 1) {
             const unsigned long long again = __ballot(redo);
             if (again == 0ull) break;
@@ -1003,8 +1003,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
 #pragma nounroll
                         for (uint32_t k = 0; k < n_entries; k++) {
                             if (((todo >> k) & 1u) == 0u) continue;
-                            const uint32_t source = quad_source[node_id * 4u + k];
-                            const double *bmin = P.nodes[source >> 1].lmin + (source & 1u) * 6u, *bmax = bmin + 3;
+                            const double *bmin = quad_boxes + (size_t)(node_id * 4u + k) * 6u, *bmax = bmin + 3;
                             const d3 inv = make_d3(quick_reciprocal(d.x), quick_reciprocal(d.y), quick_reciprocal(d.z));
                             float tmin64, tmax64;
                             bool verdict;
@@ -1073,8 +1072,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                         // the binary64 box, one step off at most -- and if that is still too close, the whole
                         // test exactly
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                        const uint32_t source = quad_source[st.parent[sp]];
-                        const double *bmin = P.nodes[source >> 1].lmin + (source & 1u) * 6u;
+                        const double *bmin = quad_boxes + (size_t)st.parent[sp] * 6u;
                         const d3 inv = make_d3(quick_reciprocal(d.x), quick_reciprocal(d.y), quick_reciprocal(d.z));
                         float etmin, etmax;
                         const bool some_nan = slab_approx_checked(RAY_O, inv, bmin, bmin + 3, etmin, etmax);

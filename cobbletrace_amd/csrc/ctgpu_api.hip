@@ -69,7 +69,7 @@ struct ctgpu_ctx {
 
     DeviceArray<WideNode> nodes;
     DeviceArray<QuadNode> quads, quads_flat;
-    DeviceArray<uint32_t> quad_source, quad_source_flat;
+    DeviceArray<double> quad_boxes, quad_boxes_flat;      // [quad][entry][6]: the entries' binary64 boxes
     uint32_t quad_root = 0, quad_root_flat = 0, quad_pending = 1;
     float plane_bound[3] = {0, 0, 0};
     DeviceArray<TriRecord> tris;
@@ -246,7 +246,7 @@ extern "C" void ctgpu_destroy(ctgpu_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     (void)ctgpu_comm_destroy(ctx);
     ctgpu_multi_comms_release(ctx->multi_comms);
-    ctx->nodes.release(); ctx->quads.release(); ctx->quad_source.release(); ctx->quads_flat.release(); ctx->quad_source_flat.release(); ctx->tris.release(); ctx->materials.release(); ctx->lights.release();
+    ctx->nodes.release(); ctx->quads.release(); ctx->quad_boxes.release(); ctx->quads_flat.release(); ctx->quad_boxes_flat.release(); ctx->tris.release(); ctx->materials.release(); ctx->lights.release();
     ctx->tiles.release(); ctx->fb.release(); ctx->gathered.release(); ctx->counters.release(); ctx->overflow.release();
     ctx->rand_table.release(); ctx->row_ordinal.release();
     ctx->coords.release(); ctx->hits.release(); ctx->shadow.release(); ctx->queue.release(); ctx->spill.release();
@@ -332,7 +332,7 @@ extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
         }
         return true;
     };
-    struct Folded { std::vector<QuadNode> quads; std::vector<uint32_t> source; uint32_t root = kLeafBit | 0u, pending = 1; };
+    struct Folded { std::vector<QuadNode> quads; std::vector<double> boxes; uint32_t root = kLeafBit | 0u, pending = 1; };
     // fold = true: the tree the packet walk uses; fold = false: the same structure with nothing folded
     // (two entries per node), walked a second time by rays folding is not proven for (DESIGN B2)
     auto build_quads = [&](bool fold, Folded &out) -> bool {
@@ -349,13 +349,14 @@ extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
             const uint32_t head = quad_head[q];
             QuadNode node;
             std::memset(&node, 0, sizeof node);
-            uint32_t source[4] = {0, 0, 0, 0};
+            double boxes[4][6] = {};
             auto add = [&](uint32_t id, uint32_t parent, uint32_t side) {
+                (void)parent; (void)side;
                 const ctgpu_node &e = s->nodes[id];
                 const uint32_t k = node.count++;
                 for (int a = 0; a < 3; a++) { node.plane[k][a][0] = (float)e.bmin[a]; node.plane[k][a][1] = (float)e.bmax[a]; }
                 node.ref[k] = e.count ? (kLeafBit | e.first) : quad_for(id);
-                source[k] = wide_of[parent] * 2u + side;
+                for (int a = 0; a < 3; a++) { boxes[k][a] = e.bmin[a]; boxes[k][3 + a] = e.bmax[a]; }
             };
             for (uint32_t side = 0; side < 2; side++) {
                 const uint32_t c = s->nodes[head].left + side;
@@ -366,7 +367,7 @@ extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
             for (uint32_t k = node.count; k < 4; k++)
                 for (int a = 0; a < 3; a++) node.plane[k][a][0] = node.plane[k][a][1] = ctx->plane_bound[a];
             out.quads.push_back(node);
-            out.source.insert(out.source.end(), source, source + 4);
+            out.boxes.insert(out.boxes.end(), &boxes[0][0], &boxes[0][0] + 24);
         }
         // most entries ever waiting on the packet walk's stack: along a path, every QuadNode leaves count-1 behind
         if (!out.quads.empty()) {
@@ -383,7 +384,7 @@ extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
                     if (!(node.ref[k] & kLeafBit)) todo.push_back({node.ref[k], before + node.count - 1u - k});
             }
         }
-        if (out.quads.empty()) { out.quads.emplace_back(); std::memset(&out.quads[0], 0, sizeof(QuadNode)); out.source.assign(4, 0u); }
+        if (out.quads.empty()) { out.quads.emplace_back(); std::memset(&out.quads[0], 0, sizeof(QuadNode)); out.boxes.assign(24, 0.0); }
         return true;
     };
     Folded folded, flat;
@@ -438,12 +439,12 @@ extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
     HIP_TRY(hipMemcpy(ctx->nodes.ptr, wide.data(), wide.size() * sizeof(WideNode), hipMemcpyHostToDevice));
     HIP_TRY(ctx->quads.resize(folded.quads.size()));
     HIP_TRY(hipMemcpy(ctx->quads.ptr, folded.quads.data(), folded.quads.size() * sizeof(QuadNode), hipMemcpyHostToDevice));
-    HIP_TRY(ctx->quad_source.resize(folded.source.size()));
-    HIP_TRY(hipMemcpy(ctx->quad_source.ptr, folded.source.data(), folded.source.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(ctx->quad_boxes.resize(folded.boxes.size()));
+    HIP_TRY(hipMemcpy(ctx->quad_boxes.ptr, folded.boxes.data(), folded.boxes.size() * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(ctx->quads_flat.resize(flat.quads.size()));
     HIP_TRY(hipMemcpy(ctx->quads_flat.ptr, flat.quads.data(), flat.quads.size() * sizeof(QuadNode), hipMemcpyHostToDevice));
-    HIP_TRY(ctx->quad_source_flat.resize(flat.source.size()));
-    HIP_TRY(hipMemcpy(ctx->quad_source_flat.ptr, flat.source.data(), flat.source.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    HIP_TRY(ctx->quad_boxes_flat.resize(flat.boxes.size()));
+    HIP_TRY(hipMemcpy(ctx->quad_boxes_flat.ptr, flat.boxes.data(), flat.boxes.size() * sizeof(double), hipMemcpyHostToDevice));
     ctx->quad_root = folded.root;
     ctx->quad_root_flat = flat.root;
     ctx->quad_pending = std::max(folded.pending, flat.pending);
@@ -571,8 +572,8 @@ int fill_params(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, const ctgpu_partition
                 FrameParams &P, hipStream_t stream) {
     const Geometry g = geometry(f);
     std::memset(&P, 0, sizeof P);
-    P.nodes = ctx->nodes.ptr; P.quads = ctx->quads.ptr; P.quad_source = ctx->quad_source.ptr; P.quad_root = ctx->quad_root;
-    P.quads_flat = ctx->quads_flat.ptr; P.quad_source_flat = ctx->quad_source_flat.ptr; P.quad_root_flat = ctx->quad_root_flat; P.tris = ctx->tris.ptr; P.materials = ctx->materials.ptr; P.lights = ctx->lights.ptr;
+    P.nodes = ctx->nodes.ptr; P.quads = ctx->quads.ptr; P.quad_boxes = ctx->quad_boxes.ptr; P.quad_root = ctx->quad_root;
+    P.quads_flat = ctx->quads_flat.ptr; P.quad_boxes_flat = ctx->quad_boxes_flat.ptr; P.quad_root_flat = ctx->quad_root_flat; P.tris = ctx->tris.ptr; P.materials = ctx->materials.ptr; P.lights = ctx->lights.ptr;
     P.n_lights = ctx->n_lights;
     if ((f->flags & CTGPU_F_SPHERES) && ctx->n_spheres) {
         P.spheres = ctx->spheres.ptr; P.sphere_nodes = ctx->sphere_nodes.ptr; P.sphere_indexes = ctx->sphere_indexes.ptr;
