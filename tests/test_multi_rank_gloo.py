@@ -88,7 +88,7 @@ def _worker(rank, world, port, result_path):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 8])
 def test_sharded_frame_over_gloo(world, tmp_path, native_build):
     result = tmp_path / "result.txt"
     mp.spawn(_worker, args=(world, _free_port(), str(result)), nprocs=world, join=True)
