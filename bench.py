@@ -15,7 +15,13 @@ gathered (N > 1), assembled and copied into a pinned host framebuffer; `value` =
 ranks / wall time of K frames (max over ranks), scene resident in HBM, a few frames in flight so that
 frame i's tail, gather and copy overlap frame i+1's tracing.  The device-only rate is reported beside it.
 
-For N > 1 (launched by torch.distributed.run, one rank per GPU) the frame's row tiles are dealt
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself: the parent --
+before anything of torch.cuda or HIP is imported -- runs `python -m torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py <same arguments>` as a child process, relays the
+child's JSON line and exit code, and never touches the GPU (`--dry-run-launch` prints that command instead).  Under
+torch.distributed.run (the other way the driver may start it) the ranks are already there.
+
+For N > 1 (one rank per GPU) the frame's row tiles are dealt
 round-robin to the ranks and assembled on rank 0 after ONE RCCL gather, issued natively by libctgpu.so
 (ctgpu_render_sharded: ncclGather on the frame's stream); the total work per step is fixed, so scaling
 is "strong".  torch.distributed only carries the communicator id, the barriers and the timing reduction.
@@ -40,7 +46,7 @@ KERNELS = ("ct_sample_grid", "ct_walk_packet<primary>", "ct_light_gate", "ct_wal
 KERNEL_SOURCES = ("ct_pipeline.hip", "ct_device.h", "ct_params.h", "ct_raygen.h")      # the device code of the fast path
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -56,7 +62,61 @@ def parse_args():
                     help="N > 1: the RCCL gather issued by libctgpu.so (default) or by torch.distributed")
     ap.add_argument("--force-collective", action="store_true",
                     help="N = 1: still go through communicator set-up and the gather (a world of one)")
-    return ap.parse_args()
+    ap.add_argument("--dry-run-launch", action="store_true",
+                    help="print the torch.distributed.run command `--gpus N` would start, as one JSON line, and exit")
+    ap.add_argument("--rehearse-launch", action="store_true",
+                    help="no GPU, nothing rendered or measured: the ranks only rendezvous over gloo and rank 0 prints a "
+                         "record marked as a rehearsal -- checks the launcher, the relay and the per-rank gather on a CPU box")
+    return ap.parse_args(argv)
+
+
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_command(n_ranks, argv, port=None):
+    """The command that runs this script as n_ranks ranks of one node (one per GPU, RCCL over xGMI)."""
+    rest = [a for a in argv if a != "--dry-run-launch"]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks),
+            "--master-addr", "127.0.0.1", "--master-port", str(port or free_port()), os.path.abspath(__file__)] + rest
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` typed without a launcher: be the launcher.  This process must not initialise
+    the GPU (it would hold a HIP context beside rank 0's, and the box forbids exec after that anyway): nothing
+    of torch is imported here, the ranks run in a CHILD process tree, their one JSON line is relayed."""
+    import subprocess
+    cmd = launch_command(args.gpus, argv)
+    if args.dry_run_launch:
+        print(json.dumps({"launch": cmd}))
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: what RCCL needs on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    print("bench.py: starting %d ranks: %s" % (args.gpus, " ".join(cmd)), file=sys.stderr)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    record = None
+    for line in proc.stdout:                                   # stderr goes straight through; stdout is filtered
+        at = line.find('{"metric"')                            # (other writers' text may share the line)
+        if at >= 0:
+            try:
+                json.loads(line[at:])
+                record = line[at:].strip()
+                line = line[:at]
+            except ValueError:
+                pass
+        if line.strip():
+            sys.stderr.write(line if line.endswith("\n") else line + "\n")
+    rc = proc.wait()
+    if record is not None:
+        print(record, flush=True)
+    elif rc == 0:
+        print("bench.py: the ranks finished without printing a record", file=sys.stderr)
+        rc = 1
+    return rc
 
 
 SCENE_FILES = {"dragon": "scene_import_dragon.json", "bunny": "scene_import_bunny.json",
@@ -144,8 +204,40 @@ def cpu_baseline(ca, scene, frame, gpu_host_fb, budget_s):
     return out, parity
 
 
+def rehearse(args):
+    """The plumbing of an N-rank run without a GPU: rendezvous (gloo), one all_gather of a per-rank row, one
+    record from rank 0 on stdout, noise on stdout from the other ranks that the relay must drop."""
+    import torch
+    import torch.distributed as dist
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        dist.init_process_group("gloo")
+    mine = torch.tensor([float(rank), 100.0 + rank], dtype=torch.float64)
+    rows = [torch.zeros_like(mine) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(rows, mine)
+    else:
+        rows = [mine]
+    print("rank %d: this line is not the record" % rank, flush=True)
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "launch rehearsal (nothing measured)", "value": None, "n_gpus": world,
+                          "ranks": [[int(r[0]), r[1].item()] for r in rows]}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     args = parse_args()
+    if (args.gpus > 1 and "WORLD_SIZE" not in os.environ) or args.dry_run_launch:
+        if args.gpus > 1:
+            raise SystemExit(launch_ranks(args, sys.argv[1:]))
+        print(json.dumps({"launch": None, "note": "--gpus 1 runs in this process"}))
+        return
+    if args.rehearse_launch:
+        return rehearse(args)
     # stdout carries exactly ONE line, the JSON record: everything else that may write to file descriptor 1 on the
     # way (RCCL prints a version banner there when a communicator comes up) goes to stderr instead
     sys.stdout.flush()
@@ -189,6 +281,8 @@ def main():
     frame = scene.frame(args.width, args.height, supersampling=ss, rng_mode=ca.RNG_HASH, rng_seed=0)
     is_ss = bool(frame.flags & ca.F_SUPERSAMPLE)
     tile_rows = 8
+    lights = [scene.desc.lights[i] for i in range(scene.desc.n_lights)]
+    n_shadow_lights = sum(1 for l in lights if l.type in (ca.LIGHT_POINT, ca.LIGHT_DIRECTIONAL))       # one shadow ray per hit each
 
     # A few frames in flight: frame i+1 is traced on another stream / context while frame i's kernels drain
     # their tail and its tiles are gathered, assembled and copied to the host, the way a renderer producing a
@@ -206,6 +300,14 @@ def main():
 
     use_comm = use_dist or args.force_collective
     collective = "none"
+    native_ok = True
+
+    def all_ranks_agree(flag):
+        t = torch.tensor([flag], device=device)
+        if use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return t.item() >= 1.0
+
     slots = []
     for i in range(inflight):
         ctx = ca.GpuContext(local_rank)
@@ -217,29 +319,37 @@ def main():
                 "fb": torch.zeros(frame.height * frame.width, dtype=torch.int32, device=device) if rank == 0 else None,
                 "host_fb": torch.zeros(frame.height * frame.width, dtype=torch.int32).pin_memory() if rank == 0 else None,
                 "native": False}
-        if use_comm and args.collective == "native":
-            # rank 0 makes the RCCL unique id, torch.distributed carries its 128 bytes to the other ranks
-            # (one communicator per rank, shared by the slots: RCCL then orders the in-flight frames' gathers itself)
-            try:
-                if i == 0:
-                    uid = torch.zeros(128, dtype=torch.uint8, device=device)
-                    if rank == 0:
+        if use_comm and args.collective == "native" and native_ok:
+            # rank 0 makes the RCCL unique id, torch.distributed carries its 128 bytes to the other ranks (one
+            # communicator per rank, shared by the slots: RCCL then orders the in-flight frames' gathers itself).
+            # Every step that can fail on one rank only is followed by a MIN over the ranks, so that all ranks take
+            # the same branch and nobody waits in a broadcast or an init the others have left.
+            if i == 0:
+                uid = torch.zeros(128, dtype=torch.uint8, device=device)
+                have_id = 1.0
+                if rank == 0:
+                    try:
                         uid.copy_(torch.frombuffer(bytearray(ca.GpuContext.comm_unique_id()), dtype=torch.uint8))
+                    except RuntimeError as e:
+                        have_id = 0.0
+                        print("bench.py: native communicator unavailable (%s); gathering through torch.distributed" % e, file=sys.stderr)
+                native_ok = all_ranks_agree(have_id)
+                if native_ok:
                     if use_dist:
                         dist.broadcast(uid, src=0)
-                    ctx.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
-                else:
-                    ctx.comm_share(slots[0]["ctx"])
-                slot["native"] = True
-            except RuntimeError as e:                      # stay measurable: the same collective through torch.distributed
-                if rank == 0:
-                    print("bench.py: native communicator unavailable (%s); gathering through torch.distributed" % e, file=sys.stderr)
+                    try:
+                        ctx.comm_init(bytes(uid.cpu().numpy().tobytes()), rank, world)
+                        up = 1.0
+                    except RuntimeError as e:
+                        up = 0.0
+                        print("bench.py: rank %d: ctgpu_comm_init failed (%s)" % (rank, e), file=sys.stderr)
+                    native_ok = all_ranks_agree(up)
+            else:
+                ctx.comm_share(slots[0]["ctx"])
+            slot["native"] = native_ok
         slots.append(slot)
     if use_comm:
-        native_everywhere = torch.tensor([1.0 if all(s["native"] for s in slots) else 0.0], device=device)
-        if use_dist:
-            dist.all_reduce(native_everywhere, op=dist.ReduceOp.MIN)
-        if native_everywhere.item() < 1.0:
+        if not native_ok:
             for s in slots:
                 s["native"] = False
         collective = ("RCCL ncclGather to rank 0, issued by libctgpu.so (ctgpu_render_sharded)" if slots[0]["native"]
@@ -251,28 +361,43 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def one_frame(i, to_host=True):
+    phase_events = []          # timed region only: (kind, start, end) torch events on the slot's stream
+
+    def mark(stream):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(stream)
+        return e
+
+    def one_frame(i, to_host=True, record=False):
         """Issue frame i: trace my tiles, gather to rank 0, assemble there, copy to the host framebuffer -- all
         asynchronous on the slot's stream."""
         s = slots[i % inflight]
         stream = s["stream"]
         with torch.cuda.stream(stream):
-            if s["native"]:
+            if s["native"]:         # (its phases are timed inside the library: ctgpu_read_phase_times)
                 s["ctx"].render_sharded(frame, tile_rows, s["fb"].data_ptr() if rank == 0 else 0, stream.cuda_stream)
             else:
+                e0 = mark(stream) if record else None
                 s["ctx"].render_partition(frame, s["part"], s["tiles"].data_ptr(), stream.cuda_stream)
+                e1 = mark(stream) if record else None
                 gathered = s["tiles"] if not use_dist else multi_gpu.gather_to_root(s["tiles"], world, rank)
+                e2 = mark(stream) if record else None
                 if rank == 0:
                     s["ctx"].assemble(frame, s["part"], gathered.data_ptr(), s["fb"].data_ptr(), stream.cuda_stream)
+                if record:
+                    phase_events.extend([("trace", e0, e1), ("gather", e1, e2), ("assemble", e2, mark(stream))])
             if rank == 0 and to_host:       # the pixels the reference writes, into the pinned host framebuffer
+                e3 = mark(stream) if record else None
                 s["ctx"].download_frame(frame, s["fb"].data_ptr(), s["host_fb"].data_ptr(), stream.cuda_stream)
+                if record:
+                    phase_events.append(("d2h", e3, mark(stream)))
         return s
 
-    def timed(n_frames, to_host):
+    def timed(n_frames, to_host, record=False):
         sync_all()
         t0 = time.perf_counter()
         for i in range(n_frames):
-            one_frame(i, to_host)
+            one_frame(i, to_host, record)
         sync_all()
         return time.perf_counter() - t0
 
@@ -285,10 +410,17 @@ def main():
         s["ctx"].kernel_timing(True)         # HIP events around every pipeline kernel, on the frame's own stream
 
     # ---- timed region: exactly K frames, dispatch -> pixels in the host framebuffer
-    elapsed = timed(args.steps, to_host=True)
+    elapsed = timed(args.steps, to_host=True, record=True)
 
     counted = [s["ctx"].read_counters() for s in slots]
     times = [s["ctx"].read_kernel_times() for s in slots]
+    phases = {"trace": 0.0, "gather": 0.0, "assemble": 0.0, "d2h": 0.0}
+    for s in slots:
+        if s["native"]:
+            pt = s["ctx"].read_phase_times()
+            phases["trace"] += pt.trace_ms; phases["gather"] += pt.gather_ms; phases["assemble"] += pt.assemble_ms
+    for kind, a, b in phase_events:
+        phases[kind] += a.elapsed_time(b)
     works = [s["ctx"].read_walk_work() for s in slots]
     for s in slots:
         s["ctx"].kernel_timing(False)
@@ -303,6 +435,16 @@ def main():
         total_rays, total_elided, elapsed = float(sums[0].item()), float(sums[1].item()), float(time_max.item())
     else:
         total_rays, total_elided = my_rays, my_elided
+    # per-rank breakdown (means per frame): what a first scaling curve is read with
+    mine = torch.tensor([my_rays / args.steps, phases["trace"] / args.steps, phases["gather"] / args.steps,
+                         phases["assemble"] / args.steps, phases["d2h"] / args.steps, float(slots[0]["n_tile"]),
+                         totals[2].item() / args.steps * 1e3], dtype=torch.float64, device=device)
+    if use_dist:
+        everyone = torch.zeros(world * mine.numel(), dtype=torch.float64, device=device)
+        dist.all_gather_into_tensor(everyone, mine)
+        per_rank = everyone.view(world, -1).cpu().tolist()
+    else:
+        per_rank = [mine.cpu().tolist()]
     rays_per_frame = total_rays / args.steps
     ms_per_step = elapsed / args.steps * 1e3
     value = total_rays / elapsed / 1e6
@@ -338,7 +480,7 @@ def main():
         per_launch_primary = sum(c.rays_primary for c in counted) / n_launch
         per_launch_shadow = sum(c.rays_shadow for c in counted) / n_launch
         per_launch_elided = sum(c.rays_shadow_elided for c in counted) / n_launch
-        n_lights = 2 if per_launch_shadow else 0
+        n_lights = n_shadow_lights if per_launch_shadow else 0
         samples = per_launch_primary                                       # sample slots of this rank's share (traced ones)
         pixels = samples / (16 if is_ss else 1)
         hits = (per_launch_shadow + per_launch_elided) / max(n_lights, 1)
@@ -406,9 +548,9 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic (deterministic 871,200-triangle stand-in for the undistributed "
                                     "Stanford dragon)" if args.scene == "dragon" else "reference asset",
-            "config": {"workload": "%s %dx%d T=%d %s, 3 lights with shadow rays" %
+            "config": {"workload": "%s %dx%d T=%d %s, %d lights (%d with shadow rays)" %
                                    (SCENE_FILES[args.scene], args.width, args.height, frame.num_threads,
-                                    "supersampling 16 spp (hash jitter)" if is_ss else "1 spp"),
+                                    "supersampling 16 spp (hash jitter)" if is_ss else "1 spp", len(lights), n_shadow_lights),
                        "rays_per_frame": int(rays_per_frame),
                        "reference_rays_per_frame": int(rays_per_frame + total_elided / args.steps),
                        "rays_note": "value counts rays actually traced; the reference also starts the shadow rays "
@@ -419,6 +561,15 @@ def main():
             "value_device_only": round(total_rays / elapsed_device / 1e6, 2),
             "ms_per_step_device_only": round(elapsed_device / args.steps * 1e3, 4),
             "roofline": roofline,
+            "scaling_detail": {
+                "note": "means per frame over the timed region, per rank; the phases are HIP events on the frame's stream "
+                        "(with several frames in flight they overlap other frames' work, so they do not add up to ms_per_step); "
+                        "gather_ms on rank 0 ends when the slowest rank's tiles have arrived; wall_ms = that rank's wall time per frame",
+                "tile_rows": tile_rows,
+                "ranks": [{"rank": r, "rays": int(v[0]), "trace_ms": round(v[1], 4), "gather_ms": round(v[2], 4),
+                           "assemble_ms": round(v[3], 4), "d2h_ms": round(v[4], 4), "tile_pixels": int(v[5]),
+                           "row_tiles": int(v[5]) // max(1, tile_rows * 2 * (frame.height // 2)), "wall_ms": round(v[6], 4)}
+                          for r, v in enumerate(per_rank)]},
         }
         if world == 1 and not args.no_cpu_baseline:
             last = slots[(args.steps - 1) % inflight]["host_fb"].numpy().view(np.uint32).reshape(frame.height, frame.width)

@@ -16,6 +16,7 @@ except Exception:  # pragma: no cover - torch-less installs use the system runti
 
 F_SUPERSAMPLE, F_SUBSAMPLE, F_SPHERES, F_REFLECT_FIX = 1, 2, 4, 8
 RNG_HASH, RNG_LIBC = 0, 1
+LIGHT_POINT, LIGHT_DIRECTIONAL, LIGHT_AMBIENT = 0, 1, 2        # ctgpu.h CTGPU_LIGHT_* (scenefile.h:13)
 
 
 class NativeLibraryMissing(RuntimeError):
@@ -80,6 +81,10 @@ class KernelTimes(C.Structure):
     _fields_ = [("launches", C.c_uint64 * 5), ("total_ms", C.c_double * 5)]
 
 
+class PhaseTimes(C.Structure):
+    _fields_ = [("frames", C.c_uint64), ("trace_ms", C.c_double), ("gather_ms", C.c_double), ("assemble_ms", C.c_double)]
+
+
 class Partition(C.Structure):
     _fields_ = [("tile_rows", C.c_int32), ("part_index", C.c_int32), ("part_count", C.c_int32)]
 
@@ -113,6 +118,7 @@ _GPU_SYMBOLS = {
     "ctgpu_render": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.c_void_p, C.POINTER(Stats)]),
     "ctgpu_render_begin": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.c_void_p]),
     "ctgpu_render_poll": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(Stats)]),
+    "ctgpu_keep_framebuffer_pinned": (C.c_int, [C.c_void_p, C.c_int]),
     "ctgpu_render_multi": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.POINTER(FrameDesc), C.c_void_p, C.POINTER(Stats)]),
     "ctgpu_partition_pixels": (C.c_int, [C.POINTER(FrameDesc), C.POINTER(Partition), C.POINTER(C.c_uint64)]),
     "ctgpu_render_partition": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.POINTER(Partition), C.c_void_p, C.c_void_p]),
@@ -132,6 +138,7 @@ _GPU_SYMBOLS = {
     "ctgpu_read_walk_work": (C.c_int, [C.c_void_p, C.POINTER(WalkWork)]),
     "ctgpu_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "ctgpu_read_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(KernelTimes)]),
+    "ctgpu_read_phase_times": (C.c_int, [C.c_void_p, C.POINTER(PhaseTimes)]),
     "ctgpu_count_work": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.POINTER(Stats)]),
     "ctgpu_rand_stream": (C.c_int, [C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p]),
 }
@@ -347,13 +354,23 @@ class GpuContext:
         if fb is None:
             fb = np.zeros((frame.height, frame.width), dtype=np.uint32)
         self._check(self.lib.ctgpu_render_begin(self.handle, C.byref(frame), fb.ctypes.data))
+        self._in_flight_fb = fb        # the library copies into it asynchronously: it must outlive the frame
         return fb
 
     def render_poll(self, wait=False):
         """(done, stats) of the frame in flight."""
         done, st = C.c_int(0), Stats()
-        self._check(self.lib.ctgpu_render_poll(self.handle, 1 if wait else 0, C.byref(done), C.byref(st)))
+        try:
+            self._check(self.lib.ctgpu_render_poll(self.handle, 1 if wait else 0, C.byref(done), C.byref(st)))
+        except RuntimeError:
+            self._in_flight_fb = None
+            raise
+        if done.value:
+            self._in_flight_fb = None
         return bool(done.value), st
+
+    def keep_framebuffer_pinned(self, keep=True):
+        self._check(self.lib.ctgpu_keep_framebuffer_pinned(self.handle, 1 if keep else 0))
 
     def count_work(self, frame):
         st = Stats()
@@ -377,6 +394,11 @@ class GpuContext:
     def read_kernel_times(self):
         t = KernelTimes()
         self._check(self.lib.ctgpu_read_kernel_times(self.handle, C.byref(t)))
+        return t
+
+    def read_phase_times(self):
+        t = PhaseTimes()
+        self._check(self.lib.ctgpu_read_phase_times(self.handle, C.byref(t)))
         return t
 
     def trace_rays_packet(self, rays, any_hit=False):

@@ -102,6 +102,8 @@ struct ctgpu_ctx {
     bool kernel_timing = false;                 // ctgpu_kernel_timing: events around every pipeline kernel
     std::vector<hipEvent_t> marks;              // (kPipelineKernels + 1) per timed frame
     size_t marks_used = 0;
+    std::vector<hipEvent_t> phase_marks;        // ctgpu_render_sharded: 4 per timed frame (start, traced, gathered, assembled)
+    size_t phase_marks_used = 0;
     int cu_count = 256;
     int walk_thresh[3] = {64, 32, 24};          // retire/fetch, inner, leaf (measured best on MI355X)
     int lds_depth = 8;                          // 6 KB of LDS per wave; deeper entries spill to HBM
@@ -116,14 +118,16 @@ struct ctgpu_ctx {
     ctgpu_comm_state *comm = nullptr;           // ctgpu_comm_init: this rank's RCCL communicator
     std::vector<void *> multi_comms;            // ctgpu_render_multi: one communicator per device, kept by the root context
     std::vector<int> multi_devices;
+    bool multi_comm_failed = false;             // RCCL could not serve ctgpu_render_multi once: peer copies from then on
 
     struct Pending {                            // ctgpu_render_begin .. ctgpu_render_poll
         bool active = false;
         std::chrono::steady_clock::time_point t0;
         uint64_t pixels = 0;
     } pending;
-    uint32_t *pinned_fb = nullptr;              // the caller's framebuffer, page-locked for the asynchronous copy
+    uint32_t *pinned_fb = nullptr;              // the caller's framebuffer, page-locked by begin_frame for the asynchronous copy
     size_t pinned_bytes = 0;
+    bool keep_pin = false;                      // ctgpu_keep_framebuffer_pinned: the caller promises one long-lived framebuffer
 
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev_done = nullptr;
@@ -231,6 +235,22 @@ static int create_resources(ctgpu_ctx *ctx) {
 
 ctgpu_comm_state *&ctgpu_comm_slot(ctgpu_ctx *ctx) { return ctx->comm; }
 int ctgpu_device_of(const ctgpu_ctx *ctx) { return ctx->device; }
+// one mark of a sharded frame's phases (ctgpu_read_phase_times); nothing happens unless timing is on
+int ctgpu_phase_mark(ctgpu_ctx *ctx, int which, hipStream_t stream) {
+    if (!ctx->kernel_timing) return CTGPU_OK;
+    if (which == 0) {
+        while (ctx->phase_marks.size() < ctx->phase_marks_used + 4) {
+            hipEvent_t e;
+            HIP_TRY(hipEventCreate(&e));
+            ctx->phase_marks.push_back(e);
+        }
+        ctx->phase_marks_used += 4;
+    }
+    if (ctx->phase_marks_used < 4) return CTGPU_OK;          // timing was switched on in mid-frame
+    HIP_TRY(hipEventRecord(ctx->phase_marks[ctx->phase_marks_used - 4 + (size_t)which], stream));
+    return CTGPU_OK;
+}
+
 int ctgpu_shard_buffers(ctgpu_ctx *ctx, uint64_t n_tiles, uint64_t n_all, void **tiles, void **all) {
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(ctx->tiles.resize(n_tiles));
@@ -253,6 +273,7 @@ extern "C" void ctgpu_destroy(ctgpu_ctx *ctx) {
     ctx->shadow_lights.release(); ctx->walk_work.release();
     ctx->spheres.release(); ctx->sphere_nodes.release(); ctx->sphere_indexes.release();
     for (hipEvent_t e : ctx->marks) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->phase_marks) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
@@ -268,6 +289,7 @@ extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
         return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_upload_scene: empty scene or null array");
     if (s->n_lights && !s->lights) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_upload_scene: null light array");
     if (s->n_nodes > 2u * s->n_triangles) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_upload_scene: more nodes than 2N-1");
+    if (ctx->pending.active) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_upload_scene: a frame is in flight on this context (ctgpu_render_poll)");
     HIP_TRY(hipSetDevice(ctx->device));
 
     const uint32_t N = s->n_triangles, M = s->n_nodes;
@@ -876,18 +898,24 @@ int begin_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, uint32_t *host_fb
     return CTGPU_OK;
 }
 
+// the page-lock begin_frame put on the caller's framebuffer ends with the frame: the caller may free that memory
+// (and the allocator may hand the same address out again) as soon as the frame has been reported finished
+void release_pin(ctgpu_ctx *ctx) {
+    if (ctx->pinned_fb) (void)hipHostUnregister(ctx->pinned_fb);
+    ctx->pinned_fb = nullptr;
+    ctx->pinned_bytes = 0;
+}
+
 int finish_frame(ctgpu_ctx *ctx, bool wait, int *done, ctgpu_stats *stats) {
     if (!ctx->pending.active) return ctgpu_fail(CTGPU_ERR_ARG, "no frame is in flight on this context");
     HIP_TRY(hipSetDevice(ctx->device));
-    if (wait) {
-        HIP_TRY(hipEventSynchronize(ctx->ev_done));
-    } else {
-        const hipError_t q = hipEventQuery(ctx->ev_done);
-        if (q == hipErrorNotReady) { if (done) *done = 0; return CTGPU_OK; }
-        if (q != hipSuccess) return ctgpu_fail(CTGPU_ERR_HIP, "hipEventQuery: %s", hipGetErrorString(q));
-    }
+    if (!wait && hipEventQuery(ctx->ev_done) == hipErrorNotReady) { if (done) *done = 0; return CTGPU_OK; }
+    // from here on the frame is over, whatever is reported: the context must accept the next one
+    const hipError_t waited = hipEventSynchronize(ctx->ev_done);
     const auto t1 = std::chrono::steady_clock::now();
     ctx->pending.active = false;
+    if (!ctx->keep_pin) release_pin(ctx);
+    if (waited != hipSuccess) return ctgpu_fail(CTGPU_ERR_HIP, "hipEventSynchronize: %s", hipGetErrorString(waited));
     if (done) *done = 1;
     ctgpu_stats st;
     std::memset(&st, 0, sizeof st);
@@ -917,6 +945,14 @@ extern "C" int ctgpu_render_poll(ctgpu_ctx *ctx, int wait, int *done, ctgpu_stat
     return finish_frame(ctx, wait != 0, done, stats);
 }
 
+extern "C" int ctgpu_keep_framebuffer_pinned(ctgpu_ctx *ctx, int keep) {
+    if (!ctx) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_keep_framebuffer_pinned: null argument");
+    if (ctx->pending.active) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_keep_framebuffer_pinned: a frame is in flight");
+    ctx->keep_pin = keep != 0;
+    if (!ctx->keep_pin) { HIP_TRY(hipSetDevice(ctx->device)); release_pin(ctx); }
+    return CTGPU_OK;
+}
+
 // ------------------------------------------------------------------ whole frame on several GPUs, one process
 // The in-process counterpart of bench.py's one-process-per-GPU loop, for hosts like RayThread
 // that own all devices: every context traces its interleaved row tiles on its own device and
@@ -929,6 +965,7 @@ extern "C" int ctgpu_render_multi(ctgpu_ctx *const *ctxs, int n_ctx, const ctgpu
     for (int i = 0; i < n_ctx; i++) {
         if (!ctxs[i]) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_render_multi: null context %d", i);
         if (!ctxs[i]->has_scene) return ctgpu_fail(CTGPU_ERR_NO_SCENE, "context %d has no scene", i);
+        if (ctxs[i]->pending.active) return ctgpu_fail(CTGPU_ERR_ARG, "context %d has a frame in flight (ctgpu_render_poll)", i);
     }
     int rc = check_frame(frame); if (rc) return rc;
     const auto t0 = std::chrono::steady_clock::now();
@@ -950,14 +987,17 @@ extern "C" int ctgpu_render_multi(ctgpu_ctx *const *ctxs, int n_ctx, const ctgpu
         for (int d : devices) distinct = distinct && d != ctxs[i]->device;
         devices.push_back(ctxs[i]->device);
     }
-    if (distinct && root->multi_devices != devices) {
+    // RCCL that cannot come up (no librccl, ncclCommInitAll failing) is remembered, not retried every frame: the
+    // peer-copy hand-over below serves any set of devices
+    bool use_rccl = distinct && !root->multi_comm_failed;
+    if (use_rccl && root->multi_devices != devices) {
         ctgpu_multi_comms_release(root->multi_comms);
         root->multi_devices.clear();
-        rc = ctgpu_multi_comms(devices.data(), n_ctx, root->multi_comms); if (rc) return rc;
-        root->multi_devices = devices;
+        if (ctgpu_multi_comms(devices.data(), n_ctx, root->multi_comms) == CTGPU_OK) root->multi_devices = devices;
+        else { use_rccl = false; root->multi_comm_failed = true; }
     }
 
-    // trace: each device on its own stream; then its tiles go to the root's gather buffer
+    // trace: each device on its own stream
     std::vector<void *> tile_ptrs;
     std::vector<hipStream_t> streams;
     for (int i = 0; i < n_ctx; i++) {
@@ -973,18 +1013,28 @@ extern "C" int ctgpu_render_multi(ctgpu_ctx *const *ctxs, int n_ctx, const ctgpu
         if (i == 0) HIP_TRY(hipEventRecord(root->ev1, root->stream));
         tile_ptrs.push_back(c->tiles.ptr);
         streams.push_back(c->stream);
-        if (distinct) continue;
-        HIP_TRY(hipMemcpyPeerAsync(root->gathered.ptr + per_part * (size_t)i, root->device, c->tiles.ptr, c->device,
-                                   per_part * sizeof(uint32_t), c->stream));
-        if (i != 0) {
-            HIP_TRY(hipEventRecord(c->ev1, c->stream));
-            HIP_TRY(hipSetDevice(root->device));
-            HIP_TRY(hipStreamWaitEvent(root->stream, c->ev1, 0));
-        }
     }
-    if (distinct) {     // ncclGather from every device's stream; the root's completes when all tiles have arrived
-        rc = ctgpu_multi_gather(root->multi_comms, devices.data(), tile_ptrs.data(), per_part, root->gathered.ptr, streams.data());
-        if (rc) return rc;
+    // gather: ncclGather from every device's stream (the root's completes when all tiles have arrived) ...
+    if (use_rccl && ctgpu_multi_gather(root->multi_comms, devices.data(), tile_ptrs.data(), per_part, root->gathered.ptr,
+                                       streams.data()) != CTGPU_OK) {
+        use_rccl = false;
+        root->multi_comm_failed = true;
+        ctgpu_multi_comms_release(root->multi_comms);
+        root->multi_devices.clear();
+    }
+    // ... or peer-to-peer copies over xGMI, each on its device's stream, the root's stream waiting for all of them
+    if (!use_rccl) {
+        for (int i = 0; i < n_ctx; i++) {
+            ctgpu_ctx *c = ctxs[i];
+            HIP_TRY(hipSetDevice(c->device));
+            HIP_TRY(hipMemcpyPeerAsync(root->gathered.ptr + per_part * (size_t)i, root->device, c->tiles.ptr, c->device,
+                                       per_part * sizeof(uint32_t), c->stream));
+            if (i != 0) {
+                HIP_TRY(hipEventRecord(c->ev1, c->stream));
+                HIP_TRY(hipSetDevice(root->device));
+                HIP_TRY(hipStreamWaitEvent(root->stream, c->ev1, 0));
+            }
+        }
     }
 
     // assemble on the root device and copy back the rectangle the reference writes
@@ -1151,6 +1201,22 @@ extern "C" int ctgpu_kernel_timing(ctgpu_ctx *ctx, int enable) {
     if (!ctx) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_kernel_timing: null argument");
     ctx->kernel_timing = enable != 0;
     ctx->marks_used = 0;
+    ctx->phase_marks_used = 0;
+    return CTGPU_OK;
+}
+
+extern "C" int ctgpu_read_phase_times(ctgpu_ctx *ctx, ctgpu_phase_times *out) {
+    if (!ctx || !out) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_read_phase_times: null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::memset(out, 0, sizeof *out);
+    for (size_t f = 0; f + 4 <= ctx->phase_marks_used; f += 4) {
+        HIP_TRY(hipEventSynchronize(ctx->phase_marks[f + 3]));
+        float ms[3] = {0, 0, 0};
+        for (int k = 0; k < 3; k++) HIP_TRY(hipEventElapsedTime(&ms[k], ctx->phase_marks[f + k], ctx->phase_marks[f + k + 1]));
+        out->trace_ms += ms[0]; out->gather_ms += ms[1]; out->assemble_ms += ms[2];
+        out->frames += 1;
+    }
+    ctx->phase_marks_used = 0;
     return CTGPU_OK;
 }
 

@@ -9,7 +9,8 @@
 //
 // librccl is opened at run time (preferring a copy the process has already loaded, e.g. PyTorch's, so
 // that there is one RCCL and one HIP runtime per process); without it the comm entry points fail with
-// CTGPU_ERR_COMM -- nothing here has a host-memory fallback.
+// CTGPU_ERR_COMM -- nothing here has a host-memory fallback (ctgpu_render_multi, one process owning several
+// devices, then hands tiles over with peer-to-peer device copies instead: ctgpu_api.hip).
 #include "ctgpu_internal.h"
 
 #include <rccl/rccl.h>
@@ -28,6 +29,7 @@ struct Rccl {
     decltype(&ncclCommInitRank) comm_init_rank = nullptr;
     decltype(&ncclCommInitAll) comm_init_all = nullptr;
     decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclCommAbort) comm_abort = nullptr;
     decltype(&ncclGather) gather = nullptr;
     decltype(&ncclGroupStart) group_start = nullptr;
     decltype(&ncclGroupEnd) group_end = nullptr;
@@ -39,8 +41,11 @@ Rccl &rccl() {
     static Rccl api;
     static std::once_flag once;
     std::call_once(once, [] {
-        const char *override_path = std::getenv("CTGPU_RCCL_LIBRARY");
-        if (override_path) api.lib = dlopen(override_path, RTLD_NOW | RTLD_GLOBAL);
+        // an explicit choice is final: a CTGPU_RCCL_LIBRARY that cannot be loaded means "no RCCL", not "some other RCCL"
+        if (const char *override_path = std::getenv("CTGPU_RCCL_LIBRARY")) {
+            api.lib = dlopen(override_path, RTLD_NOW | RTLD_GLOBAL);
+            if (!api.lib) { api.why = std::string("CTGPU_RCCL_LIBRARY: ") + dlerror(); return; }
+        }
         // a copy the process already holds (PyTorch maps its own librccl.so without a soname) ...
         const char *names[] = {"librccl.so", "librccl.so.1"};
         for (const char *n : names)
@@ -57,6 +62,7 @@ Rccl &rccl() {
         RESOLVE(comm_init_rank, "ncclCommInitRank");
         RESOLVE(comm_init_all, "ncclCommInitAll");
         RESOLVE(comm_destroy, "ncclCommDestroy");
+        RESOLVE(comm_abort, "ncclCommAbort");
         RESOLVE(gather, "ncclGather");
         RESOLVE(group_start, "ncclGroupStart");
         RESOLVE(group_end, "ncclGroupEnd");
@@ -141,7 +147,7 @@ extern "C" int ctgpu_comm_destroy(ctgpu_ctx *ctx) {
     ctgpu_comm_state *&slot = ctgpu_comm_slot(ctx);
     if (!slot) return CTGPU_OK;
     if (--slot->users == 0) {
-        if (slot->comm && rccl().lib) (void)rccl().comm_destroy(slot->comm);
+        if (slot->comm && rccl().lib) (void)rccl().comm_destroy(slot->comm);      // (an aborted communicator is already gone)
         delete slot;
     }
     slot = nullptr;
@@ -164,6 +170,7 @@ extern "C" int ctgpu_gather_tiles(ctgpu_ctx *ctx, const void *d_tiles, uint64_t 
     if (!s) return ctgpu_fail(CTGPU_ERR_COMM, "this context has no communicator (ctgpu_comm_init)");
     if (root < 0 || root >= s->world) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_gather_tiles: root %d of %d", root, s->world);
     if (s->rank == root && !d_all) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_gather_tiles: the root needs a receive buffer");
+    if (!s->comm) return ctgpu_fail(CTGPU_ERR_COMM, "this context's communicator was aborted after an earlier failure");
     HIP_TRY(hipSetDevice(ctgpu_device_of(ctx)));
     RCCL_TRY(rccl().gather(d_tiles, d_all, (size_t)n, ncclUint32, root, s->comm, (hipStream_t)stream));
     return CTGPU_OK;
@@ -171,20 +178,39 @@ extern "C" int ctgpu_gather_tiles(ctgpu_ctx *ctx, const void *d_tiles, uint64_t 
 
 // One frame, this rank's part of it: trace my row tiles, gather to rank 0, assemble there -- all queued on
 // `stream`, nothing synchronises.  d_fb: the root's device framebuffer (width * height uint32); ignored elsewhere.
+//
+// A collective that one rank never queues blocks every other rank for good, so whatever fails locally here must not
+// keep this rank out of the gather.  Argument errors are the same on every rank (the frame and the partition rule
+// are shared) and return before anything is queued anywhere.  After that, a local failure (no memory for the
+// buffers, a kernel launch error) still takes part: the rank sends its tile buffer zeroed -- "nothing rendered",
+// the value the reference's bitmap starts with -- and reports its error; only when there is no buffer to send
+// does it abort the communicator, which makes the peers' gather return with an error instead of waiting.
 extern "C" int ctgpu_render_sharded(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, int tile_rows, void *d_fb, void *stream) {
     if (!ctx) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_render_sharded: null argument");
     ctgpu_comm_state *s = ctgpu_comm_slot(ctx);
     if (!s) return ctgpu_fail(CTGPU_ERR_COMM, "this context has no communicator (ctgpu_comm_init)");
-    if (s->rank == 0 && !d_fb) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_render_sharded: rank 0 needs a framebuffer");
+    if (!s->comm) return ctgpu_fail(CTGPU_ERR_COMM, "this context's communicator was aborted after an earlier failure");
     const ctgpu_partition part = {tile_rows, s->rank, s->world};
     uint64_t n = 0;
-    int rc = ctgpu_partition_pixels(frame, &part, &n); if (rc) return rc;
+    int rc = ctgpu_partition_pixels(frame, &part, &n); if (rc) return rc;                 // same verdict on every rank
+    if (s->rank == 0 && !d_fb) rc = ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_render_sharded: rank 0 needs a framebuffer");
     void *tiles = nullptr, *all = nullptr;
-    rc = ctgpu_shard_buffers(ctx, n, s->rank == 0 ? n * (uint64_t)s->world : 0, &tiles, &all); if (rc) return rc;
-    rc = ctgpu_render_partition(ctx, frame, &part, tiles, stream); if (rc) return rc;
-    rc = ctgpu_gather_tiles(ctx, tiles, n, all, 0, stream); if (rc) return rc;
-    if (s->rank == 0) return ctgpu_assemble(ctx, frame, &part, all, d_fb, stream);
-    return CTGPU_OK;
+    const int have = ctgpu_shard_buffers(ctx, n, s->rank == 0 ? n * (uint64_t)s->world : 0, &tiles, &all);
+    if (have != CTGPU_OK) {                                                               // nothing to send at all
+        if (s->comm) { (void)rccl().comm_abort(s->comm); s->comm = nullptr; }
+        return have;
+    }
+    (void)ctgpu_phase_mark(ctx, 0, (hipStream_t)stream);
+    if (rc == CTGPU_OK) rc = ctgpu_render_partition(ctx, frame, &part, tiles, stream);
+    if (rc != CTGPU_OK) (void)hipMemsetAsync(tiles, 0, n * sizeof(uint32_t), (hipStream_t)stream);
+    const std::string first_error = rc != CTGPU_OK ? ctgpu_last_error() : "";
+    (void)ctgpu_phase_mark(ctx, 1, (hipStream_t)stream);
+    const int gathered = ctgpu_gather_tiles(ctx, tiles, n, all, 0, stream);
+    (void)ctgpu_phase_mark(ctx, 2, (hipStream_t)stream);
+    if (rc != CTGPU_OK) return ctgpu_fail(rc, "%s", first_error.c_str());
+    if (gathered != CTGPU_OK) return gathered;
+    if (s->rank == 0) { rc = ctgpu_assemble(ctx, frame, &part, all, d_fb, stream); if (rc) return rc; }
+    return ctgpu_phase_mark(ctx, 3, (hipStream_t)stream);
 }
 
 // ------------------------------------------------------------------ one process, several devices

@@ -40,6 +40,7 @@ struct GpuApi {
     decltype(&ctgpu_render_multi) render_multi = nullptr;
     decltype(&ctgpu_render_begin) render_begin = nullptr;
     decltype(&ctgpu_render_poll) render_poll = nullptr;
+    decltype(&ctgpu_keep_framebuffer_pinned) keep_pinned = nullptr;
     decltype(&ctgpu_device_count) device_count = nullptr;
     decltype(&ctgpu_build_bvh) build_bvh = nullptr;
 };
@@ -77,6 +78,7 @@ GpuApi &gpu() {
     RESOLVE(render_multi, "ctgpu_render_multi");
     RESOLVE(render_begin, "ctgpu_render_begin");
     RESOLVE(render_poll, "ctgpu_render_poll");
+    RESOLVE(keep_pinned, "ctgpu_keep_framebuffer_pinned");
     RESOLVE(device_count, "ctgpu_device_count");
     RESOLVE(build_bvh, "ctgpu_build_bvh");
 #undef RESOLVE
@@ -196,6 +198,9 @@ bool RayThread(environment_t *env, scene_t *scene) {
             ctgpu_ctx *ctx = nullptr;
             if (api.create((b.options.device + i) % visible, &ctx) != CTGPU_OK) die("ctgpu_create", api.last_error());
             if (api.upload_scene(ctx, &desc) != CTGPU_OK) die("ctgpu_upload_scene", api.last_error());
+            // env->bitmap is the application's one framebuffer for its whole life (cobbletrace.cpp:60-75): its page-lock
+            // stays between frames; RayThreadReset / ctgpu_destroy ends it
+            if (b.options.async && api.keep_pinned(ctx, 1) != CTGPU_OK) die("ctgpu_keep_framebuffer_pinned", api.last_error());
             b.ctxs.push_back(ctx);
         }
         b.initialised = true;

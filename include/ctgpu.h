@@ -196,16 +196,22 @@ int  ctgpu_render(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, uint32_t *host_
 
 /* The same frame without blocking the caller (raythread.cpp:546-593: the reference's RayThread dispatches its
  * workers and looks at their status on later calls).  begin queues trace + assemble + the copy into host_fb on
- * the context's stream (host_fb is page-locked on first use and must stay valid until the frame is done; one
+ * the context's stream (host_fb is page-locked for the frame and must stay valid until poll reports it done; one
  * frame in flight per context); poll says whether it has finished -- or waits for it when `wait` is non-zero --
- * and then fills `stats`. */
+ * and then fills `stats`.  Once poll has reported the frame done (or failed) the page-lock is gone and the context
+ * takes the next frame.  A host that hands over the SAME long-lived framebuffer every frame (the reference's
+ * env->bitmap) calls ctgpu_keep_framebuffer_pinned(ctx, 1) to keep the page-lock between frames, and (ctx, 0) --
+ * or ctgpu_destroy -- before it frees that memory.  ctgpu_upload_scene and ctgpu_render_multi refuse a context
+ * with a frame in flight. */
 int  ctgpu_render_begin(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, uint32_t *host_fb);
 int  ctgpu_render_poll(ctgpu_ctx *ctx, int wait, int *done, ctgpu_stats *stats);
+int  ctgpu_keep_framebuffer_pinned(ctgpu_ctx *ctx, int keep);
 
 /* The same frame split over several contexts of THIS process (one per GPU): interleaved row tiles, an RCCL
  * gather (one communicator per device, ncclGather in one group) to the first context's device, assembly
  * there.  All contexts must hold the same scene.  Contexts that share a device are allowed (RCCL cannot
- * address a device twice: their tiles travel as plain device copies instead).  This is what RayThread uses when
+ * address a device twice: their tiles travel as plain device copies instead; the same peer copies over xGMI
+ * take over, for the rest of the context's life, when RCCL cannot be loaded or its communicators fail).  This is what RayThread uses when
  * it is given more than one device (raythread.cpp:574-618 had one worker thread per band). */
 int  ctgpu_render_multi(ctgpu_ctx *const *ctxs, int n_ctx, const ctgpu_frame_desc *frame, uint32_t *host_fb,
                         ctgpu_stats *stats);
@@ -286,6 +292,11 @@ typedef struct ctgpu_walk_work {
     uint64_t shadow_rays_blocked, shadow_packets_all_blocked;      /* shadow walk: rays that found a blocker; packets whose every ray did */
 } ctgpu_walk_work;
 typedef struct ctgpu_kernel_times { uint64_t launches[CTGPU_PIPELINE_KERNELS]; double total_ms[CTGPU_PIPELINE_KERNELS]; } ctgpu_kernel_times;
+/* ctgpu_render_sharded's phases on this rank, HIP events on the frame's stream while ctgpu_kernel_timing is on:
+ * trace (this rank's tiles), gather (ncclGather: on the root it ends when the slowest rank's tiles have arrived),
+ * assemble (root only). */
+typedef struct ctgpu_phase_times { uint64_t frames; double trace_ms, gather_ms, assemble_ms; } ctgpu_phase_times;
+int  ctgpu_read_phase_times(ctgpu_ctx *ctx, ctgpu_phase_times *out);
 int  ctgpu_read_walk_work(ctgpu_ctx *ctx, ctgpu_walk_work *out);
 int  ctgpu_kernel_timing(ctgpu_ctx *ctx, int enable);
 int  ctgpu_read_kernel_times(ctgpu_ctx *ctx, ctgpu_kernel_times *out);
