@@ -85,6 +85,14 @@ class PhaseTimes(C.Structure):
     _fields_ = [("frames", C.c_uint64), ("trace_ms", C.c_double), ("gather_ms", C.c_double), ("assemble_ms", C.c_double)]
 
 
+class SceneInfo(C.Structure):
+    _fields_ = [("n_triangles", C.c_uint32), ("n_nodes", C.c_uint32), ("tree_depth", C.c_uint32), ("n_wide", C.c_uint32),
+                ("n_quads", C.c_uint32), ("n_quads_flat", C.c_uint32), ("quad_root", C.c_uint32), ("quad_root_flat", C.c_uint32),
+                ("quad_pending", C.c_uint32), ("root_ref", C.c_uint32), ("slot_of_triangle0", C.c_uint32), ("shared_by", C.c_uint32),
+                ("plane_bound", C.c_float * 3), ("pad_", C.c_uint32), ("build_ms", C.c_double), ("pack_ms", C.c_double),
+                ("hbm_bytes", C.c_uint64)]
+
+
 class Partition(C.Structure):
     _fields_ = [("tile_rows", C.c_int32), ("part_index", C.c_int32), ("part_count", C.c_int32)]
 
@@ -115,6 +123,10 @@ _GPU_SYMBOLS = {
     "ctgpu_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "ctgpu_destroy": (None, [C.c_void_p]),
     "ctgpu_upload_scene": (C.c_int, [C.c_void_p, C.POINTER(SceneDesc)]),
+    "ctgpu_share_scene": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "ctgpu_download_tree": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]),
+    "ctgpu_scene_info": (C.c_int, [C.c_void_p, C.POINTER(SceneInfo)]),
+    "ctgpu_debug_scene_array": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)]),
     "ctgpu_render": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.c_void_p, C.POINTER(Stats)]),
     "ctgpu_render_begin": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.c_void_p]),
     "ctgpu_render_poll": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(Stats)]),
@@ -327,8 +339,39 @@ class GpuContext:
         except Exception:
             pass
 
-    def upload(self, scene_desc):
+    def upload(self, scene_desc, build_on_device=False):
+        """Scene -> HBM.  build_on_device: hand over vertices / materials / lights only; BuildBVH runs on the GPU."""
+        if build_on_device:
+            d = SceneDesc()
+            C.memmove(C.byref(d), C.byref(scene_desc), C.sizeof(SceneDesc))
+            d.n_nodes, d.nodes, d.indexes = 0, None, None
+            scene_desc = d
         self._check(self.lib.ctgpu_upload_scene(self.handle, C.byref(scene_desc)))
+
+    def share_scene(self, owner):
+        self._check(self.lib.ctgpu_share_scene(self.handle, owner.handle))
+
+    def scene_info(self):
+        info = SceneInfo()
+        self._check(self.lib.ctgpu_scene_info(self.handle, C.byref(info)))
+        return info
+
+    def download_tree(self):
+        """(nodes as raw 64-byte records, indexes) of a tree that was built on the device."""
+        info = self.scene_info()
+        nodes = np.zeros((max(2 * info.n_triangles - 1, 1), 64), dtype=np.uint8)
+        indexes = np.zeros(info.n_triangles, dtype=np.uint32)
+        used = C.c_uint32(0)
+        self._check(self.lib.ctgpu_download_tree(self.handle, nodes.ctypes.data, indexes.ctypes.data, C.byref(used)))
+        return nodes[:used.value], indexes
+
+    def scene_array(self, which):
+        """One packed device array as bytes (test hook): 0 WideNodes, 1 QuadNodes, 2 boxes, 3 flat QuadNodes, 4 boxes, 5 TriRecords."""
+        need = C.c_uint64(0)
+        self._check(self.lib.ctgpu_debug_scene_array(self.handle, which, None, 0, C.byref(need)))
+        out = np.zeros(need.value, dtype=np.uint8)
+        self._check(self.lib.ctgpu_debug_scene_array(self.handle, which, out.ctypes.data, out.nbytes, C.byref(need)))
+        return out
 
     def render(self, frame, fb=None):
         """Whole frame -> (uint32 [H, W] array, Stats)."""

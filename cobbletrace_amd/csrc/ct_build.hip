@@ -68,7 +68,7 @@ struct BuildArrays {
     // work lists of the boxes to fit
     uint32_t *box_small, *box_big, *box_huge;
     double *huge_runs;         // [huge nodes][256][6] partial boxes
-    uint32_t *counters;        // [0] nodes used, [1] next level's active nodes, [2] small, [3] big, [4] huge boxes
+    uint32_t *counters;        // [0] nodes used, [1] next level's active nodes, [2] small, [3] big, [4] huge boxes; [7] a NaN vertex was seen
     uint32_t n;
 };
 
@@ -82,6 +82,9 @@ __global__ void k_centroids(BuildArrays A) {
     const double third = (double)0.3333f;              // bvh.cpp:111: (p1 + p2 + p3) * 0.3333f
     const double *v = A.verts + (size_t)i * 9;
     for (int c = 0; c < 3; c++) A.cent[(size_t)i * 3 + c] = ((v[c] + v[3 + c]) + v[6 + c]) * third;
+    bool nan = false;
+    for (int c = 0; c < 9; c++) nan = nan || (v[c] != v[c]);
+    if (nan) A.counters[7] = 1u;                       // the ordered box folds below assume NaN-free corners (see ctgpu_build_bvh)
     A.idx_in[i] = i;
     A.seg[i] = (A.n > 2) ? 0 : -1;
 }
@@ -423,27 +426,34 @@ inline unsigned blocks_for(uint32_t n) { return (n + kBlock - 1) / kBlock; }
 
 }  // namespace
 
-// nodes_out: room for 2n - 1 nodes; indexes_out: n.  *device_ms (optional): time of the build on the device, copies
-// excluded.  Returns the reference's arrays: node i is bvhNodes[i], indexes_out is triangles.indexes.
-extern "C" int ctgpu_build_bvh(int device, const double *vertices, uint32_t n, ctgpu_node *nodes_out, uint32_t *indexes_out,
-                               uint32_t *n_nodes_out, double *device_ms) {
-    if (!vertices || !nodes_out || !indexes_out || !n_nodes_out || n == 0)
+// BuildBVH on vertices that are already in HBM; the finished arrays stay there (see ctgpu_internal.h).
+//
+// Precondition: no NaN among the vertex coordinates.  The reference folds a node's box with a < b ? a : b in
+// sequence, where a NaN corner RESTARTS the fold (lesser(x, NaN) = NaN, lesser(NaN, c) = c); the ordered parallel
+// fold here does not reproduce that restart, so a mesh with a NaN vertex is refused (CTGPU_ERR_ARG) and the caller
+// builds that tree on the host (host/bvh_build.cpp follows the sequence literally).  Infinities are fine.
+int ctgpu_build_bvh_resident(int device, const double *d_verts, uint32_t n, ctgpu_node **d_nodes_out, uint32_t **d_indexes_out,
+                             uint32_t *n_nodes_out, uint32_t *depth_out, double *device_ms) {
+    if (!d_verts || !d_nodes_out || !d_indexes_out || !n_nodes_out || n == 0)
         return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_build_bvh: null argument or no triangles");
     if (n > (1u << 30)) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_build_bvh: %u triangles are too many", n);
-    int n_dev = 0;
-    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return ctgpu_fail(CTGPU_ERR_NO_DEVICE, "no HIP device is visible");
-    if (device < 0 || device >= n_dev) return ctgpu_fail(CTGPU_ERR_ARG, "device %d out of range (0..%d)", device, n_dev - 1);
     HIP_TRY(hipSetDevice(device));
 
     std::vector<void *> owned;
-    struct Release { std::vector<void *> &v; ~Release() { for (void *p : v) (void)hipFree(p); } } release{owned};
+    struct Release {
+        std::vector<void *> &v;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        ~Release() {
+            for (void *p : v) (void)hipFree(p);
+            if (ev0) (void)hipEventDestroy(ev0);
+            if (ev1) (void)hipEventDestroy(ev1);
+        }
+    } release{owned};
     BuildArrays A;
     std::memset(&A, 0, sizeof A);
     A.n = n;
     const size_t max_nodes = 2 * (size_t)n;
-    double *d_verts = nullptr;
     ctgpu_node *d_out = nullptr;
-    HIP_TRY(device_alloc(d_verts, (size_t)n * 9, owned));
     HIP_TRY(device_alloc(A.cent, (size_t)n * 3, owned));
     HIP_TRY(device_alloc(A.idx_in, n, owned));      HIP_TRY(device_alloc(A.idx_out, n, owned));
     HIP_TRY(device_alloc(A.seg, n, owned));         HIP_TRY(device_alloc(A.seg_next, n, owned));
@@ -464,14 +474,12 @@ extern "C" int ctgpu_build_bvh(int device, const double *vertices, uint32_t n, c
     HIP_TRY(device_alloc(A.box_huge, max_huge, owned));
     HIP_TRY(device_alloc(A.huge_runs, max_huge * 256 * 6, owned));
     HIP_TRY(device_alloc(A.counters, 8, owned));
-    HIP_TRY(device_alloc(d_out, max_nodes, owned));
+    HIP_TRY(hipMemset(A.counters, 0, 8 * sizeof(uint32_t)));
     A.verts = d_verts;
-    HIP_TRY(hipMemcpy(d_verts, vertices, (size_t)n * 9 * sizeof(double), hipMemcpyHostToDevice));
 
-    hipEvent_t ev0, ev1;
-    HIP_TRY(hipEventCreate(&ev0));
-    HIP_TRY(hipEventCreate(&ev1));
-    HIP_TRY(hipEventRecord(ev0, nullptr));
+    HIP_TRY(hipEventCreate(&release.ev0));
+    HIP_TRY(hipEventCreate(&release.ev1));
+    HIP_TRY(hipEventRecord(release.ev0, nullptr));
 
     // root: node 0 over all triangles (bvh.cpp:113-118)
     const uint32_t root_setup[3] = {0u, n, 0u};
@@ -488,6 +496,7 @@ extern "C" int ctgpu_build_bvh(int device, const double *vertices, uint32_t n, c
     uint32_t nodes_used = 1, n_active = (n > 2) ? 1u : 0u;
     while (n_active) {
         level_begin.push_back(nodes_used);
+        // (a tree deeper than the walks' stacks is reported here, by the build, with the depth it reached)
         if (level_begin.size() > CTGPU_MAX_TREE_DEPTH + 1)
             return ctgpu_fail(CTGPU_ERR_STACK, "ctgpu_build_bvh: the tree is deeper than %d", CTGPU_MAX_TREE_DEPTH);
         const uint32_t counters[5] = {nodes_used, 0u, 0u, 0u, 0u};
@@ -502,8 +511,9 @@ extern "C" int ctgpu_build_bvh(int device, const double *vertices, uint32_t n, c
         hipLaunchKernelGGL(k_scatter, dim3(blocks_for(n)), dim3(kBlock), 0, nullptr, A);
         hipLaunchKernelGGL(k_children, dim3(blocks_for(n_active)), dim3(kBlock), 0, nullptr, A, n_active);
         hipLaunchKernelGGL(k_next_segments, dim3(blocks_for(n)), dim3(kBlock), 0, nullptr, A);
-        uint32_t after[5];
+        uint32_t after[8];
         HIP_TRY(hipMemcpy(after, A.counters, sizeof after, hipMemcpyDeviceToHost));
+        if (after[7]) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_build_bvh: a vertex coordinate is NaN (build this tree on the host)");
         if (after[2]) hipLaunchKernelGGL(k_boxes_small, dim3(blocks_for(after[2])), dim3(kBlock), 0, nullptr, A, after[2], (const uint32_t *)A.idx_out);
         if (after[3]) hipLaunchKernelGGL(k_boxes_big, dim3(after[3]), dim3(kBlock), 0, nullptr, A, (const uint32_t *)A.idx_out);
         if (after[4]) {
@@ -518,8 +528,14 @@ extern "C" int ctgpu_build_bvh(int device, const double *vertices, uint32_t n, c
         std::swap(A.a_node, A.a_node_next);
     }
     level_begin.push_back(nodes_used);               // level_begin[d] .. level_begin[d + 1]: nodes of depth d
+    {
+        uint32_t nan_seen = 0;                       // (trees of one or two triangles never entered the loop)
+        HIP_TRY(hipMemcpy(&nan_seen, A.counters + 7, 4, hipMemcpyDeviceToHost));
+        if (nan_seen) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_build_bvh: a vertex coordinate is NaN (build this tree on the host)");
+    }
 
     // numbering in the reference's allocation order
+    HIP_TRY(device_alloc(d_out, nodes_used, owned));
     const size_t depths = level_begin.size() - 1;
     for (size_t d = depths; d-- > 0;) {
         const uint32_t b = level_begin[d], e = level_begin[d + 1];
@@ -534,16 +550,50 @@ extern "C" int ctgpu_build_bvh(int device, const double *vertices, uint32_t n, c
     }
     hipLaunchKernelGGL(k_emit, dim3(blocks_for(nodes_used)), dim3(kBlock), 0, nullptr, A, nodes_used, d_out);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(ev1, nullptr));
-    HIP_TRY(hipEventSynchronize(ev1));
+    HIP_TRY(hipEventRecord(release.ev1, nullptr));
+    HIP_TRY(hipEventSynchronize(release.ev1));
     float ms = 0.0f;
-    HIP_TRY(hipEventElapsedTime(&ms, ev0, ev1));
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
+    HIP_TRY(hipEventElapsedTime(&ms, release.ev0, release.ev1));
 
-    HIP_TRY(hipMemcpy(nodes_out, d_out, (size_t)nodes_used * sizeof(ctgpu_node), hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(indexes_out, A.idx_in, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    // the two results leave the scratch list: they are the caller's now
+    for (void *keep : {(void *)d_out, (void *)A.idx_in})
+        owned.erase(std::find(owned.begin(), owned.end(), keep));
+    *d_nodes_out = d_out;
+    *d_indexes_out = A.idx_in;
     *n_nodes_out = nodes_used;
+    if (depth_out) {                                 // levels that hold a node (the last pass may have split nothing)
+        uint32_t levels = 0;
+        for (size_t d = 0; d < depths; d++) levels += level_begin[d + 1] > level_begin[d] ? 1u : 0u;
+        *depth_out = levels;
+    }
     if (device_ms) *device_ms = ms;
+    return CTGPU_OK;
+}
+
+// nodes_out: room for 2n - 1 nodes; indexes_out: n.  *device_ms (optional): time of the build on the device, copies
+// excluded.  Returns the reference's arrays: node i is bvhNodes[i], indexes_out is triangles.indexes.
+extern "C" int ctgpu_build_bvh(int device, const double *vertices, uint32_t n, ctgpu_node *nodes_out, uint32_t *indexes_out,
+                               uint32_t *n_nodes_out, double *device_ms) {
+    if (!vertices || !nodes_out || !indexes_out || !n_nodes_out || n == 0)
+        return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_build_bvh: null argument or no triangles");
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) return ctgpu_fail(CTGPU_ERR_NO_DEVICE, "no HIP device is visible");
+    if (device < 0 || device >= n_dev) return ctgpu_fail(CTGPU_ERR_ARG, "device %d out of range (0..%d)", device, n_dev - 1);
+    HIP_TRY(hipSetDevice(device));
+    std::vector<void *> owned;
+    struct Release { std::vector<void *> &v; ~Release() { for (void *p : v) if (p) (void)hipFree(p); } } release{owned};
+    double *d_verts = nullptr;
+    HIP_TRY(device_alloc(d_verts, (size_t)n * 9, owned));
+    HIP_TRY(hipMemcpy(d_verts, vertices, (size_t)n * 9 * sizeof(double), hipMemcpyHostToDevice));
+    ctgpu_node *d_nodes = nullptr;
+    uint32_t *d_idx = nullptr;
+    uint32_t used = 0;
+    const int rc = ctgpu_build_bvh_resident(device, d_verts, n, &d_nodes, &d_idx, &used, nullptr, device_ms);
+    if (rc) return rc;
+    owned.push_back(d_nodes);
+    owned.push_back(d_idx);
+    HIP_TRY(hipMemcpy(nodes_out, d_nodes, (size_t)used * sizeof(ctgpu_node), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(indexes_out, d_idx, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    *n_nodes_out = used;
     return CTGPU_OK;
 }

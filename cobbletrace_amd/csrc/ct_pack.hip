@@ -1,0 +1,410 @@
+// ct_pack.hip -- the scene's walk layouts, made ON THE DEVICE from the reference's arrays.
+//
+// Input (already in HBM, from ct_build.hip or copied up as the caller gave them): bvhNodes[] (64 B each, the
+// reference's numbering), triangles.indexes[], the triangles' vertices.  Output: what ct_device.h describes --
+// WideNodes (per-lane walks), the folded QuadNode tree and its unfolded twin with their binary64 boxes (packet walk),
+// leaf-ordered TriRecords.  The host used to fold these serially and push ~0.5 GB through pageable copies (0.34 s
+// for the dragon, 2 s for 8 M triangles); here it is a few milliseconds and the tree never crosses PCIe.
+//
+// Everything comes out byte for byte as the host restatement (pack_on_host in ctgpu_api.hip, CTGPU_PACK=host) lays
+// it out -- tests/test_gpu_scene_pack.py compares the arrays.  Two things are order-dependent:
+//  * WideNode slots: inner nodes in reference order -> an exclusive prefix count over "is inner".
+//  * QuadNode slots: the host numbers QuadNodes in the order a queue discovers them from the root (each QuadNode's
+//    inner entries, in entry order, append to the queue) -- breadth first.  A level of that queue is numbered from
+//    the level before it: per QuadNode the count of inner entries, a prefix sum over the level, slot = end of the
+//    level + sum + rank among the QuadNode's own inner entries.  One pass per level of the folded tree (~14 for the
+//    dragon), each a count kernel, a scan and an emit kernel.
+// The most entries ever pending on the packet walk's stack (quad_pending) rides along: a QuadNode reached with
+// `before` entries pending leaves before + count - 1 - k pending while entry k is walked.
+#include "ctgpu_internal.h"
+#include "ct_device.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+using namespace ctd;
+
+namespace {
+
+constexpr int kBlock = 256;
+
+#define HIP_TRY(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return ctgpu_fail(CTGPU_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+inline unsigned blocks_for(uint64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+
+// ---- exclusive prefix sum of uint32 (n + 1 outputs: out[n] = total), any n: block sums, their scan, the final pass
+constexpr int kScanItems = 8;                         // per thread
+constexpr uint32_t kScanTile = kBlock * kScanItems;
+__global__ void k_scan_tiles(const uint32_t *in, uint32_t n, uint32_t *tile_sums) {
+    __shared__ uint32_t partial[kBlock];
+    const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    uint32_t sum = 0;
+    for (int i = 0; i < kScanItems; i++) sum += (base + i < n) ? in[base + i] : 0u;
+    partial[threadIdx.x] = sum;
+    __syncthreads();
+    for (int step = kBlock / 2; step > 0; step >>= 1) {
+        if ((int)threadIdx.x < step) partial[threadIdx.x] += partial[threadIdx.x + step];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tile_sums[blockIdx.x] = partial[0];
+}
+__global__ void k_scan_tile_sums(uint32_t *tile_sums, uint32_t n_tiles) {     // one block, serial carry over chunks
+    __shared__ uint32_t chunk[kBlock];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t start = 0; start < n_tiles; start += kBlock) {
+        const uint32_t i = start + threadIdx.x;
+        const uint32_t mine = (i < n_tiles) ? tile_sums[i] : 0u;
+        chunk[threadIdx.x] = mine;
+        __syncthreads();
+        for (int step = 1; step < kBlock; step <<= 1) {                    // inclusive scan of the chunk
+            const uint32_t add = ((int)threadIdx.x >= step) ? chunk[threadIdx.x - step] : 0u;
+            __syncthreads();
+            chunk[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (i < n_tiles) tile_sums[i] = carry + chunk[threadIdx.x] - mine;
+        __syncthreads();
+        if (threadIdx.x == 0) carry += chunk[kBlock - 1];
+        __syncthreads();
+    }
+}
+__global__ void k_scan_finish(const uint32_t *in, uint32_t n, const uint32_t *tile_sums, uint32_t *out) {
+    __shared__ uint32_t partial[kBlock];
+    const uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
+    uint32_t v[kScanItems], sum = 0;
+    for (int i = 0; i < kScanItems; i++) { v[i] = (base + i < n) ? in[base + i] : 0u; sum += v[i]; }
+    partial[threadIdx.x] = sum;
+    __syncthreads();
+    for (int step = 1; step < kBlock; step <<= 1) {
+        const uint32_t add = ((int)threadIdx.x >= step) ? partial[threadIdx.x - step] : 0u;
+        __syncthreads();
+        partial[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = tile_sums[blockIdx.x] + partial[threadIdx.x] - sum;
+    for (int i = 0; i < kScanItems; i++) {
+        if (base + i <= n) out[base + i] = run;                           // (position n receives the total)
+        run += v[i];
+    }
+}
+struct Scanner {
+    uint32_t *tile_sums = nullptr;
+    uint32_t capacity = 0;                 // elements
+    int prepare(uint32_t max_n) {
+        capacity = max_n;
+        HIP_TRY(hipMalloc((void **)&tile_sums, ((size_t)max_n / kScanTile + 2) * sizeof(uint32_t)));
+        return CTGPU_OK;
+    }
+    void run(const uint32_t *in, uint32_t n, uint32_t *out, hipStream_t stream) const {     // out: n + 1 words
+        const uint32_t tiles = n / kScanTile + 1;
+        hipLaunchKernelGGL(k_scan_tiles, dim3(tiles), dim3(kBlock), 0, stream, in, n, tile_sums);
+        hipLaunchKernelGGL(k_scan_tile_sums, dim3(1), dim3(kBlock), 0, stream, tile_sums, tiles);
+        hipLaunchKernelGGL(k_scan_finish, dim3(tiles), dim3(kBlock), 0, stream, in, n, (const uint32_t *)tile_sums, out);
+    }
+    ~Scanner() { if (tile_sums) (void)hipFree(tile_sums); }
+};
+
+// ---- WideNodes
+__global__ void k_inner_flags(const ctgpu_node *nodes, uint32_t m, uint32_t *flag) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < m) flag[i] = nodes[i].count == 0 ? 1u : 0u;
+}
+__device__ __forceinline__ uint32_t child_ref(const ctgpu_node *nodes, const uint32_t *wide_of, uint32_t id) {
+    return nodes[id].count ? (kLeafBit | nodes[id].first) : wide_of[id];
+}
+__global__ void k_wide(const ctgpu_node *nodes, uint32_t m, const uint32_t *wide_of, WideNode *wide) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= m || nodes[i].count) return;
+    const uint32_t left = nodes[i].left;
+    const ctgpu_node l = nodes[left], r = nodes[left + 1];
+    WideNode w;
+    for (int c = 0; c < 3; c++) { w.lmin[c] = l.bmin[c]; w.lmax[c] = l.bmax[c]; w.rmin[c] = r.bmin[c]; w.rmax[c] = r.bmax[c]; }
+    w.lref = child_ref(nodes, wide_of, left);
+    w.rref = child_ref(nodes, wide_of, left + 1);
+    for (int k = 0; k < 6; k++) w.pad_[k] = 0u;
+    wide[wide_of[i]] = w;
+}
+
+// ---- the bound the binary32 filter needs: max |plane| per axis over every node; anything beyond 1e30 or NaN -> flag
+__global__ void k_bound(const ctgpu_node *nodes, uint32_t m, unsigned long long *out) {    // out[0..2] maxima as bits, out[3] flag
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    double big[3] = {0.0, 0.0, 0.0};
+    bool bad = false;
+    if (i < m) {
+        for (int c = 0; c < 3; c++) {
+            const double lo = __builtin_fabs(nodes[i].bmin[c]), hi = __builtin_fabs(nodes[i].bmax[c]);
+            if (!(lo <= 1e30) || !(hi <= 1e30)) bad = true;
+            else big[c] = lo > hi ? lo : hi;
+        }
+    }
+    // non-negative doubles order like their bit patterns
+    for (int c = 0; c < 3; c++) {
+        unsigned long long bits = (unsigned long long)__double_as_longlong(big[c]);
+        for (int off = 32; off > 0; off >>= 1) {
+            const unsigned long long other = __shfl_xor(bits, off);
+            bits = other > bits ? other : bits;
+        }
+        if ((threadIdx.x & 63) == 0 && bits) atomicMax(out + c, bits);
+    }
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicMax(out + 3, 1ull);
+}
+
+// ---- QuadNodes, one breadth-first level at a time
+// may inner node `id` be folded into its parent's QuadNode: its children's boxes lie inside its own (DESIGN B2)
+__device__ __forceinline__ bool folds(const ctgpu_node *nodes, uint32_t id) {
+    const ctgpu_node &c = nodes[id];
+    if (c.count) return false;
+    for (uint32_t side = 0; side < 2; side++) {
+        const ctgpu_node &g = nodes[c.left + side];
+        for (int a = 0; a < 3; a++)
+            if (!(g.bmin[a] >= c.bmin[a] && g.bmax[a] <= c.bmax[a])) return false;
+    }
+    return true;
+}
+// the entries of the QuadNode headed by reference node `head`, in the reference's visiting order
+__device__ __forceinline__ uint32_t quad_entries(const ctgpu_node *nodes, uint32_t head, bool fold, uint32_t entry[4]) {
+    uint32_t n = 0;
+    for (uint32_t side = 0; side < 2; side++) {
+        const uint32_t c = nodes[head].left + side;
+        if (fold && folds(nodes, c)) { entry[n++] = nodes[c].left; entry[n++] = nodes[c].left + 1; }
+        else entry[n++] = c;
+    }
+    return n;
+}
+__global__ void k_quad_count(const ctgpu_node *nodes, const uint32_t *head, uint32_t begin, uint32_t end, int fold,
+                             uint32_t *inner_entries) {
+    const uint32_t q = begin + blockIdx.x * kBlock + threadIdx.x;
+    if (q >= end) return;
+    uint32_t entry[4];
+    const uint32_t n = quad_entries(nodes, head[q], fold != 0, entry);
+    uint32_t inner = 0;
+    for (uint32_t k = 0; k < n; k++) inner += nodes[entry[k]].count == 0 ? 1u : 0u;
+    inner_entries[q - begin] = inner;
+}
+struct QuadOut {
+    QuadNode *quads;
+    double *boxes;            // [quad][4][6]
+    uint32_t *head, *before;  // per QuadNode: its reference node; entries pending on the stack when it is reached
+    uint32_t *pending_max;
+    float bound[3];
+};
+__global__ void k_quad_emit(const ctgpu_node *nodes, QuadOut out, uint32_t begin, uint32_t end, int fold, const uint32_t *offset) {
+    const uint32_t q = begin + blockIdx.x * kBlock + threadIdx.x;
+    if (q >= end) return;
+    uint32_t entry[4];
+    const uint32_t n = quad_entries(nodes, out.head[q], fold != 0, entry);
+    QuadNode node;
+    double box[4][6];
+    uint32_t next = end + offset[q - begin];              // slot of this QuadNode's first inner entry
+    const uint32_t before = out.before[q];
+    for (uint32_t k = 0; k < 4; k++) {
+        if (k < n) {
+            const ctgpu_node &e = nodes[entry[k]];
+            for (int a = 0; a < 3; a++) {
+                node.plane[k][a][0] = (float)e.bmin[a]; node.plane[k][a][1] = (float)e.bmax[a];
+                box[k][a] = e.bmin[a]; box[k][3 + a] = e.bmax[a];
+            }
+            if (e.count) node.ref[k] = kLeafBit | e.first;
+            else {
+                node.ref[k] = next;
+                out.head[next] = entry[k];
+                out.before[next] = before + n - 1u - k;
+                next += 1;
+            }
+        } else {
+            // absent entry: a one-point box at the corner of the plane bound (never entered, see ct_walk_packet)
+            for (int a = 0; a < 3; a++) { node.plane[k][a][0] = node.plane[k][a][1] = out.bound[a]; box[k][a] = 0.0; box[k][3 + a] = 0.0; }
+            node.ref[k] = 0u;
+        }
+    }
+    node.count = n;
+    node.pad_[0] = node.pad_[1] = node.pad_[2] = 0u;
+    out.quads[q] = node;
+    double *dst = out.boxes + (size_t)q * 24;
+    for (int i = 0; i < 24; i++) dst[i] = (&box[0][0])[i];
+    atomicMax(out.pending_max, before + n - 1u);
+}
+
+// ---- TriRecords (leaf order) and where scene triangle 0 went
+__global__ void k_tri_records(const double *verts, const uint32_t *indexes, uint32_t n, TriRecord *recs, uint32_t *slot0) {
+    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+    if (slot >= n) return;
+    const uint32_t tri = indexes[slot];
+    const double *v = verts + (size_t)tri * 9;
+    TriRecord t;
+    for (int c = 0; c < 3; c++) {
+        t.p1[c] = v[c];
+        t.e1[c] = v[3 + c] - v[c];      // p2 - p1, as bvh.cpp:148
+        t.e2[c] = v[6 + c] - v[c];      // p3 - p1, as bvh.cpp:149
+    }
+    t.triangle = tri;
+    t.remaining = 1u;                   // (k_leaf_remaining overwrites it; every slot lies in a leaf)
+    recs[slot] = t;
+    if (tri == 0u) *slot0 = slot;
+}
+__global__ void k_leaf_remaining(const ctgpu_node *nodes, uint32_t m, TriRecord *recs) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= m) return;
+    const uint32_t count = nodes[i].count, first = nodes[i].first;
+    for (uint32_t k = 0; k < count; k++) recs[first + k].remaining = count - k;
+}
+
+struct Owned {
+    std::vector<void *> blocks;
+    ~Owned() { for (void *p : blocks) (void)hipFree(p); }
+    template <typename T> hipError_t alloc(T *&ptr, size_t count) {
+        void *raw = nullptr;
+        const hipError_t e = hipMalloc(&raw, std::max<size_t>(count, 1) * sizeof(T));
+        if (e == hipSuccess) { ptr = (T *)raw; blocks.push_back(raw); }
+        return e;
+    }
+    void keep(void *p) { blocks.erase(std::find(blocks.begin(), blocks.end(), p)); }     // the caller's from now on
+};
+
+// one of the two QuadNode trees; arrays sized for the worst case (every inner node heads a QuadNode) and left so
+int build_quads(const ctgpu_node *d_nodes, bool root_is_inner, uint32_t n_inner, bool fold, const float bound[3], Owned &owned,
+                const Scanner &scan, uint32_t *d_counts, uint32_t *d_offsets, uint32_t *d_pending, QuadNode *&quads,
+                double *&boxes, uint32_t &n_quads, uint32_t &root, uint32_t &pending) {
+    const uint32_t room = std::max<uint32_t>(n_inner, 1);
+    HIP_TRY(owned.alloc(quads, room));
+    HIP_TRY(owned.alloc(boxes, (size_t)room * 24));
+    root = kLeafBit | 0u;
+    pending = 1;
+    if (!root_is_inner) {                             // a single leaf: one all-zero QuadNode nobody visits
+        HIP_TRY(hipMemsetAsync(quads, 0, sizeof(QuadNode), nullptr));
+        HIP_TRY(hipMemsetAsync(boxes, 0, 24 * sizeof(double), nullptr));
+        n_quads = 1;
+        return CTGPU_OK;
+    }
+    QuadOut out;
+    out.quads = quads; out.boxes = boxes; out.pending_max = d_pending;
+    std::memcpy(out.bound, bound, sizeof out.bound);
+    HIP_TRY(owned.alloc(out.head, room));
+    HIP_TRY(owned.alloc(out.before, room));
+    const uint32_t first[2] = {0u, 1u};               // QuadNode 0 is headed by reference node 0, nothing pending; pending starts at 1
+    HIP_TRY(hipMemcpy(out.head, &first[0], 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(out.before, &first[0], 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_pending, &first[1], 4, hipMemcpyHostToDevice));
+    root = 0;
+    uint32_t begin = 0, end = 1;
+    for (uint32_t level = 0; begin < end; level++) {
+        if (level > 2u * CTGPU_MAX_TREE_DEPTH + 2u) return ctgpu_fail(CTGPU_ERR_ARG, "node links form a cycle");
+        const uint32_t width = end - begin;
+        hipLaunchKernelGGL(k_quad_count, dim3(blocks_for(width)), dim3(kBlock), 0, nullptr, d_nodes, (const uint32_t *)out.head,
+                           begin, end, fold ? 1 : 0, d_counts);
+        scan.run(d_counts, width, d_offsets, nullptr);
+        hipLaunchKernelGGL(k_quad_emit, dim3(blocks_for(width)), dim3(kBlock), 0, nullptr, d_nodes, out, begin, end, fold ? 1 : 0,
+                           (const uint32_t *)d_offsets);
+        HIP_TRY(hipGetLastError());
+        uint32_t made = 0;
+        HIP_TRY(hipMemcpy(&made, d_offsets + width, 4, hipMemcpyDeviceToHost));
+        if ((uint64_t)end + made > room) return ctgpu_fail(CTGPU_ERR_ARG, "node links form a cycle");
+        begin = end;
+        end += made;
+    }
+    n_quads = end;
+    HIP_TRY(hipMemcpy(&pending, d_pending, 4, hipMemcpyDeviceToHost));
+    owned.keep(quads);
+    owned.keep(boxes);
+    return CTGPU_OK;
+}
+
+}  // namespace
+
+int ctgpu_pack_on_device(int device, const ctgpu_node *d_nodes, uint32_t m, const uint32_t *d_indexes, const double *d_verts,
+                         uint32_t n, ctgpu_packed_scene *out) {
+    if (!d_nodes || !d_indexes || !d_verts || !out || m == 0 || n == 0) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_pack_on_device: null argument");
+    HIP_TRY(hipSetDevice(device));
+    Owned owned;
+    struct Events {
+        hipEvent_t a = nullptr, b = nullptr;
+        ~Events() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); }
+    } ev;
+    HIP_TRY(hipEventCreate(&ev.a));
+    HIP_TRY(hipEventCreate(&ev.b));
+    HIP_TRY(hipEventRecord(ev.a, nullptr));
+
+    // ---- the root and the plane bound
+    ctgpu_node root_node;
+    HIP_TRY(hipMemcpy(&root_node, d_nodes, sizeof root_node, hipMemcpyDeviceToHost));
+    std::memcpy(out->root_min, root_node.bmin, 24);
+    std::memcpy(out->root_max, root_node.bmax, 24);
+    unsigned long long *d_bound = nullptr;
+    HIP_TRY(owned.alloc(d_bound, 4));
+    HIP_TRY(hipMemsetAsync(d_bound, 0, 4 * sizeof(unsigned long long), nullptr));
+    hipLaunchKernelGGL(k_bound, dim3(blocks_for(m)), dim3(kBlock), 0, nullptr, d_nodes, m, d_bound);
+
+    // ---- WideNodes: inner nodes in reference order
+    Scanner scan;
+    int rc = scan.prepare(m); if (rc) return rc;
+    uint32_t *d_flag = nullptr, *d_wide_of = nullptr;
+    HIP_TRY(owned.alloc(d_flag, m));
+    HIP_TRY(owned.alloc(d_wide_of, (size_t)m + 1));
+    hipLaunchKernelGGL(k_inner_flags, dim3(blocks_for(m)), dim3(kBlock), 0, nullptr, d_nodes, m, d_flag);
+    scan.run(d_flag, m, d_wide_of, nullptr);
+    HIP_TRY(hipGetLastError());
+    uint32_t n_inner = 0;
+    HIP_TRY(hipMemcpy(&n_inner, d_wide_of + m, 4, hipMemcpyDeviceToHost));
+    unsigned long long bound_bits[4];
+    HIP_TRY(hipMemcpy(bound_bits, d_bound, sizeof bound_bits, hipMemcpyDeviceToHost));
+    for (int c = 0; c < 3; c++) {
+        double big;
+        std::memcpy(&big, &bound_bits[c], 8);
+        out->plane_bound[c] = bound_bits[3] ? INFINITY : std::nextafterf((float)big, INFINITY);
+    }
+    WideNode *wide = nullptr;
+    out->n_wide = std::max<uint32_t>(n_inner, 1);
+    HIP_TRY(owned.alloc(wide, out->n_wide));
+    if (n_inner == 0) HIP_TRY(hipMemsetAsync(wide, 0, sizeof(WideNode), nullptr));
+    hipLaunchKernelGGL(k_wide, dim3(blocks_for(m)), dim3(kBlock), 0, nullptr, d_nodes, m, (const uint32_t *)d_wide_of, wide);
+    const bool root_is_inner = root_node.count == 0;
+    out->root_ref = root_is_inner ? 0u : (kLeafBit | root_node.first);       // (inner root: WideNode 0)
+
+    // ---- the two QuadNode trees
+    uint32_t *d_counts = nullptr, *d_offsets = nullptr, *d_pending = nullptr;
+    HIP_TRY(owned.alloc(d_counts, std::max<uint32_t>(n_inner, 1)));
+    HIP_TRY(owned.alloc(d_offsets, (size_t)std::max<uint32_t>(n_inner, 1) + 1));
+    HIP_TRY(owned.alloc(d_pending, 1));
+    QuadNode *quads = nullptr, *quads_flat = nullptr;
+    uint32_t pending = 1, pending_flat = 1;
+    rc = build_quads(d_nodes, root_is_inner, n_inner, true, out->plane_bound, owned, scan, d_counts, d_offsets, d_pending, quads,
+                     out->quad_boxes, out->n_quads, out->quad_root, pending);
+    if (rc) return rc;
+    rc = build_quads(d_nodes, root_is_inner, n_inner, false, out->plane_bound, owned, scan, d_counts, d_offsets, d_pending, quads_flat,
+                     out->quad_boxes_flat, out->n_quads_flat, out->quad_root_flat, pending_flat);
+    if (rc) return rc;
+    if (!root_is_inner) { owned.keep(quads); owned.keep(out->quad_boxes); owned.keep(quads_flat); owned.keep(out->quad_boxes_flat); }
+    out->quads = quads;
+    out->quads_flat = quads_flat;
+    out->quad_pending = std::max(pending, pending_flat);
+
+    // ---- TriRecords
+    TriRecord *recs = nullptr;
+    uint32_t *d_slot0 = nullptr;
+    HIP_TRY(owned.alloc(recs, n));
+    HIP_TRY(owned.alloc(d_slot0, 1));
+    HIP_TRY(hipMemsetAsync(d_slot0, 0, 4, nullptr));
+    hipLaunchKernelGGL(k_tri_records, dim3(blocks_for(n)), dim3(kBlock), 0, nullptr, d_verts, d_indexes, n, recs, d_slot0);
+    hipLaunchKernelGGL(k_leaf_remaining, dim3(blocks_for(m)), dim3(kBlock), 0, nullptr, d_nodes, m, recs);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(&out->slot_of_triangle0, d_slot0, 4, hipMemcpyDeviceToHost));
+
+    HIP_TRY(hipEventRecord(ev.b, nullptr));
+    HIP_TRY(hipEventSynchronize(ev.b));
+    float ms = 0.0f;
+    HIP_TRY(hipEventElapsedTime(&ms, ev.a, ev.b));
+    out->device_ms = ms;
+    owned.keep(wide);
+    owned.keep(recs);
+    out->wide = wide;
+    out->tris = recs;
+    return CTGPU_OK;
+}

@@ -14,6 +14,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -57,13 +58,15 @@ struct DeviceArray {
         return e;
     }
     void release() { if (ptr) (void)hipFree(ptr); ptr = nullptr; count = 0; }
+    void adopt(T *p, size_t n) { release(); ptr = p; count = n; }      // takes over a hipMalloc'ed block
 };
 
-struct ctgpu_ctx {
+// A scene resident in one device's HBM.  Immutable once packed, so the contexts of one device (frames in flight,
+// ranks of a test on one GPU) can share ONE copy (ctgpu_share_scene): the dragon is ~0.5 GB per copy.
+struct SceneStore {
     int device = 0;
-    bool has_scene = false;
     bool has_reflection = false;
-    uint32_t n_triangles = 0, n_lights = 0, tree_depth = 0;
+    uint32_t n_triangles = 0, n_lights = 0, tree_depth = 0, n_nodes = 0;
     uint32_t root_ref = 0, slot_of_triangle0 = 0;
     double root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
 
@@ -71,6 +74,7 @@ struct ctgpu_ctx {
     DeviceArray<QuadNode> quads, quads_flat;
     DeviceArray<double> quad_boxes, quad_boxes_flat;      // [quad][entry][6]: the entries' binary64 boxes
     uint32_t quad_root = 0, quad_root_flat = 0, quad_pending = 1;
+    uint32_t n_quads = 0, n_quads_flat = 0;
     float plane_bound[3] = {0, 0, 0};
     DeviceArray<TriRecord> tris;
     DeviceArray<Material> materials;
@@ -79,6 +83,24 @@ struct ctgpu_ctx {
     DeviceArray<ctgpu_node> sphere_nodes;
     DeviceArray<uint32_t> sphere_indexes;
     uint32_t n_spheres = 0, sphere_tree_depth = 0;
+    DeviceArray<uint32_t> shadow_lights;
+    uint32_t n_shadow_lights = 0;
+    // the reference's own arrays, kept on the device when the tree was built there (ctgpu_download_tree)
+    DeviceArray<ctgpu_node> ref_nodes;
+    DeviceArray<uint32_t> ref_indexes;
+    double build_ms = 0.0, pack_ms = 0.0;       // device time of BuildBVH and of the packing kernels
+
+    ~SceneStore() {
+        (void)hipSetDevice(device);
+        nodes.release(); quads.release(); quads_flat.release(); quad_boxes.release(); quad_boxes_flat.release();
+        tris.release(); materials.release(); lights.release(); spheres.release(); sphere_nodes.release();
+        sphere_indexes.release(); shadow_lights.release(); ref_nodes.release(); ref_indexes.release();
+    }
+};
+
+struct ctgpu_ctx {
+    int device = 0;
+    std::shared_ptr<SceneStore> scene;          // null until ctgpu_upload_scene / ctgpu_share_scene
 
     DeviceArray<uint32_t> tiles;       // compact tile buffer of a whole-frame render
     DeviceArray<uint32_t> fb;          // device framebuffer of ctgpu_render
@@ -96,9 +118,7 @@ struct ctgpu_ctx {
     DeviceArray<uint8_t> shadow;
     DeviceArray<unsigned long long> queue;      // 1 + 32 ray counters, then the hit count
     DeviceArray<unsigned long long> spill;      // stack entries beyond the LDS part
-    DeviceArray<uint32_t> shadow_lights;
     DeviceArray<unsigned long long> walk_work;  // [64][8] fetch counters of the packet walks (ct_params.h)
-    uint32_t n_shadow_lights = 0;
     bool kernel_timing = false;                 // ctgpu_kernel_timing: events around every pipeline kernel
     std::vector<hipEvent_t> marks;              // (kPipelineKernels + 1) per timed frame
     size_t marks_used = 0;
@@ -266,12 +286,11 @@ extern "C" void ctgpu_destroy(ctgpu_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     (void)ctgpu_comm_destroy(ctx);
     ctgpu_multi_comms_release(ctx->multi_comms);
-    ctx->nodes.release(); ctx->quads.release(); ctx->quad_boxes.release(); ctx->quads_flat.release(); ctx->quad_boxes_flat.release(); ctx->tris.release(); ctx->materials.release(); ctx->lights.release();
+    ctx->scene.reset();
     ctx->tiles.release(); ctx->fb.release(); ctx->gathered.release(); ctx->counters.release(); ctx->overflow.release();
     ctx->rand_table.release(); ctx->row_ordinal.release();
     ctx->coords.release(); ctx->hits.release(); ctx->shadow.release(); ctx->queue.release(); ctx->spill.release();
-    ctx->shadow_lights.release(); ctx->walk_work.release();
-    ctx->spheres.release(); ctx->sphere_nodes.release(); ctx->sphere_indexes.release();
+    ctx->walk_work.release();
     for (hipEvent_t e : ctx->marks) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->phase_marks) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -283,17 +302,13 @@ extern "C" void ctgpu_destroy(ctgpu_ctx *ctx) {
 }
 
 // ------------------------------------------------------------------ scene upload
-extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
-    if (!ctx || !s) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_upload_scene: null argument");
-    if (s->n_triangles == 0 || s->n_nodes == 0 || !s->vertices || !s->materials || !s->nodes || !s->indexes)
-        return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_upload_scene: empty scene or null array");
-    if (s->n_lights && !s->lights) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_upload_scene: null light array");
-    if (s->n_nodes > 2u * s->n_triangles) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_upload_scene: more nodes than 2N-1");
-    if (ctx->pending.active) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_upload_scene: a frame is in flight on this context (ctgpu_render_poll)");
-    HIP_TRY(hipSetDevice(ctx->device));
+namespace {
 
+// A caller's tree is checked on the host before the device trusts it: child links and leaf ranges in range, no
+// cycle, depth within the stack bound.  (A tree this library built itself, ctgpu_build_bvh's arrays, needs none of it.)
+int validate_tree(const ctgpu_scene_desc *s, uint32_t &depth) {
     const uint32_t N = s->n_triangles, M = s->n_nodes;
-    // validate the tree before trusting it on the device: child links and leaf ranges in range
+    if (M > 2u * N) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_upload_scene: more nodes than 2N-1");
     for (uint32_t i = 0; i < M; i++) {
         const ctgpu_node &n = s->nodes[i];
         if (n.count == 0) {
@@ -304,18 +319,34 @@ extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
     }
     for (uint32_t i = 0; i < N; i++)
         if (s->indexes[i] >= N) return ctgpu_fail(CTGPU_ERR_ARG, "indexes[%u] out of range", i);
+    depth = 0;
+    std::vector<std::pair<uint32_t, uint32_t>> todo;
+    todo.push_back({0u, 1u});
+    size_t visited = 0;
+    while (!todo.empty()) {
+        const auto [id, d] = todo.back();
+        todo.pop_back();
+        if (++visited > M) return ctgpu_fail(CTGPU_ERR_ARG, "node links form a cycle");
+        depth = std::max(depth, d);
+        const ctgpu_node &n = s->nodes[id];
+        if (n.count == 0) { todo.push_back({n.left, d + 1}); todo.push_back({n.left + 1, d + 1}); }
+    }
+    if (depth > CTGPU_MAX_TREE_DEPTH) return ctgpu_fail(CTGPU_ERR_STACK, "tree depth %u exceeds %d", depth, CTGPU_MAX_TREE_DEPTH);
+    return CTGPU_OK;
+}
 
-    // inner nodes get consecutive WideNode slots in reference order
+// The packing on the HOST (CTGPU_PACK=host): the serial restatement the device kernels of ct_pack.hip are compared
+// with, array for array (tests/test_gpu_scene_pack.py).  Not the default: 0.34 s for the dragon against a few ms.
+int pack_on_host(SceneStore &S, const ctgpu_scene_desc *s) {
+    const uint32_t N = s->n_triangles, M = s->n_nodes;
     std::vector<uint32_t> wide_of(M, kNoNode);
     uint32_t n_wide = 0;
     for (uint32_t i = 0; i < M; i++)
         if (s->nodes[i].count == 0) wide_of[i] = n_wide++;
-
     auto child_ref = [&](uint32_t id) -> uint32_t {
         const ctgpu_node &c = s->nodes[id];
         return c.count ? (kLeafBit | c.first) : wide_of[id];
     };
-
     std::vector<WideNode> wide(std::max<uint32_t>(n_wide, 1));
     std::memset(wide.data(), 0, wide.size() * sizeof(WideNode));
     for (uint32_t i = 0; i < M; i++) {
@@ -341,7 +372,7 @@ extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
         }
     }
     for (int c = 0; c < 3; c++)
-        ctx->plane_bound[c] = bound_ok ? std::nextafterf((float)bound[c], INFINITY) : INFINITY;
+        S.plane_bound[c] = bound_ok ? std::nextafterf((float)bound[c], INFINITY) : INFINITY;
 
     // an inner node may be folded into its parent's QuadNode when its children's boxes lie inside its own
     auto folds = [&](uint32_t id) {
@@ -372,8 +403,7 @@ extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
             QuadNode node;
             std::memset(&node, 0, sizeof node);
             double boxes[4][6] = {};
-            auto add = [&](uint32_t id, uint32_t parent, uint32_t side) {
-                (void)parent; (void)side;
+            auto add = [&](uint32_t id) {
                 const ctgpu_node &e = s->nodes[id];
                 const uint32_t k = node.count++;
                 for (int a = 0; a < 3; a++) { node.plane[k][a][0] = (float)e.bmin[a]; node.plane[k][a][1] = (float)e.bmax[a]; }
@@ -382,12 +412,12 @@ extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
             };
             for (uint32_t side = 0; side < 2; side++) {
                 const uint32_t c = s->nodes[head].left + side;
-                if (fold && folds(c)) { add(s->nodes[c].left, c, 0); add(s->nodes[c].left + 1, c, 1); }
-                else add(c, head, side);
+                if (fold && folds(c)) { add(s->nodes[c].left); add(s->nodes[c].left + 1); }
+                else add(c);
             }
             // absent entries: a one-point box at the corner of the plane bound (never entered, see ct_walk_packet)
             for (uint32_t k = node.count; k < 4; k++)
-                for (int a = 0; a < 3; a++) node.plane[k][a][0] = node.plane[k][a][1] = ctx->plane_bound[a];
+                for (int a = 0; a < 3; a++) node.plane[k][a][0] = node.plane[k][a][1] = S.plane_bound[a];
             out.quads.push_back(node);
             out.boxes.insert(out.boxes.end(), &boxes[0][0], &boxes[0][0] + 24);
         }
@@ -412,30 +442,13 @@ extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
     Folded folded, flat;
     if (!build_quads(true, folded) || !build_quads(false, flat)) return ctgpu_fail(CTGPU_ERR_ARG, "node links form a cycle");
 
-    // leaf-ordered triangle records; a tree walk gives depth and the leaf extents
+    // leaf-ordered triangle records
     std::vector<TriRecord> recs(N);
     std::vector<uint32_t> remaining(N, 1);
-    uint32_t depth = 0;
-    {
-        std::vector<std::pair<uint32_t, uint32_t>> todo;
-        todo.push_back({0u, 1u});
-        size_t visited = 0;
-        while (!todo.empty()) {
-            const auto [id, d] = todo.back();
-            todo.pop_back();
-            if (++visited > M) return ctgpu_fail(CTGPU_ERR_ARG, "node links form a cycle");
-            depth = std::max(depth, d);
-            const ctgpu_node &n = s->nodes[id];
-            if (n.count) {
-                for (uint32_t k = 0; k < n.count; k++) remaining[n.first + k] = n.count - k;
-            } else {
-                todo.push_back({n.left, d + 1});
-                todo.push_back({n.left + 1, d + 1});
-            }
-        }
+    for (uint32_t i = 0; i < M; i++) {
+        const ctgpu_node &n = s->nodes[i];
+        for (uint32_t k = 0; k < n.count; k++) remaining[n.first + k] = n.count - k;
     }
-    if (depth > CTGPU_MAX_TREE_DEPTH) return ctgpu_fail(CTGPU_ERR_STACK, "tree depth %u exceeds %d", depth, CTGPU_MAX_TREE_DEPTH);
-
     uint32_t slot0 = 0;
     for (uint32_t slot = 0; slot < N; slot++) {
         const uint32_t tri = s->indexes[slot];
@@ -451,44 +464,117 @@ extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
         if (tri == 0) slot0 = slot;
     }
 
+    HIP_TRY(S.nodes.resize(wide.size()));
+    HIP_TRY(S.tris.resize(N));
+    HIP_TRY(hipMemcpy(S.nodes.ptr, wide.data(), wide.size() * sizeof(WideNode), hipMemcpyHostToDevice));
+    HIP_TRY(S.quads.resize(folded.quads.size()));
+    HIP_TRY(hipMemcpy(S.quads.ptr, folded.quads.data(), folded.quads.size() * sizeof(QuadNode), hipMemcpyHostToDevice));
+    HIP_TRY(S.quad_boxes.resize(folded.boxes.size()));
+    HIP_TRY(hipMemcpy(S.quad_boxes.ptr, folded.boxes.data(), folded.boxes.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(S.quads_flat.resize(flat.quads.size()));
+    HIP_TRY(hipMemcpy(S.quads_flat.ptr, flat.quads.data(), flat.quads.size() * sizeof(QuadNode), hipMemcpyHostToDevice));
+    HIP_TRY(S.quad_boxes_flat.resize(flat.boxes.size()));
+    HIP_TRY(hipMemcpy(S.quad_boxes_flat.ptr, flat.boxes.data(), flat.boxes.size() * sizeof(double), hipMemcpyHostToDevice));
+    S.quad_root = folded.root;
+    S.quad_root_flat = flat.root;
+    S.n_quads = (uint32_t)folded.quads.size();
+    S.n_quads_flat = (uint32_t)flat.quads.size();
+    S.quad_pending = std::max(folded.pending, flat.pending);
+    HIP_TRY(hipMemcpy(S.tris.ptr, recs.data(), (size_t)N * sizeof(TriRecord), hipMemcpyHostToDevice));
+    S.root_ref = s->nodes[0].count ? (kLeafBit | s->nodes[0].first) : wide_of[0];
+    S.slot_of_triangle0 = slot0;
+    return CTGPU_OK;
+}
+
+}  // namespace
+
+// Scene -> HBM.  With a tree in the descriptor (nodes / indexes: the reference's arrays, from the host builder or
+// from anyone else) the tree is validated on the host, copied as it is (64 B per node, 4 B per index, 72 B per
+// triangle) and re-laid-out for the walks ON THE DEVICE (ct_pack.hip).  With nodes == indexes == NULL the tree is
+// BUILT on the device as well (ct_build.hip: BuildBVH, bvh.cpp:16-121, the reference's arrays byte for byte) and never
+// leaves it: vertices in, first frame out (ctgpu_download_tree hands the arrays back to a host that wants them).
+extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
+    if (!ctx || !s) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_upload_scene: null argument");
+    const bool build_here = !s->nodes && !s->indexes && s->n_nodes == 0;
+    if (s->n_triangles == 0 || !s->vertices || !s->materials || (!build_here && (s->n_nodes == 0 || !s->nodes || !s->indexes)))
+        return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_upload_scene: empty scene or null array");
+    if (s->n_lights && !s->lights) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_upload_scene: null light array");
+    if (ctx->pending.active) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_upload_scene: a frame is in flight on this context (ctgpu_render_poll)");
+    HIP_TRY(hipSetDevice(ctx->device));
+    // (frames of this context that may still be running read the old scene: it stays alive until they are done)
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+
+    const uint32_t N = s->n_triangles;
+    auto store = std::make_shared<SceneStore>();
+    SceneStore &S = *store;
+    S.device = ctx->device;
+    const char *where = std::getenv("CTGPU_PACK");
+    const bool host_pack = where && std::strcmp(where, "host") == 0;
+
+    uint32_t depth = 0, M = s->n_nodes;
+    if (!build_here) { int rc = validate_tree(s, depth); if (rc) return rc; }
+    if (host_pack && !build_here) {
+        int rc = pack_on_host(S, s); if (rc) return rc;
+        std::memcpy(S.root_min, s->nodes[0].bmin, 24);
+        std::memcpy(S.root_max, s->nodes[0].bmax, 24);
+    } else {
+        DeviceArray<double> d_verts;
+        struct Free { DeviceArray<double> &a; ~Free() { a.release(); } } free_verts{d_verts};
+        HIP_TRY(d_verts.resize((size_t)N * 9));
+        HIP_TRY(hipMemcpy(d_verts.ptr, s->vertices, (size_t)N * 9 * sizeof(double), hipMemcpyHostToDevice));
+        if (build_here) {
+            ctgpu_node *d_nodes = nullptr;
+            uint32_t *d_idx = nullptr;
+            int rc = ctgpu_build_bvh_resident(ctx->device, d_verts.ptr, N, &d_nodes, &d_idx, &M, &depth, &S.build_ms); if (rc) return rc;
+            S.ref_nodes.adopt(d_nodes, M);
+            S.ref_indexes.adopt(d_idx, N);
+        } else {
+            HIP_TRY(S.ref_nodes.resize(M));
+            HIP_TRY(S.ref_indexes.resize(N));
+            HIP_TRY(hipMemcpy(S.ref_nodes.ptr, s->nodes, (size_t)M * sizeof(ctgpu_node), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(S.ref_indexes.ptr, s->indexes, (size_t)N * sizeof(uint32_t), hipMemcpyHostToDevice));
+        }
+        ctgpu_packed_scene packed;
+        int rc = ctgpu_pack_on_device(ctx->device, S.ref_nodes.ptr, M, S.ref_indexes.ptr, d_verts.ptr, N, &packed); if (rc) return rc;
+        S.nodes.adopt((WideNode *)packed.wide, packed.n_wide);
+        S.quads.adopt((QuadNode *)packed.quads, packed.n_quads);
+        S.quad_boxes.adopt(packed.quad_boxes, (size_t)packed.n_quads * 24);
+        S.quads_flat.adopt((QuadNode *)packed.quads_flat, packed.n_quads_flat);
+        S.quad_boxes_flat.adopt(packed.quad_boxes_flat, (size_t)packed.n_quads_flat * 24);
+        S.tris.adopt((TriRecord *)packed.tris, N);
+        S.quad_root = packed.quad_root; S.quad_root_flat = packed.quad_root_flat;
+        S.n_quads = packed.n_quads; S.n_quads_flat = packed.n_quads_flat;
+        S.quad_pending = packed.quad_pending;
+        std::memcpy(S.plane_bound, packed.plane_bound, sizeof S.plane_bound);
+        S.root_ref = packed.root_ref;
+        S.slot_of_triangle0 = packed.slot_of_triangle0;
+        std::memcpy(S.root_min, packed.root_min, 24);
+        std::memcpy(S.root_max, packed.root_max, 24);
+        S.pack_ms = packed.device_ms;
+        if (!build_here) { S.ref_nodes.release(); S.ref_indexes.release(); }       // the caller holds these already
+    }
+    if (depth > CTGPU_MAX_TREE_DEPTH) return ctgpu_fail(CTGPU_ERR_STACK, "tree depth %u exceeds %d", depth, CTGPU_MAX_TREE_DEPTH);
+
     bool reflective = false;
     for (uint32_t i = 0; i < N; i++) reflective = reflective || (s->materials[i].reflection > 0);
-
-    HIP_TRY(ctx->nodes.resize(wide.size()));
-    HIP_TRY(ctx->tris.resize(N));
-    HIP_TRY(ctx->materials.resize(N));
-    HIP_TRY(ctx->lights.resize(std::max<uint32_t>(s->n_lights, 1)));
-    HIP_TRY(hipMemcpy(ctx->nodes.ptr, wide.data(), wide.size() * sizeof(WideNode), hipMemcpyHostToDevice));
-    HIP_TRY(ctx->quads.resize(folded.quads.size()));
-    HIP_TRY(hipMemcpy(ctx->quads.ptr, folded.quads.data(), folded.quads.size() * sizeof(QuadNode), hipMemcpyHostToDevice));
-    HIP_TRY(ctx->quad_boxes.resize(folded.boxes.size()));
-    HIP_TRY(hipMemcpy(ctx->quad_boxes.ptr, folded.boxes.data(), folded.boxes.size() * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(ctx->quads_flat.resize(flat.quads.size()));
-    HIP_TRY(hipMemcpy(ctx->quads_flat.ptr, flat.quads.data(), flat.quads.size() * sizeof(QuadNode), hipMemcpyHostToDevice));
-    HIP_TRY(ctx->quad_boxes_flat.resize(flat.boxes.size()));
-    HIP_TRY(hipMemcpy(ctx->quad_boxes_flat.ptr, flat.boxes.data(), flat.boxes.size() * sizeof(double), hipMemcpyHostToDevice));
-    ctx->quad_root = folded.root;
-    ctx->quad_root_flat = flat.root;
-    ctx->quad_pending = std::max(folded.pending, flat.pending);
-    HIP_TRY(hipMemcpy(ctx->tris.ptr, recs.data(), (size_t)N * sizeof(TriRecord), hipMemcpyHostToDevice));
     static_assert(sizeof(Material) == sizeof(ctgpu_material), "material layout");
     static_assert(sizeof(Light) == sizeof(ctgpu_light), "light layout");
-    HIP_TRY(hipMemcpy(ctx->materials.ptr, s->materials, (size_t)N * sizeof(Material), hipMemcpyHostToDevice));
+    HIP_TRY(S.materials.resize(N));
+    HIP_TRY(S.lights.resize(std::max<uint32_t>(s->n_lights, 1)));
+    HIP_TRY(hipMemcpy(S.materials.ptr, s->materials, (size_t)N * sizeof(Material), hipMemcpyHostToDevice));
     if (s->n_lights)
-        HIP_TRY(hipMemcpy(ctx->lights.ptr, s->lights, (size_t)s->n_lights * sizeof(Light), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(S.lights.ptr, s->lights, (size_t)s->n_lights * sizeof(Light), hipMemcpyHostToDevice));
 
     // non-ambient lights, in file order: each gets one shadow ray per hit (raythread.cpp:289-307)
     std::vector<uint32_t> shadow_lights;
     for (uint32_t i = 0; i < s->n_lights; i++)
         if (s->lights[i].type == CTGPU_LIGHT_POINT || s->lights[i].type == CTGPU_LIGHT_DIRECTIONAL) shadow_lights.push_back(i);
-    HIP_TRY(ctx->shadow_lights.resize(std::max<size_t>(shadow_lights.size(), 1)));
+    HIP_TRY(S.shadow_lights.resize(std::max<size_t>(shadow_lights.size(), 1)));
     if (!shadow_lights.empty())
-        HIP_TRY(hipMemcpy(ctx->shadow_lights.ptr, shadow_lights.data(), shadow_lights.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    ctx->n_shadow_lights = (uint32_t)shadow_lights.size();
+        HIP_TRY(hipMemcpy(S.shadow_lights.ptr, shadow_lights.data(), shadow_lights.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    S.n_shadow_lights = (uint32_t)shadow_lights.size();
 
     // ---- spheres and their tree (optional; validated like the triangle tree)
-    ctx->n_spheres = 0;
-    ctx->sphere_tree_depth = 0;
     if (s->n_spheres) {
         if (!s->spheres || !s->sphere_nodes || !s->sphere_indexes || s->n_sphere_nodes == 0 || s->n_sphere_nodes > 2u * s->n_spheres)
             return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_upload_scene: sphere arrays missing or inconsistent");
@@ -513,26 +599,93 @@ extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
             if (s->sphere_nodes[id].count == 0) { todo.push_back({s->sphere_nodes[id].left, d + 1}); todo.push_back({s->sphere_nodes[id].left + 1, d + 1}); }
         }
         if (sphere_depth > CTGPU_MAX_TREE_DEPTH) return ctgpu_fail(CTGPU_ERR_STACK, "sphere tree depth %u exceeds %d", sphere_depth, CTGPU_MAX_TREE_DEPTH);
-        HIP_TRY(ctx->spheres.resize(s->n_spheres));
-        HIP_TRY(ctx->sphere_nodes.resize(s->n_sphere_nodes));
-        HIP_TRY(ctx->sphere_indexes.resize(s->n_spheres));
-        HIP_TRY(hipMemcpy(ctx->spheres.ptr, s->spheres, (size_t)s->n_spheres * sizeof(ctgpu_sphere), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(ctx->sphere_nodes.ptr, s->sphere_nodes, (size_t)s->n_sphere_nodes * sizeof(ctgpu_node), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(ctx->sphere_indexes.ptr, s->sphere_indexes, (size_t)s->n_spheres * sizeof(uint32_t), hipMemcpyHostToDevice));
-        ctx->n_spheres = s->n_spheres;
-        ctx->sphere_tree_depth = sphere_depth;
+        HIP_TRY(S.spheres.resize(s->n_spheres));
+        HIP_TRY(S.sphere_nodes.resize(s->n_sphere_nodes));
+        HIP_TRY(S.sphere_indexes.resize(s->n_spheres));
+        HIP_TRY(hipMemcpy(S.spheres.ptr, s->spheres, (size_t)s->n_spheres * sizeof(ctgpu_sphere), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(S.sphere_nodes.ptr, s->sphere_nodes, (size_t)s->n_sphere_nodes * sizeof(ctgpu_node), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(S.sphere_indexes.ptr, s->sphere_indexes, (size_t)s->n_spheres * sizeof(uint32_t), hipMemcpyHostToDevice));
+        S.n_spheres = s->n_spheres;
+        S.sphere_tree_depth = sphere_depth;
         for (uint32_t i = 0; i < s->n_spheres; i++) reflective = reflective || (s->spheres[i].material.reflection > 0);
     }
 
-    ctx->n_triangles = N;
-    ctx->n_lights = s->n_lights;
-    ctx->tree_depth = depth;
-    ctx->root_ref = s->nodes[0].count ? (kLeafBit | s->nodes[0].first) : wide_of[0];
-    ctx->slot_of_triangle0 = slot0;
-    std::memcpy(ctx->root_min, s->nodes[0].bmin, 24);
-    std::memcpy(ctx->root_max, s->nodes[0].bmax, 24);
-    ctx->has_reflection = reflective;
-    ctx->has_scene = true;
+    S.n_triangles = N;
+    S.n_nodes = M;
+    S.n_lights = s->n_lights;
+    S.tree_depth = depth;
+    S.has_reflection = reflective;
+    ctx->scene = store;
+    return CTGPU_OK;
+}
+
+// Another context of the same device takes the owner's scene as its own: one copy in HBM, however many frames are
+// in flight.  The scene lives as long as any context holds it.
+extern "C" int ctgpu_share_scene(ctgpu_ctx *ctx, ctgpu_ctx *owner) {
+    if (!ctx || !owner) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_share_scene: null argument");
+    if (!owner->scene) return ctgpu_fail(CTGPU_ERR_NO_SCENE, "ctgpu_share_scene: the other context has no scene");
+    if (owner->device != ctx->device) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_share_scene: the contexts sit on different devices");
+    if (ctx->pending.active) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_share_scene: a frame is in flight on this context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    ctx->scene = owner->scene;
+    return CTGPU_OK;
+}
+
+// The reference's arrays of a tree that was built on the device (bvhNodes[] and triangles.indexes): nodes_out has
+// room for 2N - 1 records, indexes_out for N.
+extern "C" int ctgpu_download_tree(ctgpu_ctx *ctx, ctgpu_node *nodes_out, uint32_t *indexes_out, uint32_t *n_nodes) {
+    if (!ctx || !n_nodes) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_download_tree: null argument");
+    if (!ctx->scene) return ctgpu_fail(CTGPU_ERR_NO_SCENE, "no scene uploaded");
+    const SceneStore &S = *ctx->scene;
+    if (!S.ref_nodes.ptr) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_download_tree: this scene's tree came from the caller");
+    HIP_TRY(hipSetDevice(ctx->device));
+    *n_nodes = S.n_nodes;
+    if (nodes_out) HIP_TRY(hipMemcpy(nodes_out, S.ref_nodes.ptr, (size_t)S.n_nodes * sizeof(ctgpu_node), hipMemcpyDeviceToHost));
+    if (indexes_out) HIP_TRY(hipMemcpy(indexes_out, S.ref_indexes.ptr, (size_t)S.n_triangles * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return CTGPU_OK;
+}
+
+// What the upload cost on the device and what it left in HBM (measurement / tests).
+extern "C" int ctgpu_scene_info(ctgpu_ctx *ctx, ctgpu_scene_info_t *out) {
+    if (!ctx || !out) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_scene_info: null argument");
+    if (!ctx->scene) return ctgpu_fail(CTGPU_ERR_NO_SCENE, "no scene uploaded");
+    const SceneStore &S = *ctx->scene;
+    std::memset(out, 0, sizeof *out);
+    out->n_triangles = S.n_triangles; out->n_nodes = S.n_nodes; out->tree_depth = S.tree_depth;
+    out->n_wide = (uint32_t)S.nodes.count; out->n_quads = S.n_quads; out->n_quads_flat = S.n_quads_flat;
+    out->quad_root = S.quad_root; out->quad_root_flat = S.quad_root_flat; out->quad_pending = S.quad_pending;
+    out->root_ref = S.root_ref; out->slot_of_triangle0 = S.slot_of_triangle0;
+    std::memcpy(out->plane_bound, S.plane_bound, sizeof out->plane_bound);
+    out->build_ms = S.build_ms; out->pack_ms = S.pack_ms;
+    out->shared_by = (uint32_t)ctx->scene.use_count();
+    out->hbm_bytes = S.nodes.count * sizeof(WideNode) + (S.quads.count + S.quads_flat.count) * sizeof(QuadNode) +
+                     (S.quad_boxes.count + S.quad_boxes_flat.count) * sizeof(double) + S.tris.count * sizeof(TriRecord) +
+                     S.materials.count * sizeof(Material) + S.ref_nodes.count * sizeof(ctgpu_node) + S.ref_indexes.count * 4;
+    return CTGPU_OK;
+}
+
+// The packed arrays themselves, for comparing the device packing with the host's (which: 0 WideNodes, 1 QuadNodes,
+// 2 their boxes, 3 unfolded QuadNodes, 4 their boxes, 5 TriRecords).  bytes = room in out; *needed = size of the array.
+extern "C" int ctgpu_debug_scene_array(ctgpu_ctx *ctx, int which, void *out, uint64_t bytes, uint64_t *needed) {
+    if (!ctx || !needed) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_debug_scene_array: null argument");
+    if (!ctx->scene) return ctgpu_fail(CTGPU_ERR_NO_SCENE, "no scene uploaded");
+    const SceneStore &S = *ctx->scene;
+    const void *src = nullptr;
+    uint64_t size = 0;
+    switch (which) {
+        case 0: src = S.nodes.ptr; size = (uint64_t)S.nodes.count * sizeof(WideNode); break;
+        case 1: src = S.quads.ptr; size = (uint64_t)S.n_quads * sizeof(QuadNode); break;
+        case 2: src = S.quad_boxes.ptr; size = (uint64_t)S.n_quads * 24 * sizeof(double); break;
+        case 3: src = S.quads_flat.ptr; size = (uint64_t)S.n_quads_flat * sizeof(QuadNode); break;
+        case 4: src = S.quad_boxes_flat.ptr; size = (uint64_t)S.n_quads_flat * 24 * sizeof(double); break;
+        case 5: src = S.tris.ptr; size = (uint64_t)S.n_triangles * sizeof(TriRecord); break;
+        default: return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_debug_scene_array: unknown array %d", which);
+    }
+    *needed = size;
+    if (!out || bytes < size) return CTGPU_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpy(out, src, size, hipMemcpyDeviceToHost));
     return CTGPU_OK;
 }
 
@@ -594,22 +747,22 @@ int fill_params(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, const ctgpu_partition
                 FrameParams &P, hipStream_t stream) {
     const Geometry g = geometry(f);
     std::memset(&P, 0, sizeof P);
-    P.nodes = ctx->nodes.ptr; P.quads = ctx->quads.ptr; P.quad_boxes = ctx->quad_boxes.ptr; P.quad_root = ctx->quad_root;
-    P.quads_flat = ctx->quads_flat.ptr; P.quad_boxes_flat = ctx->quad_boxes_flat.ptr; P.quad_root_flat = ctx->quad_root_flat; P.tris = ctx->tris.ptr; P.materials = ctx->materials.ptr; P.lights = ctx->lights.ptr;
-    P.n_lights = ctx->n_lights;
-    if ((f->flags & CTGPU_F_SPHERES) && ctx->n_spheres) {
-        P.spheres = ctx->spheres.ptr; P.sphere_nodes = ctx->sphere_nodes.ptr; P.sphere_indexes = ctx->sphere_indexes.ptr;
-        P.n_spheres = ctx->n_spheres;
+    P.nodes = ctx->scene->nodes.ptr; P.quads = ctx->scene->quads.ptr; P.quad_boxes = ctx->scene->quad_boxes.ptr; P.quad_root = ctx->scene->quad_root;
+    P.quads_flat = ctx->scene->quads_flat.ptr; P.quad_boxes_flat = ctx->scene->quad_boxes_flat.ptr; P.quad_root_flat = ctx->scene->quad_root_flat; P.tris = ctx->scene->tris.ptr; P.materials = ctx->scene->materials.ptr; P.lights = ctx->scene->lights.ptr;
+    P.n_lights = ctx->scene->n_lights;
+    if ((f->flags & CTGPU_F_SPHERES) && ctx->scene->n_spheres) {
+        P.spheres = ctx->scene->spheres.ptr; P.sphere_nodes = ctx->scene->sphere_nodes.ptr; P.sphere_indexes = ctx->scene->sphere_indexes.ptr;
+        P.n_spheres = ctx->scene->n_spheres;
     }
     P.reflect_fix = (f->flags & CTGPU_F_REFLECT_FIX) ? 1u : 0u;
-    P.root_ref = ctx->root_ref;
-    P.slot_of_triangle0 = ctx->slot_of_triangle0;
+    P.root_ref = ctx->scene->root_ref;
+    P.slot_of_triangle0 = ctx->scene->slot_of_triangle0;
     // pending right siblings never exceed the tree depth; COUNT mode also parks rejected ones
-    P.stack_depth = std::max<uint32_t>(ctx->tree_depth, 2);
+    P.stack_depth = std::max<uint32_t>(ctx->scene->tree_depth, 2);
     (void)count_mode;
-    std::memcpy(P.plane_bound, ctx->plane_bound, 12);
-    std::memcpy(P.root_min, ctx->root_min, 24);
-    std::memcpy(P.root_max, ctx->root_max, 24);
+    std::memcpy(P.plane_bound, ctx->scene->plane_bound, 12);
+    std::memcpy(P.root_min, ctx->scene->root_min, 24);
+    std::memcpy(P.root_max, ctx->scene->root_max, 24);
     P.width = f->width; P.height = f->height; P.half = g.half;
     P.square = g.square; P.rendered_rows = g.rendered_rows; P.rows_per_band = g.rows_per_band;
     P.subsample = (f->flags & CTGPU_F_SUBSAMPLE) ? 1u : 0u;
@@ -658,7 +811,7 @@ int check_overflow(ctgpu_ctx *ctx) {
     HIP_TRY(hipMemcpy(&flag, ctx->overflow.ptr, sizeof flag, hipMemcpyDeviceToHost));
     if (flag) {
         HIP_TRY(hipMemset(ctx->overflow.ptr, 0, sizeof flag));
-        return ctgpu_fail(CTGPU_ERR_STACK, "traversal stack overflow (tree depth %u)", ctx->tree_depth);
+        return ctgpu_fail(CTGPU_ERR_STACK, "traversal stack overflow (tree depth %u)", ctx->scene->tree_depth);
     }
     return CTGPU_OK;
 }
@@ -700,9 +853,9 @@ namespace {
 // more than 32 shadow-casting lights take the megakernel.
 bool pipeline_eligible(const ctgpu_ctx *ctx, const ctgpu_frame_desc *f) {
     if (ctx->force_megakernel) return false;
-    if (ctx->has_reflection && f->max_depth > 0) return false;
-    if ((f->flags & CTGPU_F_SPHERES) && ctx->n_spheres) return false;       // spheres are rendered by the general path
-    return ctx->n_shadow_lights <= 32;
+    if (ctx->scene->has_reflection && f->max_depth > 0) return false;
+    if ((f->flags & CTGPU_F_SPHERES) && ctx->scene->n_spheres) return false;       // spheres are rendered by the general path
+    return ctx->scene->n_shadow_lights <= 32;
 }
 
 int fill_pipeline(ctgpu_ctx *ctx, uint64_t n_samples, PipelineParams &W);
@@ -710,7 +863,7 @@ int fill_pipeline(ctgpu_ctx *ctx, uint64_t n_samples, PipelineParams &W);
 int launch_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, FrameParams &P, hipStream_t stream) {
     const bool ss = (f->flags & CTGPU_F_SUPERSAMPLE) != 0;
     if (!pipeline_eligible(ctx, f)) {
-        launch_trace_tiles(P, tile_count(P), ss, ctx->has_reflection && f->max_depth > 0, false, stream);
+        launch_trace_tiles(P, tile_count(P), ss, ctx->scene->has_reflection && f->max_depth > 0, false, stream);
         HIP_TRY(hipGetLastError());
         return CTGPU_OK;
     }
@@ -742,13 +895,13 @@ int launch_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, FrameParams &P, hipS
 int fill_pipeline(ctgpu_ctx *ctx, uint64_t n_samples, PipelineParams &W) {
     std::memset(&W, 0, sizeof W);
     W.n_samples = n_samples;
-    W.n_shadow_lights = ctx->n_shadow_lights;
+    W.n_shadow_lights = ctx->scene->n_shadow_lights;
     W.keep_every_shadow_ray = ctx->keep_shadow_rays ? 1u : 0u;
-    W.lds_depth = std::min<uint32_t>((uint32_t)ctx->lds_depth, std::max<uint32_t>(ctx->tree_depth, 1));
-    W.spill_depth = std::max<uint32_t>(ctx->tree_depth, 1) - W.lds_depth;
+    W.lds_depth = std::min<uint32_t>((uint32_t)ctx->lds_depth, std::max<uint32_t>(ctx->scene->tree_depth, 1));
+    W.spill_depth = std::max<uint32_t>(ctx->scene->tree_depth, 1) - W.lds_depth;
     const size_t lds_bytes = (size_t)W.lds_depth * 64 * 12;
-    W.packet = (ctx->packet_walk && ctx->quad_pending <= 64u) ? 1u : 0u;           // stack levels are lanes of a register
-    W.packet_depth = ctx->quad_pending;
+    W.packet = (ctx->packet_walk && ctx->scene->quad_pending <= 64u) ? 1u : 0u;           // stack levels are lanes of a register
+    W.packet_depth = ctx->scene->quad_pending;
     W.packet_lds_levels = std::min<uint32_t>((uint32_t)ctx->packet_lds_levels, W.packet_depth);
     int per_cu = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu
                                         : (W.packet ? pipeline_packet_occupancy(W.packet_depth, W.packet_lds_levels)
@@ -767,7 +920,7 @@ int fill_pipeline(ctgpu_ctx *ctx, uint64_t n_samples, PipelineParams &W) {
     W.thresh_r = ctx->walk_thresh[0]; W.thresh_a = ctx->walk_thresh[1]; W.thresh_b = ctx->walk_thresh[2];
     if (W.n_samples >= 0xfffffff0ull) return ctgpu_fail(CTGPU_ERR_ARG, "frame too large: %llu samples", (unsigned long long)W.n_samples);
     HIP_TRY(ctx->spill.resize((size_t)W.walk_blocks * (size_t)std::max(W.lds_depth + W.spill_depth, W.packet_depth) * 64 * 12 / 8 + 64));
-    W.queue = ctx->queue.ptr; W.spill = ctx->spill.ptr; W.shadow_lights = ctx->shadow_lights.ptr;
+    W.queue = ctx->queue.ptr; W.spill = ctx->spill.ptr; W.shadow_lights = ctx->scene->shadow_lights.ptr;
     W.walk_work = ctx->walk_work.ptr;
     return CTGPU_OK;
 }
@@ -787,7 +940,7 @@ extern "C" int ctgpu_partition_pixels(const ctgpu_frame_desc *frame, const ctgpu
 extern "C" int ctgpu_render_partition(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, const ctgpu_partition *part,
                                       void *d_tiles, void *stream) {
     if (!ctx || !d_tiles) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_render_partition: null argument");
-    if (!ctx->has_scene) return ctgpu_fail(CTGPU_ERR_NO_SCENE, "no scene uploaded");
+    if (!ctx->scene) return ctgpu_fail(CTGPU_ERR_NO_SCENE, "no scene uploaded");
     int rc = check_frame(frame); if (rc) return rc;
     rc = check_partition(part); if (rc) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -846,7 +999,7 @@ extern "C" int ctgpu_read_counters(ctgpu_ctx *ctx, ctgpu_stats *stats) {
 namespace {
 int begin_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, uint32_t *host_fb, bool pin) {
     if (!ctx || !host_fb) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_render: null argument");
-    if (!ctx->has_scene) return ctgpu_fail(CTGPU_ERR_NO_SCENE, "no scene uploaded");
+    if (!ctx->scene) return ctgpu_fail(CTGPU_ERR_NO_SCENE, "no scene uploaded");
     if (ctx->pending.active) return ctgpu_fail(CTGPU_ERR_ARG, "a frame is already in flight on this context (ctgpu_render_poll)");
     int rc = check_frame(frame); if (rc) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -964,7 +1117,7 @@ extern "C" int ctgpu_render_multi(ctgpu_ctx *const *ctxs, int n_ctx, const ctgpu
     if (n_ctx == 1) return ctgpu_render(ctxs[0], frame, host_fb, stats);
     for (int i = 0; i < n_ctx; i++) {
         if (!ctxs[i]) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_render_multi: null context %d", i);
-        if (!ctxs[i]->has_scene) return ctgpu_fail(CTGPU_ERR_NO_SCENE, "context %d has no scene", i);
+        if (!ctxs[i]->scene) return ctgpu_fail(CTGPU_ERR_NO_SCENE, "context %d has no scene", i);
         if (ctxs[i]->pending.active) return ctgpu_fail(CTGPU_ERR_ARG, "context %d has a frame in flight (ctgpu_render_poll)", i);
     }
     int rc = check_frame(frame); if (rc) return rc;
@@ -1079,7 +1232,7 @@ extern "C" int ctgpu_render_multi(ctgpu_ctx *const *ctxs, int n_ctx, const ctgpu
 
 extern "C" int ctgpu_count_work(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, ctgpu_stats *stats) {
     if (!ctx || !stats) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_count_work: null argument");
-    if (!ctx->has_scene) return ctgpu_fail(CTGPU_ERR_NO_SCENE, "no scene uploaded");
+    if (!ctx->scene) return ctgpu_fail(CTGPU_ERR_NO_SCENE, "no scene uploaded");
     int rc = check_frame(frame); if (rc) return rc;
     HIP_TRY(hipSetDevice(ctx->device));
     const ctgpu_partition whole = {8, 0, 1};
@@ -1090,7 +1243,7 @@ extern "C" int ctgpu_count_work(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, c
     HIP_TRY(hipMemsetAsync(ctx->counters.ptr, 0, kCounterWords * sizeof(unsigned long long), ctx->stream));
     const bool ss = (frame->flags & CTGPU_F_SUPERSAMPLE) != 0;
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
-    launch_trace_tiles(P, tile_count(P), ss, ctx->has_reflection && frame->max_depth > 0, true, ctx->stream);
+    launch_trace_tiles(P, tile_count(P), ss, ctx->scene->has_reflection && frame->max_depth > 0, true, ctx->stream);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1106,7 +1259,7 @@ extern "C" int ctgpu_count_work(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, c
 // ------------------------------------------------------------------ test hook
 extern "C" int ctgpu_trace_rays(ctgpu_ctx *ctx, const ctgpu_ray *rays, uint64_t n, ctgpu_hit *hits) {
     if (!ctx || (n && (!rays || !hits))) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_trace_rays: null argument");
-    if (!ctx->has_scene) return ctgpu_fail(CTGPU_ERR_NO_SCENE, "no scene uploaded");
+    if (!ctx->scene) return ctgpu_fail(CTGPU_ERR_NO_SCENE, "no scene uploaded");
     if (n == 0) return CTGPU_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     ctgpu_frame_desc f;
@@ -1140,8 +1293,8 @@ extern "C" int ctgpu_trace_rays(ctgpu_ctx *ctx, const ctgpu_ray *rays, uint64_t 
 extern "C" int ctgpu_trace_rays_packet(ctgpu_ctx *ctx, const ctgpu_ray *rays, uint64_t n, uint32_t flags, ctgpu_hit *hits) {
     if (!ctx || (n && (!rays || !hits))) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_trace_rays_packet: null argument");
     if (flags & ~(uint32_t)CTGPU_TRACE_ANY_HIT) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_trace_rays_packet: unknown flags %u", flags);
-    if (!ctx->has_scene) return ctgpu_fail(CTGPU_ERR_NO_SCENE, "no scene uploaded");
-    if (ctx->quad_pending > 64u) return ctgpu_fail(CTGPU_ERR_STACK, "the packet walk does not serve this tree (%u entries pending)", ctx->quad_pending);
+    if (!ctx->scene) return ctgpu_fail(CTGPU_ERR_NO_SCENE, "no scene uploaded");
+    if (ctx->scene->quad_pending > 64u) return ctgpu_fail(CTGPU_ERR_STACK, "the packet walk does not serve this tree (%u entries pending)", ctx->scene->quad_pending);
     if (n == 0) return CTGPU_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     ctgpu_frame_desc f;

@@ -21,6 +21,27 @@ CTGPU_HIDDEN int ctgpu_shard_buffers(ctgpu_ctx *ctx, uint64_t n_tiles, uint64_t 
 // ctgpu_render_sharded's phase marks: which = 0 start, 1 traced, 2 gathered, 3 assembled (no-op unless timing is on)
 CTGPU_HIDDEN int ctgpu_phase_mark(ctgpu_ctx *ctx, int which, hipStream_t stream);
 
+// ---- scene on the device (ct_build.hip, ct_pack.hip)
+// BuildBVH on the device from vertices that are already there; the finished arrays STAY there: *d_nodes (n_nodes
+// records) and *d_indexes (n) are hipMalloc'ed blocks the caller owns.  depth = levels of the tree (root = 1).
+CTGPU_HIDDEN int ctgpu_build_bvh_resident(int device, const double *d_vertices, uint32_t n, ctgpu_node **d_nodes,
+                                          uint32_t **d_indexes, uint32_t *n_nodes, uint32_t *depth, double *device_ms);
+// what the walks read, produced on the device from the reference's arrays (all pointers: hipMalloc'ed, caller owns)
+struct ctgpu_packed_scene {
+    void *wide = nullptr;              // WideNode[n_wide]
+    void *quads = nullptr, *quads_flat = nullptr;          // QuadNode[n_quads], QuadNode[n_quads_flat]
+    double *quad_boxes = nullptr, *quad_boxes_flat = nullptr;   // [n][4][6]
+    void *tris = nullptr;              // TriRecord[n_triangles]
+    uint32_t n_wide = 0, n_quads = 0, n_quads_flat = 0;
+    uint32_t quad_root = 0, quad_root_flat = 0, quad_pending = 1;
+    uint32_t root_ref = 0, slot_of_triangle0 = 0;
+    float plane_bound[3] = {0, 0, 0};
+    double root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
+    double device_ms = 0.0;
+};
+CTGPU_HIDDEN int ctgpu_pack_on_device(int device, const ctgpu_node *d_nodes, uint32_t n_nodes, const uint32_t *d_indexes,
+                                      const double *d_vertices, uint32_t n_triangles, ctgpu_packed_scene *out);
+
 // one process, several devices (ctgpu_render_multi)
 CTGPU_HIDDEN int ctgpu_multi_comms(const int *devices, int n, std::vector<void *> &comms);
 CTGPU_HIDDEN void ctgpu_multi_comms_release(std::vector<void *> &comms);

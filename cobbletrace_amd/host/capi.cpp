@@ -26,7 +26,8 @@ Handle *H(void *p) { return static_cast<Handle *>(p); }
 void ensure_packed(Handle *h) {
     // the harness builds on the host unless told otherwise (CT_BVH_DEVICE=1: ctgpu_build_bvh on GPU 0)
     const char *where = std::getenv("CT_BVH_DEVICE");
-    if (!h->packed.built) h->packed.build_from(&h->scene, where && std::atoi(where) != 0, 0);
+    if (!h->packed.built)
+        h->packed.build_from(&h->scene, (where && std::atoi(where) != 0) ? ct::PackedScene::kDeviceTreeCopy : ct::PackedScene::kHostTree, 0);
 }
 
 }  // namespace

@@ -36,6 +36,7 @@ struct GpuApi {
     decltype(&ctgpu_create) create = nullptr;
     decltype(&ctgpu_destroy) destroy = nullptr;
     decltype(&ctgpu_upload_scene) upload_scene = nullptr;
+    decltype(&ctgpu_share_scene) share_scene = nullptr;
     decltype(&ctgpu_render) render = nullptr;
     decltype(&ctgpu_render_multi) render_multi = nullptr;
     decltype(&ctgpu_render_begin) render_begin = nullptr;
@@ -74,6 +75,7 @@ GpuApi &gpu() {
     RESOLVE(create, "ctgpu_create");
     RESOLVE(destroy, "ctgpu_destroy");
     RESOLVE(upload_scene, "ctgpu_upload_scene");
+    RESOLVE(share_scene, "ctgpu_share_scene");
     RESOLVE(render, "ctgpu_render");
     RESOLVE(render_multi, "ctgpu_render_multi");
     RESOLVE(render_begin, "ctgpu_render_begin");
@@ -183,25 +185,46 @@ bool RayThread(environment_t *env, scene_t *scene) {
 
     if (!b.initialised) {
         b.packed = new ct::PackedScene();
-        // the tree comes from the GPU that will walk it (ctgpu_build_bvh: the reference's arrays, a few milliseconds for
-        // the dragon instead of the host's 60-150); CT_BVH_DEVICE=0 keeps the host builder
+        // BuildBVH (raythread.cpp:647-652) runs on the GPU that will walk the tree and the tree stays there
+        // (ctgpu_upload_scene without nodes: vertices in, a few milliseconds for the dragon instead of the host's
+        // 60-150 and no half gigabyte of copies).  CT_BVH_DEVICE=0: the host builder; CT_BVH_DEVICE=copy: built on
+        // the device, arrays brought back and uploaded (round 2's path).
         const char *where = std::getenv("CT_BVH_DEVICE");
-        b.packed->build_from(scene, !(where && std::atoi(where) == 0), b.options.device);
+        ct::PackedScene::TreeSource tree = ct::PackedScene::kNoTree;
+        if (where && std::strcmp(where, "0") == 0) tree = ct::PackedScene::kHostTree;
+        else if (where && std::strcmp(where, "copy") == 0) tree = ct::PackedScene::kDeviceTreeCopy;
+        b.packed->build_from(scene, tree, b.options.device);
         // one context per GPU, the scene replicated on each (it is small against 288 GB): the GPUs
         // take the place of the reference's worker threads (raythread.cpp:596-618)
         int visible = 0;
         if (api.device_count(&visible) != CTGPU_OK || visible < 1) die("ctgpu_device_count", api.last_error());
         int wanted = b.options.n_devices > 1 ? b.options.n_devices : 1;
         if (const char *env = std::getenv("CT_RAYTHREAD_DEVICES")) wanted = std::max(1, std::atoi(env));
-        const ctgpu_scene_desc desc = b.packed->desc();
+        ctgpu_scene_desc desc = b.packed->desc();
+        std::vector<int> device_of;
         for (int i = 0; i < wanted; i++) {
             ctgpu_ctx *ctx = nullptr;
-            if (api.create((b.options.device + i) % visible, &ctx) != CTGPU_OK) die("ctgpu_create", api.last_error());
-            if (api.upload_scene(ctx, &desc) != CTGPU_OK) die("ctgpu_upload_scene", api.last_error());
+            const int device = (b.options.device + i) % visible;
+            if (api.create(device, &ctx) != CTGPU_OK) die("ctgpu_create", api.last_error());
+            // contexts that land on a device which already holds the scene take that copy
+            ctgpu_ctx *holder = nullptr;
+            for (size_t k = 0; k < b.ctxs.size(); k++)
+                if (device_of[k] == device) { holder = b.ctxs[k]; break; }
+            if (holder) {
+                if (api.share_scene(ctx, holder) != CTGPU_OK) die("ctgpu_share_scene", api.last_error());
+            } else if (api.upload_scene(ctx, &desc) != CTGPU_OK) {
+                if (desc.nodes) die("ctgpu_upload_scene", api.last_error());
+                // the device build refuses what it is not proven for (a NaN vertex): the host builder takes over
+                std::fprintf(stderr, "cobbletrace: %s -- building the tree on the host\n", api.last_error());
+                b.packed->build_tree_on_host();
+                desc = b.packed->desc();
+                if (api.upload_scene(ctx, &desc) != CTGPU_OK) die("ctgpu_upload_scene", api.last_error());
+            }
             // env->bitmap is the application's one framebuffer for its whole life (cobbletrace.cpp:60-75): its page-lock
             // stays between frames; RayThreadReset / ctgpu_destroy ends it
             if (b.options.async && api.keep_pinned(ctx, 1) != CTGPU_OK) die("ctgpu_keep_framebuffer_pinned", api.last_error());
             b.ctxs.push_back(ctx);
+            device_of.push_back(device);
         }
         b.initialised = true;
     }

@@ -44,7 +44,7 @@ static void build_sphere_tree(PackedScene &p) {
     BuildBVH(&p.sphere_bvh);
 }
 
-static void flatten(PackedScene &p, bool on_device = false, int device = 0) {
+static void flatten(PackedScene &p, PackedScene::TreeSource tree = PackedScene::kHostTree, int device = 0) {
     const size_t n = p.triangles.size();
     p.vertices.resize(n * 9);
     for (size_t i = 0; i < n; i++) {
@@ -54,8 +54,11 @@ static void flatten(PackedScene &p, bool on_device = false, int device = 0) {
     }
     std::free(p.bvh.bvhNodes);
     std::free(p.bvh.triangles.indexes);
+    p.bvh = bvh_state_t{};
+    p.built = false;
+    if (tree == PackedScene::kNoTree) return;          // (not even InitializeBVHState's 2N-node calloc)
     p.bvh = InitializeBVHState(p.triangles.data(), (int)n);
-    if (on_device && n > 0) {
+    if (tree == PackedScene::kDeviceTreeCopy && n > 0) {
         // (BuildBVH also leaves each triangle's centroid in the caller's array, bvh.cpp:110-112: nothing reads it afterwards)
         p.bvh.nodesUsed = build_bvh_on_device(device, p.vertices.data(), (uint32_t)n, p.bvh.bvhNodes, p.bvh.triangles.indexes);
     } else {
@@ -64,7 +67,14 @@ static void flatten(PackedScene &p, bool on_device = false, int device = 0) {
     p.built = true;
 }
 
-void PackedScene::build_from(const scene_t *scene, bool on_device, int device) {
+void PackedScene::build_tree_on_host() {
+    if (built) return;
+    bvh = InitializeBVHState(triangles.data(), (int)triangles.size());
+    BuildBVH(&bvh);
+    built = true;
+}
+
+void PackedScene::build_from(const scene_t *scene, TreeSource tree, int device) {
     triangles.clear();
     materials.clear();
     lights.clear();
@@ -94,7 +104,7 @@ void PackedScene::build_from(const scene_t *scene, bool on_device, int device) {
         lights.push_back(g);
     }
     build_sphere_tree(*this);
-    flatten(*this, on_device, device);
+    flatten(*this, tree, device);
 }
 
 void PackedScene::build_from_vertices(const double *verts, uint32_t n) {
@@ -116,12 +126,12 @@ ctgpu_scene_desc PackedScene::desc() const {
     ctgpu_scene_desc d;
     std::memset(&d, 0, sizeof d);
     d.n_triangles = (uint32_t)triangles.size();
-    d.n_nodes = bvh.nodesUsed;
+    d.n_nodes = built ? bvh.nodesUsed : 0u;            // no tree here: ctgpu_upload_scene builds it on the device
     d.n_lights = (uint32_t)lights.size();
     d.vertices = vertices.data();
     d.materials = materials.data();
-    d.nodes = reinterpret_cast<const ctgpu_node *>(bvh.bvhNodes);
-    d.indexes = bvh.triangles.indexes;
+    d.nodes = built ? reinterpret_cast<const ctgpu_node *>(bvh.bvhNodes) : nullptr;
+    d.indexes = built ? bvh.triangles.indexes : nullptr;
     d.lights = lights.data();
     if (!spheres.empty()) {
         d.n_spheres = (uint32_t)spheres.size();

@@ -29,9 +29,14 @@ struct PackedScene {
     PackedScene(const PackedScene &) = delete;
     PackedScene &operator=(const PackedScene &) = delete;
 
-    // Gathers the OT_TRIANGLE objects in stack order, builds the BVH, fills the arrays.  on_device: BuildBVH runs
-    // on that GPU (ctgpu_build_bvh, the same arrays) instead of on the host.
-    void build_from(const scene_t *scene, bool on_device = false, int device = 0);
+    // Gathers the OT_TRIANGLE objects in stack order, builds the BVH, fills the arrays.  Where the tree comes from:
+    //   kHostTree        BuildBVH on the host (bvh_build.cpp)
+    //   kDeviceTreeCopy  BuildBVH on that GPU, arrays copied back (ctgpu_build_bvh)
+    //   kNoTree          none here: desc() carries vertices / materials / lights only and ctgpu_upload_scene builds the
+    //                    tree in HBM, where it stays (nothing of it is ever in host memory)
+    enum TreeSource { kHostTree, kDeviceTreeCopy, kNoTree };
+    void build_from(const scene_t *scene, TreeSource tree = kHostTree, int device = 0);
+    void build_tree_on_host();         // after kNoTree: the host tree after all (the device refused the mesh)
     // Same from bare vertices (n x 9 doubles), default material; used by the BvhTest KAT.
     void build_from_vertices(const double *verts, uint32_t n);
     ctgpu_scene_desc desc() const;

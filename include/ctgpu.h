@@ -184,11 +184,37 @@ int  ctgpu_device_count(int *count);
  *   CTGPU_RCCL_LIBRARY   path of the librccl to bind (default: one the process already holds, else ROCm's)
  *   CTGPU_PACKET         0: per-lane walk over the binary tree instead of the shared (packet) walk
  *   CTGPU_PACKET_LDS_LEVELS, CTGPU_LDS_DEPTH   stack levels kept in LDS (deeper ones go to HBM)
- *   CTGPU_FORCE_MEGAKERNEL   1: the general path (one kernel, reflection capable) for every frame */
+ *   CTGPU_FORCE_MEGAKERNEL   1: the general path (one kernel, reflection capable) for every frame
+ *   CTGPU_PACK           host: re-lay-out an uploaded tree on the host (default: on the device) */
 int  ctgpu_create(int device, ctgpu_ctx **out);
 void ctgpu_destroy(ctgpu_ctx *ctx);
 
+/* Scene -> HBM (raythread.cpp:641-654: GetSceneTriangles + InitializeBVHState + BuildBVH at RayThread's first call).
+ *   scene->nodes / indexes given: the reference's arrays from any builder (this repository's host builder, the
+ *     reference's own BuildBVH).  Validated on the host, copied as they are, re-laid-out for the walks by kernels
+ *     (ct_pack.hip; CTGPU_PACK=host does that packing on the host instead -- the restatement the kernels are tested
+ *     against, two orders of magnitude slower).
+ *   scene->nodes == indexes == NULL, n_nodes == 0: BuildBVH runs on the device too (ct_build.hip, bvh.cpp:16-121: the
+ *     same arrays byte for byte) and the tree never leaves it -- vertices in, frames out.  ctgpu_download_tree hands
+ *     bvhNodes[] / indexes[] back to a host that wants them (nodes_out: room for 2N-1, indexes_out: N; either may
+ *     be NULL).
+ * ctgpu_share_scene: a second context of the SAME device takes the owner's scene (one copy in HBM for all frames
+ * in flight; it lives as long as any context holds it).  ctgpu_scene_info: sizes, device time of build and packing. */
 int  ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *scene);
+int  ctgpu_share_scene(ctgpu_ctx *ctx, ctgpu_ctx *owner);
+int  ctgpu_download_tree(ctgpu_ctx *ctx, ctgpu_node *nodes_out, uint32_t *indexes_out, uint32_t *n_nodes);
+typedef struct ctgpu_scene_info_t {
+    uint32_t n_triangles, n_nodes, tree_depth, n_wide, n_quads, n_quads_flat;
+    uint32_t quad_root, quad_root_flat, quad_pending, root_ref, slot_of_triangle0, shared_by;
+    float    plane_bound[3];
+    uint32_t pad_;
+    double   build_ms, pack_ms;      /* device time of BuildBVH (0 when the caller brought the tree) and of the packing */
+    uint64_t hbm_bytes;              /* what the scene occupies */
+} ctgpu_scene_info_t;
+int  ctgpu_scene_info(ctgpu_ctx *ctx, ctgpu_scene_info_t *out);
+/* test hook: one packed array as bytes (0 WideNodes, 1 QuadNodes, 2 their boxes, 3 unfolded QuadNodes, 4 their
+ * boxes, 5 TriRecords); *needed = its size, copied when `bytes` is enough */
+int  ctgpu_debug_scene_array(ctgpu_ctx *ctx, int which, void *out, uint64_t bytes, uint64_t *needed);
 
 /* One whole frame on this context's GPU into a caller-owned host framebuffer
  * (width*height uint32).  Synchronous.  stats may be NULL. */
