@@ -73,7 +73,8 @@ class Stats(C.Structure):
 
 class WalkWork(C.Structure):
     _fields_ = [("packets", C.c_uint64 * 2), ("quad_nodes", C.c_uint64 * 2), ("triangle_records", C.c_uint64 * 2),
-                ("shadow_rays_blocked", C.c_uint64), ("shadow_packets_all_blocked", C.c_uint64)]
+                ("shadow_rays_blocked", C.c_uint64), ("shadow_packets_all_blocked", C.c_uint64),
+                ("rays_handed_over", C.c_uint64 * 2)]
 
 
 class KernelTimes(C.Structure):
@@ -148,6 +149,7 @@ _GPU_SYMBOLS = {
     "ctgpu_trace_rays_packet": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]),
     "ctgpu_build_bvh": (C.c_int, [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]),
     "ctgpu_read_walk_work": (C.c_int, [C.c_void_p, C.POINTER(WalkWork)]),
+    "ctgpu_walk_choice": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ctgpu_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "ctgpu_read_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(KernelTimes)]),
     "ctgpu_read_phase_times": (C.c_int, [C.c_void_p, C.POINTER(PhaseTimes)]),
@@ -438,6 +440,12 @@ class GpuContext:
         t = KernelTimes()
         self._check(self.lib.ctgpu_read_kernel_times(self.handle, C.byref(t)))
         return t
+
+    def walk_choice(self, supersampled):
+        """(per-lane walk chosen?, last kernel ms on the shared walk, on the per-lane walk) for a frame kind."""
+        lane, a, b = C.c_int(0), C.c_double(0), C.c_double(0)
+        self._check(self.lib.ctgpu_walk_choice(self.handle, 1 if supersampled else 0, C.byref(lane), C.byref(a), C.byref(b)))
+        return bool(lane.value), a.value, b.value
 
     def read_phase_times(self):
         t = PhaseTimes()

@@ -11,8 +11,13 @@
 namespace ctd {
 
 // words of FrameParams::counters: 0 primary rays, 1 shadow rays, 2 reflected rays, 3 node visits, 4 triangle
-// tests, 5..14 diagnostic builds, 15 rays the packet walk walked again unfolded, 16 shadow rays not needed
+// tests, 5..14 diagnostic builds, 15 rays the packet walk walked again unfolded, 16 shadow rays not needed,
+// 17 / 18 primary / shadow rays the packet walk handed over to the per-lane walk
 constexpr int kCounterWords = 24;
+// ray-queue head words: walk 0 primary rays, walks 1..32 the shadow rays of up to 32 lights, walks 33 / 34 the
+// handed-over primary / shadow rays; 8 shards each, one 128-byte line per head word
+constexpr int kQueueWalks = 35;
+constexpr int kQueueWords = kQueueWalks * 8 * 16;
 constexpr int kCounterElided = 16;
 
 struct FrameParams {
@@ -74,12 +79,13 @@ struct PipelineParams {
     float2   *coords;            // [n_samples] jittered canvas position (supersampled frames)
     uint2    *hits;              // [n_samples] {ray.t bits, closest TriRecord slot | kNoNode | invalid}
     uint8_t  *shadow;            // [n_shadow_lights][n_samples] 1 = that light is blocked
-    unsigned long long *queue;   // [1 + 32 walks][8 shards][16] head words (128-byte stride) of the ray queues
+    unsigned long long *queue;   // [kQueueWalks][8 shards][16] head words (128-byte stride) of the ray queues
     void     *spill;             // [walk_blocks][spill_depth][64] stack entries beyond the LDS part
     const uint32_t *shadow_lights;   // [n_shadow_lights] index into lights[]
     uint64_t n_samples;
     uint32_t n_shadow_lights;
     uint32_t lds_depth, spill_depth, walk_blocks;
+    uint32_t listed_blocks;      // grid of the per-lane launches that trace the handed-over rays
     uint32_t chunk;              // ray ids a wave reserves per queue atomic (multiple of 64)
     uint32_t chunk_shadow;       // the same for the shadow walk (its candidates are only partly rays)
     uint32_t packet;             // 1: supersampled frames use ct_walk_packet (shared walk per wave)
@@ -90,6 +96,13 @@ struct PipelineParams {
     unsigned long long *walk_work;    // [64 slots][8]: {packets, QuadNodes fetched, triangle records fetched} of the primary
                                       // walk in words 0..2, of the shadow walk in words 3..5 (packet walk only); word 6: shadow
                                       // rays that found a blocker, word 7: shadow packets whose every ray did
+    // Hand-over of incoherent packets (ct_walk_packet -> ct_walk): a packet that has made `packet_budget` visits with
+    // fewer than `packet_lanes` rays per visit on average is not sharing its walk any more -- it stops, its rays go on
+    // the list, and the per-lane kernel traces them from the start after the packet launch.  0 = never hand over.
+    uint32_t packet_budget, packet_lanes;
+    unsigned long long *handed;  // [0] primary, [16] shadow: number of listed ray ids (128-byte apart); never reset in a launch
+    unsigned long long *handed_ids[2];   // the ids: primary ray = sample id; shadow ray = light * n_samples + sample
+    uint64_t handed_room;        // ids each list can hold (a full list: the packet simply walks on)
     const ctgpu_ray *ray_list;   // ctgpu_trace_rays_packet: the caller's rays (n_samples of them) ...
     ctgpu_hit *ray_hits;         // ... and where their results go
 };

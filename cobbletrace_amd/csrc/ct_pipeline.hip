@@ -407,9 +407,11 @@ __device__ __forceinline__ void step_leaf(Walker &w, const TriRecord *__restrict
 // the chunk with ballots only.
 // ------------------------------------------------------------------------------------
 
-template <int KIND, bool SS>
+// LISTED: the rays are the ones ct_walk_packet handed over (W.handed_ids[KIND], ids as above in any order): the
+// queue then runs over list positions, and a shadow ray's light comes from its id.
+template <int KIND, bool SS, bool LISTED = false>
 __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk(const FrameParams P, const PipelineParams W) {
-    const uint32_t q_chunk = (KIND == 1) ? W.chunk_shadow : W.chunk;      // ray ids per queue atomic
+    const uint32_t q_chunk = LISTED ? 64u : ((KIND == 1) ? W.chunk_shadow : W.chunk);      // ray ids per queue atomic
     extern __shared__ __align__(16) unsigned char lds_raw[];
     WalkStack st;
     st.lds = (LdsEntry *)lds_raw;
@@ -429,9 +431,17 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk(const FrameParam
     // per light -- each with its own head word on its own 128-byte line (one head saturates near 90
     // dequeues/us chip-wide); a wave starts on the shard of its workgroup id (workgroups b and b+8
     // share an XCD under round-robin placement: speed only) and moves to the next when one runs dry.
-    const uint64_t n_samples = W.n_samples;
-    const uint32_t n_shards = (KIND == 0) ? kShards : kShards * W.n_shadow_lights;
-    unsigned long long *heads = W.queue + (size_t)(KIND == 0 ? 0u : kShards) * 16u;
+    // (LISTED: "samples" below are list positions, one run of kShards shards; the queue's head words are walk 33 / 34's, ct_params.h)
+    uint64_t listed = 0;
+    if (LISTED) {
+        listed = W.handed[KIND == 0 ? 0 : 16];
+        if (listed > W.handed_room) listed = W.handed_room;
+        if (listed == 0) return;
+    }
+    const unsigned long long *listed_ids = W.handed_ids[KIND == 0 ? 0 : 1];
+    const uint64_t n_samples = LISTED ? listed : W.n_samples;
+    const uint32_t n_shards = (KIND == 0 || LISTED) ? kShards : kShards * W.n_shadow_lights;
+    unsigned long long *heads = W.queue + (size_t)(LISTED ? (KIND == 0 ? 33u : 34u) * kShards : (KIND == 0 ? 0u : kShards)) * 16u;
     const uint64_t shard_span = ((n_samples + kShards - 1) / kShards + q_chunk - 1) / q_chunk * q_chunk;
     uint32_t shard = blockIdx.x % n_shards, shards_done = 0;
     uint64_t light_base = 0;                 // first ray id of the light the current chunk belongs to
@@ -509,26 +519,36 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk(const FrameParam
                     uint64_t hi = lo + q_chunk;
                     if (hi > ((uint64_t)part + 1u) * shard_span) hi = ((uint64_t)part + 1u) * shard_span;
                     if (hi > n_samples) hi = n_samples;
-                    light_base = (uint64_t)light * n_samples;
+                    light_base = LISTED ? 0u : (uint64_t)light * n_samples;
                     chunk_next = light_base + lo;
                     chunk_end = light_base + hi;
-                    if (KIND == 1) shadow_light = P.lights[W.shadow_lights[light]];
+                    if (KIND == 1 && !LISTED) shadow_light = P.lights[W.shadow_lights[light]];
                 }
                 const uint64_t avail = chunk_end - chunk_next;
                 const uint32_t rank = (uint32_t)__popcll(m_i & lanes_below);
                 const bool take = !has_ray && rank < avail;
-                const uint64_t id = chunk_next + rank;
+                uint64_t id = chunk_next + rank;
                 const uint64_t wanted = (uint64_t)__popcll(m_i);
                 chunk_next += (wanted < avail) ? wanted : avail;
                 if (take) {
+                    bool listed_ok = true;
+                    if (LISTED) {
+                        id = listed_ids[id];
+                        // (a slot some packet reserved but could not use carries ~0; anything else out of range cannot
+                        //  be there, and is not followed if it is)
+                        listed_ok = id < W.n_samples * (KIND == 1 ? (uint64_t)W.n_shadow_lights : 1u);
+                        if (!listed_ok) id = 0;
+                        light_base = (KIND == 1) ? (id / W.n_samples) * W.n_samples : 0u;
+                        if (KIND == 1) shadow_light = P.lights[W.shadow_lights[id / W.n_samples]];
+                    }
                     const uint64_t sample = id - light_base;
                     float px, py;
-                    bool live = sample_position<SS>(P, W, sample, px, py);
+                    bool live = sample_position<SS>(P, W, sample, px, py) && listed_ok;
                     if (KIND == 0) {
                         if (live) {
                             w.o = eye;
                             w.d = primary_direction(P, px, py);
-                        } else {
+                        } else if (!LISTED) {                             // (a listed ray's slot was marked when its packet was formed)
                             W.hits[id] = make_uint2(__float_as_uint(kNoHit), kInvalidSample);
                         }
                     } else if (live) {
@@ -711,7 +731,10 @@ extern "C" __attribute__((visibility("default"))) int ctgpu_debug_packet_trace(u
 // KIND 1  shadow rays of the frame             (any hit     -> shadow bytes)
 // KIND 2  caller's ray list, closest hit       (-> ctgpu_hit; the per-ray test hook ctgpu_trace_rays_packet:
 // KIND 3  caller's ray list, any hit               64 consecutive list entries are one packet, same walk code)
-template <int KIND, bool SS>
+// HANDOVER: the instantiation that may give a packet's rays up to the per-lane kernel (W.packet_budget; an experiment
+// that is off by default -- it is a template parameter because the bookkeeping alone, compiled in but switched off,
+// cost the primary walk 12 % through register pressure: profiles/r03_handover_sweep.log).
+template <int KIND, bool SS, bool HANDOVER = false>
 __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const FrameParams P, const PipelineParams W) {
     const uint32_t q_chunk = (KIND == 1) ? W.chunk_shadow : W.chunk;      // ray ids per queue atomic
     constexpr bool LIST = KIND >= 2;                 // rays come from W.ray_list instead of the frame's samples
@@ -753,6 +776,9 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
     // records (80 B each) fetched -- the kernel's own bytes of the roofline (ctgpu_read_walk_work)
     uint32_t n_packets = 0, n_quads = 0, n_records = 0;
     uint32_t n_blocked = 0, n_all_blocked = 0;     // shadow walk: rays that found a blocker, packets whose every ray did
+    uint32_t n_handed = 0;                         // rays given to the per-lane walk (their packets had stopped sharing)
+    bool list_full = false;
+    const uint32_t budget = (HANDOVER && !LIST) ? W.packet_budget : 0u;
 #ifdef CT_WALK_STATS
     unsigned long long pk_n[6] = {0, 0, 0, 0, 0, 0}, pk_cyc[3] = {0, 0, 0};
     const unsigned long long pk_begin = __builtin_amdgcn_s_memtime();
@@ -882,6 +908,8 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
         // direction component and the origin exactly on a box plane -- the one case folding is not
         // proven for, DESIGN B2) leaves the packet, and pass 1 walks those rays again from the root
         // over the same tree UNFOLDED (two entries per node, the reference's own structure).
+        uint32_t visits = 0, lane_visits = 0;         // of this packet: nodes visited, rays that took part in them
+        bool hand_over = false;
         for (int walk_pass = 0; walk_pass < 2; walk_pass++) {
         const QuadNode *quads = walk_pass == 0 ? P.quads : P.quads_flat;
         const double *quad_boxes = walk_pass == 0 ? P.quad_boxes : P.quad_boxes_flat;
@@ -905,6 +933,45 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
 
         // ---------------- the shared walk
         while (mask != 0ull) {
+            // A packet whose rays have gone separate ways walks the union of 64 different paths one node at a time:
+            // after `budget` visits with fewer than packet_lanes rays per visit it stops here and its rays are traced
+            // again, each on its own, by the per-lane kernel (a ray's result does not depend on who walks it).
+            if (HANDOVER && budget != 0u && !list_full) {
+                visits += 1u;
+                lane_visits += (uint32_t)__popcll(mask);
+                if (visits >= budget && walk_pass == 0) {
+                    if (lane_visits < visits * W.packet_lanes) {
+                        // a shadow ray that has met its blocker is done; every other ray of the packet goes on the list
+                        const bool listed = has_ray && (!ANY_HIT || t == kNoHit);
+                        const unsigned long long m_l = __ballot(listed);
+                        const uint32_t n_l = (uint32_t)__popcll(m_l);
+                        unsigned long long at = 0;
+                        if (lane == 0) at = atomicAdd(W.handed + (KIND == 0 ? 0 : 16), (unsigned long long)n_l);
+                        at = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)at) |
+                             ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(at >> 32)) << 32);
+                        if (at + n_l <= W.handed_room) {
+                            if (listed) {
+                                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_l >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_l, 0u));
+                                W.handed_ids[KIND == 0 ? 0 : 1][at + rank] = (KIND == 0) ? packet_base + lane : ray_id;
+                                has_ray = false;               // (the retirement below writes nothing for it)
+                            }
+                            n_traced -= n_l;                   // the per-lane kernel counts them
+                            n_handed += n_l;
+                            hand_over = true;
+                            break;
+                        }
+                        // no room (the list is sized for a part of the frame's rays): this wave walks its packets out from
+                        // now on.  A reservation that straddles the end must not leave unwritten slots behind: the
+                        // per-lane kernel reads every slot below the end, so they get a mark it skips.
+                        if (at < W.handed_room) {
+                            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_l >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_l, 0u));
+                            if (listed && at + rank < W.handed_room) W.handed_ids[KIND == 0 ? 0 : 1][at + rank] = ~0ull;
+                        }
+                        list_full = true;
+                    }
+                    visits = 0u; lane_visits = 0u;             // still sharing well: look again after another `budget`
+                }
+            }
             if (cur & kLeafBit) {
                 // leaf: every triangle in index order, each lane keeps its own closest hit
                 const uint32_t first = cur & ~kLeafBit;
@@ -1090,6 +1157,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
             }
         }
 
+        if (hand_over) break;
         }   // passes
 
         // ---------------- retire the packet
@@ -1139,6 +1207,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
         atomicAdd(work + 0, (unsigned long long)n_packets);
         atomicAdd(work + 1, (unsigned long long)n_quads);
         atomicAdd(work + 2, (unsigned long long)n_records);
+        if (n_handed) atomicAdd(&P.counters[KIND == 0 ? 17 : 18], (unsigned long long)n_handed);
         if (KIND == 1) {
             atomicAdd(W.walk_work + (size_t)(blockIdx.x & 63u) * 8u + 6u, (unsigned long long)n_blocked);
             atomicAdd(W.walk_work + (size_t)(blockIdx.x & 63u) * 8u + 7u, (unsigned long long)n_all_blocked);
@@ -1355,14 +1424,27 @@ void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hip
         // shared walk: a wave holds 2x2 pixels x 16 samples (supersampled) or an 8x8 pixel tile
         const uint32_t depth_p = W.packet_depth;
         const size_t lds_p = PacketStack::bytes(depth_p, W.packet_lds_levels < depth_p ? W.packet_lds_levels : depth_p);
-        if (ss) hipLaunchKernelGGL((ct_walk_packet<0, true>), grid, wave, lds_p, stream, P, W);
-        else hipLaunchKernelGGL((ct_walk_packet<0, false>), grid, wave, lds_p, stream, P, W);
+        // (the per-lane kernel behind each packet launch traces the rays of packets that had stopped sharing their
+        //  walk: a short list, usually empty for supersampled frames -- its waves then leave at once)
+        const size_t lds_l = (size_t)W.lds_depth * kWave * 12u;
+        const dim3 grid_l(W.listed_blocks);
+        const bool handover = W.packet_budget != 0u;
+        if (ss && !handover) hipLaunchKernelGGL((ct_walk_packet<0, true>), grid, wave, lds_p, stream, P, W);
+        if (!ss && !handover) hipLaunchKernelGGL((ct_walk_packet<0, false>), grid, wave, lds_p, stream, P, W);
+        if (ss && handover) hipLaunchKernelGGL((ct_walk_packet<0, true, true>), grid, wave, lds_p, stream, P, W);
+        if (!ss && handover) hipLaunchKernelGGL((ct_walk_packet<0, false, true>), grid, wave, lds_p, stream, P, W);
+        if (handover && ss) hipLaunchKernelGGL((ct_walk<0, true, true>), grid_l, wave, lds_l, stream, P, W);
+        if (handover && !ss) hipLaunchKernelGGL((ct_walk<0, false, true>), grid_l, wave, lds_l, stream, P, W);
         mark(2);
         if (shadows && ss) hipLaunchKernelGGL((ct_light_gate<true>), dim3(sample_blocks), dim3(256), 0, stream, P, W);
         if (shadows && !ss) hipLaunchKernelGGL((ct_light_gate<false>), dim3(sample_blocks), dim3(256), 0, stream, P, W);
         mark(3);
-        if (shadows && ss) hipLaunchKernelGGL((ct_walk_packet<1, true>), grid, wave, lds_p, stream, P, W);
-        if (shadows && !ss) hipLaunchKernelGGL((ct_walk_packet<1, false>), grid, wave, lds_p, stream, P, W);
+        if (shadows && ss && !handover) hipLaunchKernelGGL((ct_walk_packet<1, true>), grid, wave, lds_p, stream, P, W);
+        if (shadows && !ss && !handover) hipLaunchKernelGGL((ct_walk_packet<1, false>), grid, wave, lds_p, stream, P, W);
+        if (shadows && ss && handover) hipLaunchKernelGGL((ct_walk_packet<1, true, true>), grid, wave, lds_p, stream, P, W);
+        if (shadows && !ss && handover) hipLaunchKernelGGL((ct_walk_packet<1, false, true>), grid, wave, lds_p, stream, P, W);
+        if (shadows && handover && ss) hipLaunchKernelGGL((ct_walk<1, true, true>), grid_l, wave, lds_l, stream, P, W);
+        if (shadows && handover && !ss) hipLaunchKernelGGL((ct_walk<1, false, true>), grid_l, wave, lds_l, stream, P, W);
     } else {
         const size_t lds = (size_t)W.lds_depth * kWave * 12u;      // entries + parent words
         if (ss) hipLaunchKernelGGL((ct_walk<0, true>), grid, wave, lds, stream, P, W);

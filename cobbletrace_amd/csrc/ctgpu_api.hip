@@ -131,8 +131,23 @@ struct ctgpu_ctx {
     int chunk = 0;                              // 0 = sized from the frame
     int chunk_shadow = 0;                       // 0 = same as chunk
     int packet_lds_levels = 14;                 // per-lane tmin levels kept in LDS by the packet walk
+    int packet_budget = 0, packet_lanes = 12;   // CTGPU_PACKET_BUDGET: hand-over of incoherent packets to the per-lane walk (PipelineParams); 0 = off, the default
+    DeviceArray<unsigned long long> handed_ids[2];
+    unsigned long long handed_over[2] = {0, 0}; // rays handed over since the last ctgpu_read_walk_work
     bool keep_shadow_rays = false;              // CTGPU_KEEP_SHADOW_RAYS=1: trace the shadow rays whose answer cannot matter, too
-    bool packet_walk = true;                    // ct_walk_packet for supersampled frames (CTGPU_PACKET=0: per-lane walk)
+    bool packet_walk = true;                    // ct_walk_packet (CTGPU_PACKET=0: per-lane walk)
+    // Which walk traces a frame kind ([0] single sample, [1] supersampled) when CTGPU_PACKET does not say: the shared
+    // walk, unless this scene's packets turn out to share little (many fetches per packet) AND a frame traced per lane
+    // was measured faster.  Both walks give the same pixels, so the choice is invisible; it is re-examined every 256
+    // frames with one frame on the other walk.  Only frames that report their time (ctgpu_render, _begin / _poll) feed it.
+    bool walk_auto = true;
+    struct WalkChoice {
+        uint32_t frames = 0;                    // frames of this kind finished
+        bool use_lane = false, probe = false;   // the settled choice; the NEXT frame runs on the other walk, as a probe
+        bool ran_lane = false, ran_probe = false;   // what the frame in flight runs on
+        double packet_ms = 0.0, lane_ms = 0.0;  // last measured kernel time on either walk
+        unsigned long long packets = 0, fetches = 0;        // walk_work totals at the last look (they only grow between reads)
+    } choice[2];
     bool force_megakernel = false;
 
     ctgpu_comm_state *comm = nullptr;           // ctgpu_comm_init: this rank's RCCL communicator
@@ -144,7 +159,9 @@ struct ctgpu_ctx {
         bool active = false;
         std::chrono::steady_clock::time_point t0;
         uint64_t pixels = 0;
+        int kind = -1;                          // 0 / 1: a single-sample / supersampled frame on the fast path (walk choice)
     } pending;
+    int probe_above = 100;                      // CTGPU_PROBE_ABOVE: fetches per packet beyond which the per-lane walk gets a trial frame
     uint32_t *pinned_fb = nullptr;              // the caller's framebuffer, page-locked by begin_frame for the asynchronous copy
     size_t pinned_bytes = 0;
     bool keep_pin = false;                      // ctgpu_keep_framebuffer_pinned: the caller promises one long-lived framebuffer
@@ -241,13 +258,16 @@ static int create_resources(ctgpu_ctx *ctx) {
     if (const char *t = std::getenv("CTGPU_BLOCKS_PER_CU")) ctx->blocks_per_cu = std::max(0, std::atoi(t));
     if (const char *t = std::getenv("CTGPU_CHUNK")) ctx->chunk = std::max(0, std::atoi(t));
     if (const char *t = std::getenv("CTGPU_CHUNK_SHADOW")) ctx->chunk_shadow = std::max(0, std::atoi(t));
-    if (const char *t = std::getenv("CTGPU_PACKET")) ctx->packet_walk = std::atoi(t) != 0;
+    if (const char *t = std::getenv("CTGPU_PACKET")) { ctx->packet_walk = std::atoi(t) != 0; ctx->walk_auto = false; }
     if (const char *t = std::getenv("CTGPU_KEEP_SHADOW_RAYS")) ctx->keep_shadow_rays = std::atoi(t) != 0;
+    if (const char *t = std::getenv("CTGPU_PROBE_ABOVE")) ctx->probe_above = std::max(0, std::atoi(t));
+    if (const char *t = std::getenv("CTGPU_PACKET_BUDGET")) ctx->packet_budget = std::max(0, std::atoi(t));
+    if (const char *t = std::getenv("CTGPU_PACKET_LANES")) ctx->packet_lanes = std::min(64, std::max(1, std::atoi(t)));
     if (const char *t = std::getenv("CTGPU_PACKET_LDS_LEVELS")) ctx->packet_lds_levels = std::max(1, std::atoi(t));
     if (const char *t = std::getenv("CTGPU_FORCE_MEGAKERNEL")) ctx->force_megakernel = std::atoi(t) != 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->cu_count = prop.multiProcessorCount;
-    HIP_TRY(ctx->queue.resize(33 * 8 * 16));
+    HIP_TRY(ctx->queue.resize(kQueueWords + 32));           // + the two hand-over counters (cleared with the queue, per frame)
     HIP_TRY(ctx->walk_work.resize(64 * 8));
     HIP_TRY(hipMemset(ctx->walk_work.ptr, 0, 64 * 8 * sizeof(unsigned long long)));
     return CTGPU_OK;
@@ -290,7 +310,7 @@ extern "C" void ctgpu_destroy(ctgpu_ctx *ctx) {
     ctx->tiles.release(); ctx->fb.release(); ctx->gathered.release(); ctx->counters.release(); ctx->overflow.release();
     ctx->rand_table.release(); ctx->row_ordinal.release();
     ctx->coords.release(); ctx->hits.release(); ctx->shadow.release(); ctx->queue.release(); ctx->spill.release();
-    ctx->walk_work.release();
+    ctx->walk_work.release(); ctx->handed_ids[0].release(); ctx->handed_ids[1].release();
     for (hipEvent_t e : ctx->marks) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->phase_marks) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -616,6 +636,7 @@ extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
     S.tree_depth = depth;
     S.has_reflection = reflective;
     ctx->scene = store;
+    ctx->choice[0] = ctx->choice[1] = ctgpu_ctx::WalkChoice();       // another scene: the walk choice starts over
     return CTGPU_OK;
 }
 
@@ -629,6 +650,7 @@ extern "C" int ctgpu_share_scene(ctgpu_ctx *ctx, ctgpu_ctx *owner) {
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->scene = owner->scene;
+    ctx->choice[0] = ctx->choice[1] = ctgpu_ctx::WalkChoice();
     return CTGPU_OK;
 }
 
@@ -836,6 +858,8 @@ int read_counters(ctgpu_ctx *ctx, ctgpu_stats *st) {
                      100.0 * c[11] / c[14], 100.0 * c[12] / c[14], 100.0 * c[13] / c[14],
                      100.0 * (c[14] - c[11] - c[12] - c[13]) / c[14]);
     HIP_TRY(hipMemset(ctx->counters.ptr, 0, sizeof c));
+    ctx->handed_over[0] += c[17];                 // reported by ctgpu_read_walk_work
+    ctx->handed_over[1] += c[18];
     if (st) {
         st->rays_primary = c[0]; st->rays_shadow = c[1]; st->rays_reflect = c[2];
         st->node_visits = c[3]; st->triangle_tests = c[4];
@@ -858,7 +882,7 @@ bool pipeline_eligible(const ctgpu_ctx *ctx, const ctgpu_frame_desc *f) {
     return ctx->scene->n_shadow_lights <= 32;
 }
 
-int fill_pipeline(ctgpu_ctx *ctx, uint64_t n_samples, PipelineParams &W);
+int fill_pipeline(ctgpu_ctx *ctx, uint64_t n_samples, PipelineParams &W, int kind = -1);
 
 int launch_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, FrameParams &P, hipStream_t stream) {
     const bool ss = (f->flags & CTGPU_F_SUPERSAMPLE) != 0;
@@ -868,13 +892,13 @@ int launch_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, FrameParams &P, hipS
         return CTGPU_OK;
     }
     PipelineParams W;
-    int rc = fill_pipeline(ctx, pipeline_sample_count(P, ss), W); if (rc) return rc;
+    int rc = fill_pipeline(ctx, pipeline_sample_count(P, ss), W, ss ? 1 : 0); if (rc) return rc;
 
     if (ss) HIP_TRY(ctx->coords.resize(W.n_samples));
     HIP_TRY(ctx->hits.resize(W.n_samples));
     HIP_TRY(ctx->shadow.resize(W.n_samples * std::max<uint32_t>(W.n_shadow_lights, 1)));
     W.coords = ctx->coords.ptr; W.hits = ctx->hits.ptr; W.shadow = ctx->shadow.ptr;
-    HIP_TRY(hipMemsetAsync(ctx->queue.ptr, 0, 33 * 8 * 16 * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(ctx->queue.ptr, 0, (kQueueWords + 32) * sizeof(unsigned long long), stream));
     hipEvent_t *marks = nullptr;
     if (ctx->kernel_timing) {
         const size_t need = ctx->marks_used + kPipelineKernels + 1;
@@ -892,7 +916,8 @@ int launch_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, FrameParams &P, hipS
 }
 
 // grid, queue chunk and stack buffers of the walk kernels for n_samples ray ids
-int fill_pipeline(ctgpu_ctx *ctx, uint64_t n_samples, PipelineParams &W) {
+// kind: 0 single-sample frame, 1 supersampled frame, -1 not a frame (caller's ray list)
+int fill_pipeline(ctgpu_ctx *ctx, uint64_t n_samples, PipelineParams &W, int kind) {
     std::memset(&W, 0, sizeof W);
     W.n_samples = n_samples;
     W.n_shadow_lights = ctx->scene->n_shadow_lights;
@@ -901,6 +926,13 @@ int fill_pipeline(ctgpu_ctx *ctx, uint64_t n_samples, PipelineParams &W) {
     W.spill_depth = std::max<uint32_t>(ctx->scene->tree_depth, 1) - W.lds_depth;
     const size_t lds_bytes = (size_t)W.lds_depth * 64 * 12;
     W.packet = (ctx->packet_walk && ctx->scene->quad_pending <= 64u) ? 1u : 0u;           // stack levels are lanes of a register
+    if (kind >= 0 && ctx->walk_auto && W.packet) {
+        ctgpu_ctx::WalkChoice &c = ctx->choice[kind];
+        c.ran_probe = c.probe;
+        c.ran_lane = c.use_lane != c.probe;               // a probe frame runs on the walk that is NOT the settled one
+        c.probe = false;
+        if (c.ran_lane) W.packet = 0u;
+    }
     W.packet_depth = ctx->scene->quad_pending;
     W.packet_lds_levels = std::min<uint32_t>((uint32_t)ctx->packet_lds_levels, W.packet_depth);
     int per_cu = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu
@@ -909,6 +941,10 @@ int fill_pipeline(ctgpu_ctx *ctx, uint64_t n_samples, PipelineParams &W) {
     if (per_cu < 1) per_cu = 1;
     const uint64_t waves_needed = (W.n_samples + 63) / 64;
     W.walk_blocks = (uint32_t)std::min<uint64_t>((uint64_t)per_cu * ctx->cu_count, std::max<uint64_t>(waves_needed, 1));
+    {   // the per-lane launches behind the packet launches: never more waves than the packet grid (they share its spill area)
+        const int lane_per_cu = std::max(1, pipeline_walk_occupancy(lds_bytes));
+        W.listed_blocks = std::max<uint32_t>(1u, std::min<uint32_t>(W.walk_blocks, (uint32_t)lane_per_cu * (uint32_t)ctx->cu_count));
+    }
     // chunk: small enough that every wave gets many (dynamic balance), large enough that the
     // queue's head word sees few atomics
     // (measured on MI355X, dragon stand-in: 128 for 18M-sample frames, 64 for 1M-sample frames)
@@ -922,6 +958,18 @@ int fill_pipeline(ctgpu_ctx *ctx, uint64_t n_samples, PipelineParams &W) {
     HIP_TRY(ctx->spill.resize((size_t)W.walk_blocks * (size_t)std::max(W.lds_depth + W.spill_depth, W.packet_depth) * 64 * 12 / 8 + 64));
     W.queue = ctx->queue.ptr; W.spill = ctx->spill.ptr; W.shadow_lights = ctx->scene->shadow_lights.ptr;
     W.walk_work = ctx->walk_work.ptr;
+    // hand-over lists: room for half of the frame's primary rays and half of its possible shadow rays
+    W.packet_budget = W.packet ? (uint32_t)ctx->packet_budget : 0u;
+    W.packet_lanes = (uint32_t)ctx->packet_lanes;
+    W.handed = ctx->queue.ptr + kQueueWords;
+    W.handed_room = 0;
+    if (W.packet_budget) {
+        W.handed_room = std::max<uint64_t>(n_samples / 2u, 4096u);
+        HIP_TRY(ctx->handed_ids[0].resize(W.handed_room));
+        HIP_TRY(ctx->handed_ids[1].resize(W.handed_room));
+        W.handed_ids[0] = ctx->handed_ids[0].ptr;
+        W.handed_ids[1] = ctx->handed_ids[1].ptr;
+    }
     return CTGPU_OK;
 }
 
@@ -1028,6 +1076,7 @@ int begin_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, uint32_t *host_fb
         }
     }
 
+    ctx->pending.kind = pipeline_eligible(ctx, frame) ? ((frame->flags & CTGPU_F_SUPERSAMPLE) ? 1 : 0) : -1;
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
     rc = launch_frame(ctx, frame, P, ctx->stream); if (rc) return rc;
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
@@ -1053,6 +1102,34 @@ int begin_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, uint32_t *host_fb
 
 // the page-lock begin_frame put on the caller's framebuffer ends with the frame: the caller may free that memory
 // (and the allocator may hand the same address out again) as soon as the frame has been reported finished
+// One finished frame's kernel time -> the walk choice of its kind (ctgpu_ctx::WalkChoice).
+int walk_feedback(ctgpu_ctx *ctx, int kind, double kernel_ms) {
+    ctgpu_ctx::WalkChoice &c = ctx->choice[kind];
+    c.frames += 1;
+    (c.ran_lane ? c.lane_ms : c.packet_ms) = kernel_ms;
+    if (c.ran_probe) {                          // both times are fresh: settle (the per-lane walk has to win clearly)
+        c.use_lane = c.lane_ms < 0.9 * c.packet_ms;
+        return CTGPU_OK;
+    }
+    if (c.frames % 256u != 3u) return CTGPU_OK;             // (the third frame: the first two carry one-off costs)
+    if (c.use_lane) { c.probe = true; return CTGPU_OK; }    // is the shared walk still the slower one?
+    // on the shared walk: worth a probe only if this scene's packets share little -- fetches per packet, from the
+    // walks' own counters (totals since the last ctgpu_read_walk_work; read, not cleared)
+    unsigned long long w[64 * 8];
+    HIP_TRY(hipMemcpy(w, ctx->walk_work.ptr, sizeof w, hipMemcpyDeviceToHost));
+    unsigned long long packets = 0, fetches = 0;
+    for (int slot = 0; slot < 64; slot++)
+        for (int k = 0; k < 2; k++) {
+            packets += w[slot * 8 + k * 3];
+            fetches += w[slot * 8 + k * 3 + 1] + w[slot * 8 + k * 3 + 2];
+        }
+    const bool grew = packets > c.packets && fetches >= c.fetches;
+    const double per_packet = grew ? (double)(fetches - c.fetches) / (double)(packets - c.packets) : 0.0;
+    c.packets = packets; c.fetches = fetches;
+    if (per_packet > (double)ctx->probe_above) c.probe = true;
+    return CTGPU_OK;
+}
+
 void release_pin(ctgpu_ctx *ctx) {
     if (ctx->pinned_fb) (void)hipHostUnregister(ctx->pinned_fb);
     ctx->pinned_fb = nullptr;
@@ -1080,6 +1157,9 @@ int finish_frame(ctgpu_ctx *ctx, bool wait, int *done, ctgpu_stats *stats) {
     st.total_ms = std::chrono::duration<double, std::milli>(t1 - ctx->pending.t0).count();
     st.pixels_written = ctx->pending.pixels;
     if (stats) *stats = st;
+    if (ctx->walk_auto && ctx->pending.kind >= 0) {
+        int rc2 = walk_feedback(ctx, ctx->pending.kind, ms); if (rc2) return rc2;
+    }
     return CTGPU_OK;
 }
 }  // namespace
@@ -1313,7 +1393,7 @@ extern "C" int ctgpu_trace_rays_packet(ctgpu_ctx *ctx, const ctgpu_ray *rays, ui
     hipError_t e = hipMalloc((void **)&d_hits, n * sizeof(ctgpu_hit));
     if (e != hipSuccess) { (void)hipFree(d_rays); return ctgpu_fail(CTGPU_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
     e = hipMemcpy(d_rays, rays, n * sizeof(ctgpu_ray), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemsetAsync(ctx->queue.ptr, 0, 33 * 8 * 16 * sizeof(unsigned long long), ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(ctx->queue.ptr, 0, (kQueueWords + 32) * sizeof(unsigned long long), ctx->stream);
     if (e == hipSuccess) {
         W.ray_list = d_rays;
         W.ray_hits = d_hits;
@@ -1347,6 +1427,22 @@ extern "C" int ctgpu_read_walk_work(ctgpu_ctx *ctx, ctgpu_walk_work *out) {
         out->shadow_rays_blocked += w[slot * 8 + 6];
         out->shadow_packets_all_blocked += w[slot * 8 + 7];
     }
+    // (counted in the frame counters, words 17 / 18: what earlier counter reads collected + what is there now)
+    unsigned long long handed[2];
+    HIP_TRY(hipMemcpy(handed, ctx->counters.ptr + 17, sizeof handed, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemset(ctx->counters.ptr + 17, 0, sizeof handed));
+    out->rays_handed_over[0] = ctx->handed_over[0] + handed[0];
+    out->rays_handed_over[1] = ctx->handed_over[1] + handed[1];
+    ctx->handed_over[0] = ctx->handed_over[1] = 0;
+    return CTGPU_OK;
+}
+
+extern "C" int ctgpu_walk_choice(ctgpu_ctx *ctx, int supersampled, int *per_lane, double *packet_ms, double *lane_ms) {
+    if (!ctx) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_walk_choice: null argument");
+    const ctgpu_ctx::WalkChoice &c = ctx->choice[supersampled ? 1 : 0];
+    if (per_lane) *per_lane = ctx->walk_auto ? (c.use_lane ? 1 : 0) : (ctx->packet_walk ? 0 : 1);
+    if (packet_ms) *packet_ms = c.packet_ms;
+    if (lane_ms) *lane_ms = c.lane_ms;
     return CTGPU_OK;
 }
 

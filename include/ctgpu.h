@@ -182,7 +182,10 @@ int  ctgpu_device_count(int *count);
  *   CTGPU_CHUNK_SHADOW   the same for the shadow walk alone (default: CTGPU_CHUNK's value)
  *   CTGPU_KEEP_SHADOW_RAYS   1: trace also the shadow rays whose answer cannot change a pixel (ct_light_gate)
  *   CTGPU_RCCL_LIBRARY   path of the librccl to bind (default: one the process already holds, else ROCm's)
- *   CTGPU_PACKET         0: per-lane walk over the binary tree instead of the shared (packet) walk
+ *   CTGPU_PACKET         0: per-lane walk over the binary tree, 1: the shared (packet) walk, always (unset: the
+ *                        shared walk unless the per-lane one was measured faster on this scene, ctgpu_walk_choice)
+ *   CTGPU_PACKET_BUDGET, CTGPU_PACKET_LANES   experiment, off by default: packets that made BUDGET visits with fewer
+ *                        than LANES rays per visit hand their rays to the per-lane kernel
  *   CTGPU_PACKET_LDS_LEVELS, CTGPU_LDS_DEPTH   stack levels kept in LDS (deeper ones go to HBM)
  *   CTGPU_FORCE_MEGAKERNEL   1: the general path (one kernel, reflection capable) for every frame
  *   CTGPU_PACK           host: re-lay-out an uploaded tree on the host (default: on the device) */
@@ -316,6 +319,7 @@ int  ctgpu_build_bvh(int device, const double *vertices, uint32_t n, ctgpu_node 
 typedef struct ctgpu_walk_work {
     uint64_t packets[2], quad_nodes[2], triangle_records[2];
     uint64_t shadow_rays_blocked, shadow_packets_all_blocked;      /* shadow walk: rays that found a blocker; packets whose every ray did */
+    uint64_t rays_handed_over[2];      /* rays of packets that had stopped sharing their walk, traced by the per-lane kernel instead */
 } ctgpu_walk_work;
 typedef struct ctgpu_kernel_times { uint64_t launches[CTGPU_PIPELINE_KERNELS]; double total_ms[CTGPU_PIPELINE_KERNELS]; } ctgpu_kernel_times;
 /* ctgpu_render_sharded's phases on this rank, HIP events on the frame's stream while ctgpu_kernel_timing is on:
@@ -324,6 +328,12 @@ typedef struct ctgpu_kernel_times { uint64_t launches[CTGPU_PIPELINE_KERNELS]; d
 typedef struct ctgpu_phase_times { uint64_t frames; double trace_ms, gather_ms, assemble_ms; } ctgpu_phase_times;
 int  ctgpu_read_phase_times(ctgpu_ctx *ctx, ctgpu_phase_times *out);
 int  ctgpu_read_walk_work(ctgpu_ctx *ctx, ctgpu_walk_work *out);
+/* Which walk traces this context's frames of a kind (supersampled or not) at the moment -- the shared walk or the
+ * per-lane one -- and the kernel times last measured on either.  Without CTGPU_PACKET in the environment the context
+ * chooses by measurement: a scene whose packets share little (more than CTGPU_PROBE_ABOVE fetches per packet, default
+ * 100) gets one frame on the per-lane walk, and whichever was faster is kept (same pixels either way); every 256
+ * frames the other walk gets one frame again. */
+int  ctgpu_walk_choice(ctgpu_ctx *ctx, int supersampled, int *per_lane, double *packet_ms, double *lane_ms);
 int  ctgpu_kernel_timing(ctgpu_ctx *ctx, int enable);
 int  ctgpu_read_kernel_times(ctgpu_ctx *ctx, ctgpu_kernel_times *out);
 

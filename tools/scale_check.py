@@ -34,12 +34,23 @@ assert (indexes == scene.indexes()).all(), "device index permutation differs"
 print("device BVH build: %.1f ms on the GPU, byte-identical to the host builder's tree" % ms); sys.stdout.flush()
 
 ctx = ca.GpuContext(0)
-t0 = time.time(); ctx.upload(scene.desc); print("upload %.1f s" % (time.time() - t0)); sys.stdout.flush()
+t0 = time.time(); ctx.upload(scene.desc); print("upload (tree from the host, packed on the device) %.2f s" % (time.time() - t0)); sys.stdout.flush()
+fresh = ca.GpuContext(0)
+t0 = time.time(); fresh.upload(scene.desc, build_on_device=True); dt = time.time() - t0
+info = fresh.scene_info()
+print("vertices -> BuildBVH + packing in HBM: %.3f s (device: build %.1f ms, packing %.1f ms); %.0f MB" % (dt, info.build_ms, info.pack_ms, info.hbm_bytes / 1e6))
+for which in range(6):
+    assert (fresh.scene_array(which) == ctx.scene_array(which)).all(), which
+fresh.close()
+sys.stdout.flush()
 orc = oracle
 for (wd, ht, ss) in ((1920, 1080, False), (640, 360, True)):
     f = scene.frame(wd, ht, threads=8, supersampling=ss, rng_seed=1)
     f.cam_pos = (C.c_double * 3)(0.0, 2.5, -4.0)
-    got, st = ctx.render(f); got, st = ctx.render(f)
+    for _ in range(6):                      # (the context measures both walks on a scene like this one and keeps the faster)
+        got, st = ctx.render(f)
+    lane, packet_ms, lane_ms = ctx.walk_choice(ss)
+    print("   walk chosen: %s (shared %.2f ms, per-lane %.2f ms)" % ("per-lane" if lane else "shared", packet_ms, lane_ms))
     t0 = time.time(); want, cst = orc.render(scene.desc, f, os_threads=16); dt = time.time() - t0
     diff = int((got != want).sum())
     print("%dx%d ss=%d: %d rays, GPU kernel %.2f ms (%.0f Mrays/s), oracle %.1f s; differing pixels %d, hit pixels %d" % (
