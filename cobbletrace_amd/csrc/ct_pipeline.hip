@@ -989,6 +989,39 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                         PK_COUNT(2, count);
                         PK_COUNT(3, (uint64_t)count * __popcll(mask));
                     }
+#ifdef CT_TRI_STATS
+                    // diagnostic build (tools/tri_stats.py): how far does the WAVE get into IntersectTriangle for this
+                    // record -- the test's exits are wave-level branches, so a stage costs only if some lane reaches it
+                    if (KIND == W.thresh_a) {
+                        const d3 p1s = make_d3(tr.f64(0), tr.f64(1), tr.f64(2)), e1s = make_d3(tr.f64(3), tr.f64(4), tr.f64(5)),
+                                 e2s = make_d3(tr.f64(6), tr.f64(7), tr.f64(8));
+                        const bool active = mine && (!ANY_HIT || t == kNoHit);
+                        int stage = 0;                                      // 0: out at |a| < 1e-4, 1: out at u, 2: out at v / u+v, 3: passes
+                        {
+                            const d3 hs = cross(d, e2s);
+                            const float as = dotf(e1s, hs);
+                            if (!(as > -0.0001f && as < 0.0001f)) {
+                                const float fs = 1.0f / as;
+                                const d3 ss = RAY_O - p1s;
+                                const float us = fs * dotf(ss, hs);
+                                stage = 1;
+                                if (!(us < 0 || us > 1)) {
+                                    const d3 qs = cross(ss, e1s);
+                                    const float vs = fs * dotf(d, qs);
+                                    stage = 2;
+                                    if (!(vs < 0 || us + vs > 1)) stage = 3;
+                                }
+                            }
+                        }
+                        const unsigned long long n_act = __ballot(active), r3 = __ballot(active && stage == 3),
+                                                 r2 = __ballot(active && stage == 2), r1 = __ballot(active && stage == 1);
+                        const int reach = r3 ? 3 : (r2 ? 2 : (r1 ? 1 : 0));
+                        if (n_act != 0ull && lane == 0) {
+                            atomicAdd(&P.counters[19], 1ull);
+                            atomicAdd(&P.counters[20 + reach], 1ull);
+                        }
+                    }
+#endif
                     if (mine && (!ANY_HIT || t == kNoHit)) {
                         const d3 p1 = make_d3(tr.f64(0), tr.f64(1), tr.f64(2)), e1 = make_d3(tr.f64(3), tr.f64(4), tr.f64(5)),
                                  e2 = make_d3(tr.f64(6), tr.f64(7), tr.f64(8));

@@ -845,6 +845,9 @@ int read_counters(ctgpu_ctx *ctx, ctgpu_stats *st) {
         std::fprintf(stderr, "phases: A %llu x %.1f lanes (%.0f cyc each), B %llu x %.1f lanes (%.0f cyc), C %llu x %.1f lanes (%.0f cyc)\n", c[5],
                      (double)c[6] / c[5], (double)c[11] / c[5], c[7], c[7] ? (double)c[8] / c[7] : 0.0, c[7] ? (double)c[12] / c[7] : 0.0,
                      c[9], c[9] ? (double)c[10] / c[9] : 0.0, c[9] ? (double)c[13] / c[9] : 0.0);
+    if (std::getenv("CTGPU_DEBUG_TRI") && c[19])         // diagnostic build -DCT_TRI_STATS (tools/tri_stats.py)
+        std::fprintf(stderr, "triangle records tested by a wave: %llu; the wave's furthest lane stops at |a| %.2f%%, at u %.2f%%, at v / u+v %.2f%%, "
+                     "passes (a hit candidate) %.2f%%\n", c[19], 100.0 * c[20] / c[19], 100.0 * c[21] / c[19], 100.0 * c[22] / c[19], 100.0 * c[23] / c[19]);
     if (std::getenv("CTGPU_DEBUG_REDO"))
         std::fprintf(stderr, "packet walk: %llu rays walked again unfolded (NaN box parameter)\n", c[15]);
     if (std::getenv("CTGPU_DEBUG_PACKET") && c[14])
