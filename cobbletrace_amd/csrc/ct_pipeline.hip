@@ -29,6 +29,7 @@
 // ct_kernels.hip header.
 #include "ct_params.h"
 #include "ct_raygen.h"
+#include "ct_spheres.h"
 
 #include <algorithm>
 
@@ -46,6 +47,10 @@ constexpr int kWave = 64;
 #endif
 constexpr uint32_t kShards = 8;                     // ray-queue head words (one per XCD)
 constexpr uint32_t kInvalidSample = 0xfffffffeu;   // hits[].slot of a sample that is not part of the frame
+// hits[].slot of a sample whose closest object is a SPHERE (CTGPU_F_SPHERES): bit 30 and the sphere's index (TriRecord
+// slots stay below 2^30, kNoNode / kInvalidSample have bit 31)
+constexpr uint32_t kSphereTag = 0x40000000u;
+__device__ __forceinline__ bool is_sphere_hit(uint32_t slot) { return (slot & 0xC0000000u) == kSphereTag; }
 
 struct StackEntry { uint32_t ref; float tmin; };
 
@@ -1267,15 +1272,23 @@ __device__ __forceinline__ ShadedPoint shaded_point(const FrameParams &P, const 
     if (SS) { const float2 c = W.coords[id]; cx = c.x; cy = c.y; }
     else { cx = (float)((int)xi - P.half); cy = (float)((int)yi - P.half); }
     const d3 dir = primary_direction(P, cx, cy);
-    const uint32_t rec_slot = (h.y != kNoNode) ? h.y : P.slot_of_triangle0;
     const float tclosest = (h.y != kNoNode) ? __uint_as_float(h.x) : kFarAway;
-    const TriRecord *rec = P.tris + rec_slot;
     ShadedPoint s;
-    s.material = P.materials[rec->triangle];
     s.position = eye + scale((double)tclosest, dir);
+    s.view = -dir;
+    if (is_sphere_hit(h.y)) {
+        // NormalOfSceneObject, OT_SPHERE (raythread.cpp:331-334): n / Magnitude(n) = (1.0f / (D)F|n|) * n
+        const ctgpu_sphere &sphere = P.spheres[h.y & ~kSphereTag];
+        s.material.color = sphere.material.color; s.material.specular = sphere.material.specular; s.material.reflection = sphere.material.reflection;
+        const d3 n = s.position - load_d3(sphere.center);
+        s.normal = scale((double)1.0f / (double)lengthf(n), n);
+        return s;
+    }
+    const uint32_t rec_slot = (h.y != kNoNode) ? h.y : P.slot_of_triangle0;
+    const TriRecord *rec = P.tris + rec_slot;
+    s.material = P.materials[rec->triangle];
     s.normal = cross(load_d3(rec->e1), load_d3(rec->e2));
     if (!(dotf(s.normal, dir) < 0)) s.normal = -s.normal;
-    s.view = -dir;
     return s;
 }
 // vector towards a non-ambient light (raythread.cpp:289-296)
@@ -1321,6 +1334,46 @@ __device__ __forceinline__ uint32_t shade_sample(const FrameParams &P, const Pip
         }
     }
     return shade_value(s.material.color, intensity);
+}
+
+// ------------------------------------------------------------------------------------
+// ct_sphere_pass: the scene's spheres (CTGPU_F_SPHERES), after a triangle walk.  The reference renders no spheres since
+// it got its BVH (raythread.cpp:207); behind the frame flag they are intersected as its pre-BVH loop did
+// (raythread.cpp:230-246, ct_spheres.h) AFTER the triangles, against the closest distance those left -- so the
+// triangles stay on the packet walk and the spheres are one lane per ray over their own small tree.
+//   KIND 0 (after the primary walk): a sphere nearer than the closest triangle takes the sample over --
+//          hits[] = {its distance, kSphereTag | sphere}; camera rays accept t in [1, inf) (raythread.cpp:480).
+//   KIND 1 (after the shadow walk): a shadow ray no triangle blocked may still meet a sphere, t in [0.001, 1] towards
+//          a point light, [0.001, inf) along a directional one (raythread.cpp:289-307).
+// ------------------------------------------------------------------------------------
+template <bool SS, int KIND>
+__global__ __launch_bounds__(256) void ct_sphere_pass(const FrameParams P, const PipelineParams W) {
+    const uint64_t total = (KIND == 0) ? W.n_samples : W.n_samples * (uint64_t)W.n_shadow_lights;
+    const d3 eye = make_d3(P.cam[0], P.cam[1], P.cam[2]);
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256u) {
+        const uint64_t id = (KIND == 0) ? i : i % W.n_samples;
+        if (KIND == 1 && W.shadow[i] != 0) continue;             // blocked by a triangle already, or no ray here
+        const uint2 h = W.hits[id];
+        if (h.y == kInvalidSample) continue;
+        float px, py;
+        if (!sample_position<SS>(P, W, id, px, py)) continue;
+        const d3 dir = primary_direction(P, px, py);
+        if (KIND == 0) {
+            float tclosest = (h.y != kNoNode) ? __uint_as_float(h.x) : kFarAway;
+            int sphere = -1;
+            walk_spheres(P, eye, dir, 1.0f, kFarAway, tclosest, sphere);
+            if (sphere >= 0) W.hits[id] = make_uint2(__float_as_uint(tclosest), kSphereTag | (uint32_t)sphere);
+        } else {
+            const float tclosest = (h.y != kNoNode) ? __uint_as_float(h.x) : kFarAway;
+            const d3 position = eye + scale((double)tclosest, dir);
+            const Light L = P.lights[W.shadow_lights[i / W.n_samples]];
+            const d3 to_light = (L.type == CTGPU_LIGHT_POINT) ? load_d3(L.position) - position : load_d3(L.direction);
+            float nearest = kFarAway;
+            int sphere = -1;
+            walk_spheres(P, position, to_light, 0.001f, L.type == CTGPU_LIGHT_POINT ? 1.0f : kFarAway, nearest, sphere);
+            if (sphere >= 0) W.shadow[i] = 1;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1449,6 +1502,14 @@ void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hip
     const uint32_t pixel_blocks = (pixel_slots + 255u) / 256u;
     const uint32_t sample_blocks = (uint32_t)std::min<uint64_t>((W.n_samples + 255u) / 256u, 2048u);      // ct_light_gate strides
     const bool shadows = W.n_shadow_lights != 0;
+    // the spheres' own passes (CTGPU_F_SPHERES frames of scenes that have any): their time goes to the walk before them
+    auto sphere_pass = [&](int kind) {
+        if (!P.n_spheres) return;
+        if (kind == 0 && ss) hipLaunchKernelGGL((ct_sphere_pass<true, 0>), dim3(sample_blocks), dim3(256), 0, stream, P, W);
+        if (kind == 0 && !ss) hipLaunchKernelGGL((ct_sphere_pass<false, 0>), dim3(sample_blocks), dim3(256), 0, stream, P, W);
+        if (kind == 1 && ss) hipLaunchKernelGGL((ct_sphere_pass<true, 1>), dim3(sample_blocks), dim3(256), 0, stream, P, W);
+        if (kind == 1 && !ss) hipLaunchKernelGGL((ct_sphere_pass<false, 1>), dim3(sample_blocks), dim3(256), 0, stream, P, W);
+    };
     mark(0);
     if (ss) hipLaunchKernelGGL(ct_sample_grid, dim3(pixel_blocks), dim3(256), 0, stream, P, W);
     mark(1);
@@ -1468,6 +1529,7 @@ void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hip
         if (!ss && handover) hipLaunchKernelGGL((ct_walk_packet<0, false, true>), grid, wave, lds_p, stream, P, W);
         if (handover && ss) hipLaunchKernelGGL((ct_walk<0, true, true>), grid_l, wave, lds_l, stream, P, W);
         if (handover && !ss) hipLaunchKernelGGL((ct_walk<0, false, true>), grid_l, wave, lds_l, stream, P, W);
+        sphere_pass(0);
         mark(2);
         if (shadows && ss) hipLaunchKernelGGL((ct_light_gate<true>), dim3(sample_blocks), dim3(256), 0, stream, P, W);
         if (shadows && !ss) hipLaunchKernelGGL((ct_light_gate<false>), dim3(sample_blocks), dim3(256), 0, stream, P, W);
@@ -1482,6 +1544,7 @@ void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hip
         const size_t lds = (size_t)W.lds_depth * kWave * 12u;      // entries + parent words
         if (ss) hipLaunchKernelGGL((ct_walk<0, true>), grid, wave, lds, stream, P, W);
         else hipLaunchKernelGGL((ct_walk<0, false>), grid, wave, lds, stream, P, W);
+        sphere_pass(0);
         mark(2);
         if (shadows && ss) hipLaunchKernelGGL((ct_light_gate<true>), dim3(sample_blocks), dim3(256), 0, stream, P, W);
         if (shadows && !ss) hipLaunchKernelGGL((ct_light_gate<false>), dim3(sample_blocks), dim3(256), 0, stream, P, W);
@@ -1489,6 +1552,7 @@ void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hip
         if (shadows && ss) hipLaunchKernelGGL((ct_walk<1, true>), grid, wave, lds, stream, P, W);
         if (shadows && !ss) hipLaunchKernelGGL((ct_walk<1, false>), grid, wave, lds, stream, P, W);
     }
+    if (shadows) sphere_pass(1);
     mark(4);
     if (ss) hipLaunchKernelGGL((ct_shade<true>), dim3(pixel_blocks), dim3(256), 0, stream, P, W);
     else hipLaunchKernelGGL((ct_shade<false>), dim3(pixel_blocks), dim3(256), 0, stream, P, W);

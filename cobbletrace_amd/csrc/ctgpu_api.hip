@@ -65,7 +65,8 @@ struct DeviceArray {
 // ranks of a test on one GPU) can share ONE copy (ctgpu_share_scene): the dragon is ~0.5 GB per copy.
 struct SceneStore {
     int device = 0;
-    bool has_reflection = false;
+    bool has_reflection = false;                // some material reflects (triangles' or spheres')
+    bool triangles_reflect = false, spheres_reflect = false;
     uint32_t n_triangles = 0, n_lights = 0, tree_depth = 0, n_nodes = 0;
     uint32_t root_ref = 0, slot_of_triangle0 = 0;
     double root_min[3] = {0, 0, 0}, root_max[3] = {0, 0, 0};
@@ -577,6 +578,7 @@ extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
 
     bool reflective = false;
     for (uint32_t i = 0; i < N; i++) reflective = reflective || (s->materials[i].reflection > 0);
+    S.triangles_reflect = reflective;
     static_assert(sizeof(Material) == sizeof(ctgpu_material), "material layout");
     static_assert(sizeof(Light) == sizeof(ctgpu_light), "light layout");
     HIP_TRY(S.materials.resize(N));
@@ -627,7 +629,8 @@ extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
         HIP_TRY(hipMemcpy(S.sphere_indexes.ptr, s->sphere_indexes, (size_t)s->n_spheres * sizeof(uint32_t), hipMemcpyHostToDevice));
         S.n_spheres = s->n_spheres;
         S.sphere_tree_depth = sphere_depth;
-        for (uint32_t i = 0; i < s->n_spheres; i++) reflective = reflective || (s->spheres[i].material.reflection > 0);
+        for (uint32_t i = 0; i < s->n_spheres; i++) S.spheres_reflect = S.spheres_reflect || (s->spheres[i].material.reflection > 0);
+        reflective = reflective || S.spheres_reflect;
     }
 
     S.n_triangles = N;
@@ -880,8 +883,10 @@ namespace {
 // more than 32 shadow-casting lights take the megakernel.
 bool pipeline_eligible(const ctgpu_ctx *ctx, const ctgpu_frame_desc *f) {
     if (ctx->force_megakernel) return false;
-    if (ctx->scene->has_reflection && f->max_depth > 0) return false;
-    if ((f->flags & CTGPU_F_SPHERES) && ctx->scene->n_spheres) return false;       // spheres are rendered by the general path
+    const bool spheres = (f->flags & CTGPU_F_SPHERES) && ctx->scene->n_spheres;
+    // reflective materials bounce (TraceRay's recursion): the general path.  A sphere's material counts only in frames
+    // that draw spheres.
+    if (f->max_depth > 0 && (ctx->scene->triangles_reflect || (spheres && ctx->scene->spheres_reflect))) return false;
     return ctx->scene->n_shadow_lights <= 32;
 }
 

@@ -98,3 +98,56 @@ def test_walk_is_chosen_by_measurement(scenes, monkeypatch):
         assert ctx.walk_choice(True) == (False, 0.0, 0.0) or ctx.walk_choice(True)[2] == 0.0
     finally:
         ctx.close()
+
+
+def test_spheres_stay_on_the_fast_path(tmp_path, monkeypatch):
+    """CTGPU_F_SPHERES frames of a scene without reflective materials: the triangles on the packet walk, the spheres
+    in their own passes after it (ct_sphere_pass) -- against the oracle's restatement and against the general path
+    (which renders the same frame in one kernel).  Spheres in front of, behind and between triangles; shadows of
+    spheres on triangles and of triangles on spheres; a point light (tMax = 1) and a directional one."""
+    import json
+    from oracle import oracle
+    rng = np.random.default_rng(12)
+    objs = [{"type": "sphere", "center": [0, -1, 3], "radius": 1, "color": [255, 0, 0], "specular": 500, "reflection": 0},
+            {"type": "sphere", "center": [2, 0, 4], "radius": 1, "color": [0, 0, 255], "specular": 500, "reflection": 0},
+            {"type": "sphere", "center": [-2, 0, 4], "radius": 1, "color": [0, 255, 0], "specular": 10, "reflection": 0},
+            {"type": "sphere", "center": [0, -5001, 0], "radius": 5000, "color": [255, 255, 0], "specular": 1000, "reflection": 0},
+            {"type": "sphere", "center": [0.5, 0.8, 2.2], "radius": 0.3, "color": [200, 200, 200], "specular": -1, "reflection": 0},
+            {"type": "sphere", "center": [0.2, 1.5, 8.0], "radius": 1.2, "color": [90, 200, 200], "specular": 40, "reflection": 0}]
+    for _ in range(60):                                     # a cloud of small triangles among the spheres
+        c = rng.uniform([-3, -1, 2], [3, 2.5, 7])
+        p = [list(c + rng.normal(size=3) * 0.35) for _ in range(3)]
+        objs.append({"type": "triangle", "p1": p[0], "p2": p[1], "p3": p[2], "color": [int(x) for x in rng.integers(60, 255, 3)],
+                     "specular": int(rng.choice([-1, 20, 300])), "reflection": 0})
+    objs.append({"type": "triangle", "p1": [-4, -1, 6.5], "p2": [4, -1, 6.5], "p3": [0, 4, 6.5], "color": [255, 0, 255], "specular": 50, "reflection": 0})
+    lights = [{"type": "ambient", "intensity": 0.2}, {"type": "point", "intensity": 0.6, "position": [2, 1, 0]},
+              {"type": "directional", "intensity": 0.2, "direction": [1, 4, 4]}]
+    path = tmp_path / "spheres_and_triangles.json"
+    path.write_text(json.dumps({"objects": objs, "lights": lights, "camera": {"position": [0, 0, -1]},
+                                "settings": {"numberOfThreads": 4, "subsampling": False, "wireframe": False, "supersampling": True}}))
+    scene = ca.HostScene(str(path))
+    assert scene.desc.n_spheres == 6 and scene.desc.n_triangles == 61
+    fast = ca.GpuContext(0)
+    fast.upload(scene.desc)
+    monkeypatch.setenv("CTGPU_FORCE_MEGAKERNEL", "1")
+    general = ca.GpuContext(0)
+    general.upload(scene.desc)
+    monkeypatch.delenv("CTGPU_FORCE_MEGAKERNEL")
+    try:
+        for ss, w, h in ((False, 640, 480), (True, 400, 300)):
+            frame = scene.frame(w, h, supersampling=ss, rng_seed=5, spheres=True)
+            fast.read_walk_work()
+            got, st = fast.render(frame)
+            assert fast.read_walk_work().packets[0] > 0                     # the packet walk traced the triangles
+            want, _ = oracle.render(scene.desc, frame, os_threads=4)
+            other, _ = general.render(frame)
+            diff = int((got != want).sum())
+            print("spheres on the fast path ss=%d: %d pixels differ from the oracle, %d from the general path" % (ss, diff, int((got != other).sum())))
+            shifts = np.array([0, 8, 16])
+            assert np.abs(((got[..., None] >> shifts) & 255).astype(int) - ((want[..., None] >> shifts) & 255).astype(int)).max() <= 1
+            assert (got == other).all()
+            without, _ = fast.render(scene.frame(w, h, supersampling=ss, rng_seed=5))
+            assert (without != got).sum() > 2000                            # the flag really draws spheres
+    finally:
+        fast.close()
+        general.close()
