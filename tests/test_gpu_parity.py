@@ -26,6 +26,37 @@ def _compare(gpu_fb, cpu_fb, what):
     return n_diff
 
 
+class _knob:
+    """`with _knob("CTGPU_PACKET", "0"):` -- a CTGPU_* variable for the duration, then whatever was there before
+    (the suite itself may be running under a knob: CTGPU_PACKET=0 python -m pytest ...)."""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.before = os.environ.get(self.name)
+        os.environ[self.name] = self.value
+
+    def __exit__(self, *exc):
+        if self.before is None:
+            os.environ.pop(self.name, None)
+        else:
+            os.environ[self.name] = self.before
+
+
+def _context_with(monkeypatch, scene, **knobs):
+    """A context of its own whose knobs are what THIS test says (CTGPU_* are read when a context is made), whatever
+    the environment the suite runs under: None removes a variable."""
+    for key, value in knobs.items():
+        if value is None:
+            monkeypatch.delenv(key, raising=False)
+        else:
+            monkeypatch.setenv(key, str(value))
+    ctx = ca.GpuContext(0)
+    ctx.upload(scene.desc)
+    return ctx
+
+
 def _random_rays(scene, n, seed):
     rng = np.random.default_rng(seed)
     v = scene.vertices()
@@ -262,13 +293,13 @@ def test_native_rccl_frame_on_a_world_of_one(scenes, gpu_ctx):
         gpu_ctx("bunny").render_sharded(scene.frame(64, 64, threads=1), 8, 0)
 
 
-def test_measurement_hooks(scenes):
+def test_measurement_hooks(scenes, monkeypatch):
     """ctgpu_kernel_timing / ctgpu_read_kernel_times and ctgpu_read_walk_work, what bench.py's roofline object is
     made of: one launch of each pipeline kernel per frame, event times that add up to the frame's kernel time,
-    fetch counts of the two walks that are plausible (every packet fetches at least the root QuadNode)."""
+    fetch counts of the two walks that are plausible (every packet fetches at least the root QuadNode).  The fetch
+    counters are the shared walk's: the test asks for it."""
     scene = scenes("bunny")
-    ctx = ca.GpuContext(0)
-    ctx.upload(scene.desc)
+    ctx = _context_with(monkeypatch, scene, CTGPU_PACKET=1, CTGPU_PACKET_BUDGET=None)
     try:
         frame = scene.frame(640, 360, threads=8, supersampling=True, rng_seed=1)
         ctx.render(frame)
@@ -293,7 +324,7 @@ def test_measurement_hooks(scenes):
         ctx.close()
 
 
-def test_dragon_full_size_properties(scenes, gpu_ctx):
+def test_dragon_full_size_properties(scenes, gpu_ctx, monkeypatch):
     """BASELINE.json's headline workload at full size (the oracle would take minutes here):
     size-independent properties -- determinism, ray accounting, tile-split invariance against
     a band of oracle rows."""
@@ -304,7 +335,13 @@ def test_dragon_full_size_properties(scenes, gpu_ctx):
     assert (a == b).all() and sa.rays == sb.rays                  # idempotent
     hits = int(((a != 0x333333) & (a != 0)).sum())
     # two non-ambient lights per hit: traced, or left out because the light cannot contribute there
-    assert sa.rays_shadow + sa.rays_shadow_elided == 2 * hits and 0 < sa.rays_shadow_elided < hits * 2
+    assert sa.rays_shadow + sa.rays_shadow_elided == 2 * hits and 0 <= sa.rays_shadow_elided < hits * 2
+    lean = _context_with(monkeypatch, scene, CTGPU_KEEP_SHADOW_RAYS=None)          # (the default, whatever the suite runs under)
+    try:
+        c, sc = lean.render(frame)
+        assert (c == a).all() and sc.rays_shadow + sc.rays_shadow_elided == 2 * hits and sc.rays_shadow_elided > 0
+    finally:
+        lean.close()
     assert sa.rays_primary == 1080 * 1056 - 1080                  # rendered rows x square, minus the dropped row
     assert (a[1:25] == 0).all() and (a[0] == 0).all() and (a[:, :420] == 0).all() and (a[:, 1500:] == 0).all()
     # four bands (of 32) against the oracle, bit for bit
@@ -359,6 +396,27 @@ def test_dragon_headline_frame_supersampled(scenes, gpu_ctx):
     n_diff = _compare(a[rows], cpu_fb[rows], "dragon stand-in 1920x1080 ss=on, bands %s" % bands)
     assert n_diff == 0            # observed: bit-identical (the 1-LSB allowance is for pow(), which has not bitten yet)
     assert ((a[rows] != 0x333333) & (a[rows] != 0)).sum() > 50_000             # the bands show the mesh
+
+
+@pytest.mark.parametrize("name,bands,min_hit", [("import", [2, 9, 15, 20, 27], 60_000), ("bunny", [4, 10, 16, 23, 29], 40_000)])
+def test_c2_c3_scene_default_frames_at_full_size(name, bands, min_hit, scenes, gpu_ctx):
+    """BASELINE.json configs[1] and [2] (C2 scene_import.json, C3 scene_import_bunny.json) at 1920x1080 with the scene
+    files' OWN settings -- 32 bands, supersampling on (16 samples per pixel, hash jitter seed 0), three lights with
+    shadow rays: five of the 32 row bands, spread over the image, against the oracle, bit for bit; whole-frame
+    properties (idempotence, ray accounting, the untouched border)."""
+    scene, ctx = scenes(name), gpu_ctx(name)
+    frame = scene.frame(1920, 1080, rng_mode=ca.RNG_HASH, rng_seed=0)
+    assert frame.flags & ca.F_SUPERSAMPLE and not (frame.flags & ca.F_SUBSAMPLE) and frame.num_threads == 32
+    a, sa = ctx.render(frame)
+    b, sb = ctx.render(frame)
+    assert (a == b).all() and sa.rays == sb.rays
+    assert sa.rays_primary == (1080 * 1056 - 1080) * 16
+    assert (a[1:25] == 0).all() and (a[0] == 0).all() and (a[:, :420] == 0).all() and (a[:, 1500:] == 0).all()
+    cpu_fb, rows = _oracle_bands_parallel(scene, frame, bands)
+    assert rows.sum() == len(bands) * 33
+    n_diff = _compare(a[rows], cpu_fb[rows], "%s 1920x1080 ss=on (scene default), bands %s" % (name, bands))
+    assert n_diff == 0
+    assert ((a[rows] != 0x333333) & (a[rows] != 0)).sum() > min_hit
 
 
 def test_dragon_4k_supersampled_c5(scenes, gpu_ctx):
@@ -438,11 +496,13 @@ def test_elided_shadow_rays_are_accounted_for(scenes, gpu_ctx, monkeypatch):
             ctxs[name] = ca.GpuContext(0)
             ctxs[name].upload(scenes(name).desc)
         monkeypatch.delenv("CTGPU_KEEP_SHADOW_RAYS")
+        leans = {name: _context_with(monkeypatch, scenes(name), CTGPU_KEEP_SHADOW_RAYS=None) for name in ("bunny", "import")}
+        ctxs.update({"lean " + k: v for k, v in leans.items()})
         for name, w, h in (("bunny", 640, 360), ("import", 480, 270)):
             scene = scenes(name)
             for ss in (False, True):
                 frame = scene.frame(w, h, threads=8, supersampling=ss, rng_seed=6)
-                lean, sl = gpu_ctx(name).render(frame)
+                lean, sl = leans[name].render(frame)
                 full, sf = ctxs[name].render(frame)
                 assert (lean == full).all()
                 assert sf.rays_shadow_elided == 0 and sl.rays_shadow_elided > 0
@@ -704,11 +764,8 @@ def test_rays_with_nan_box_parameters(tmp_path):
     rays["direction"] = np.c_[rng.normal(size=4000) * 0.5, np.zeros(4000), np.ones(4000)]
     rays["t"] = np.float32(1e30)
     for packet in ("1", "0"):
-        os.environ["CTGPU_PACKET"] = packet
-        try:
+        with _knob("CTGPU_PACKET", packet):
             ctx = ca.GpuContext(0)
-        finally:
-            del os.environ["CTGPU_PACKET"]
         ctx.upload(scene.desc)
         try:
             for ss, sub in ((False, False), (True, False), (False, True)):
@@ -768,11 +825,8 @@ def test_nan_parameter_rays_that_hit(tmp_path):
     ref = _oracle().trace_rays(scene.desc, rays)
     assert ref["found"][640:].sum() > 1500            # the in-plane rays really hit (the tall triangles)
     for packet in ("1", "0"):
-        os.environ["CTGPU_PACKET"] = packet
-        try:
+        with _knob("CTGPU_PACKET", packet):
             ctx = ca.GpuContext(0)
-        finally:
-            del os.environ["CTGPU_PACKET"]
         ctx.upload(scene.desc)
         try:
             for ss, sub in ((False, False), (True, False), (False, True)):
@@ -948,13 +1002,10 @@ def test_degenerate_inputs(tmp_path):
     for name, lights in cases.items():
         path = _write_scene(tmp_path, name + ".json", tris, lights, camera=(0, 0.4, -3))
         for packet in ("1", "0"):
-            os.environ["CTGPU_PACKET"] = packet
-            try:
+            with _knob("CTGPU_PACKET", packet):
                 for ss in (False, True):
                     gpu_fb, cpu_fb, st, cst = _render_both(path, 192, 144, threads=4, supersampling=ss, rng_seed=3)
                     _compare(gpu_fb, cpu_fb, "%s packet=%s ss=%d" % (name, packet, ss))
-            finally:
-                del os.environ["CTGPU_PACKET"]
 
 
 @pytest.mark.parametrize("spheres,reflect_fix", [(True, False), (False, True), (True, True)])

@@ -26,6 +26,7 @@ def _sheet(side, seed=3):
 @pytest.mark.parametrize("name,w,h", [("bunny", 960, 540), ("import", 640, 360)])
 def test_handover_of_incoherent_packets_keeps_every_pixel(name, w, h, scenes, gpu_ctx, monkeypatch):
     scene = scenes(name)
+    monkeypatch.setenv("CTGPU_PACKET", "1")                   # (the hand-over belongs to the shared walk)
     monkeypatch.setenv("CTGPU_PACKET_BUDGET", "16")
     monkeypatch.setenv("CTGPU_PACKET_LANES", "40")            # eager: most packets that live 16 visits hand over
     ctx = ca.GpuContext(0)
@@ -127,6 +128,8 @@ def test_spheres_stay_on_the_fast_path(tmp_path, monkeypatch):
                                 "settings": {"numberOfThreads": 4, "subsampling": False, "wireframe": False, "supersampling": True}}))
     scene = ca.HostScene(str(path))
     assert scene.desc.n_spheres == 6 and scene.desc.n_triangles == 61
+    monkeypatch.setenv("CTGPU_PACKET", "1")
+    monkeypatch.delenv("CTGPU_FORCE_MEGAKERNEL", raising=False)
     fast = ca.GpuContext(0)
     fast.upload(scene.desc)
     monkeypatch.setenv("CTGPU_FORCE_MEGAKERNEL", "1")
