@@ -183,6 +183,7 @@ _HOST_SYMBOLS = {
     "cth_event_queue_script": (C.c_uint32, [C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]),
     "cth_raythread_options": (None, [C.c_int, C.c_uint64, C.c_int, C.c_int]),
     "cth_raythread_reset": (None, []),
+    "cth_intersect_bvh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]),
     "cth_raythread_frames": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_char_p]),
     "cth_last_frame_stats": (None, [C.POINTER(Stats)]),
 }

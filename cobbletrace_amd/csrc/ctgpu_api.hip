@@ -892,9 +892,12 @@ bool pipeline_eligible(const ctgpu_ctx *ctx, const ctgpu_frame_desc *f) {
 
 int fill_pipeline(ctgpu_ctx *ctx, uint64_t n_samples, PipelineParams &W, int kind = -1);
 
-int launch_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, FrameParams &P, hipStream_t stream) {
+// `begin` (optional): recorded on the stream right before the frame's first launch -- after the buffers have been
+// sized, so that a context's first frame of a size does not count its hipMallocs as kernel time
+int launch_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, FrameParams &P, hipStream_t stream, hipEvent_t begin = nullptr) {
     const bool ss = (f->flags & CTGPU_F_SUPERSAMPLE) != 0;
     if (!pipeline_eligible(ctx, f)) {
+        if (begin) HIP_TRY(hipEventRecord(begin, stream));
         launch_trace_tiles(P, tile_count(P), ss, ctx->scene->has_reflection && f->max_depth > 0, false, stream);
         HIP_TRY(hipGetLastError());
         return CTGPU_OK;
@@ -906,6 +909,7 @@ int launch_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, FrameParams &P, hipS
     HIP_TRY(ctx->hits.resize(W.n_samples));
     HIP_TRY(ctx->shadow.resize(W.n_samples * std::max<uint32_t>(W.n_shadow_lights, 1)));
     W.coords = ctx->coords.ptr; W.hits = ctx->hits.ptr; W.shadow = ctx->shadow.ptr;
+    if (begin) HIP_TRY(hipEventRecord(begin, stream));
     HIP_TRY(hipMemsetAsync(ctx->queue.ptr, 0, (kQueueWords + 32) * sizeof(unsigned long long), stream));
     hipEvent_t *marks = nullptr;
     if (ctx->kernel_timing) {
@@ -1085,8 +1089,7 @@ int begin_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, uint32_t *host_fb
     }
 
     ctx->pending.kind = pipeline_eligible(ctx, frame) ? ((frame->flags & CTGPU_F_SUPERSAMPLE) ? 1 : 0) : -1;
-    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
-    rc = launch_frame(ctx, frame, P, ctx->stream); if (rc) return rc;
+    rc = launch_frame(ctx, frame, P, ctx->stream, ctx->ev0); if (rc) return rc;
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
     launch_assemble(P, ctx->tiles.ptr, ctx->fb.ptr, ctx->stream);
     HIP_TRY(hipGetLastError());
@@ -1249,8 +1252,7 @@ extern "C" int ctgpu_render_multi(ctgpu_ctx *const *ctxs, int n_ctx, const ctgpu
         rc = fill_params(c, frame, &part, false, P, c->stream); if (rc) return rc;
         HIP_TRY(c->tiles.resize(per_part));
         P.out = c->tiles.ptr;
-        if (i == 0) HIP_TRY(hipEventRecord(root->ev0, root->stream));
-        rc = launch_frame(c, frame, P, c->stream); if (rc) return rc;
+        rc = launch_frame(c, frame, P, c->stream, i == 0 ? root->ev0 : nullptr); if (rc) return rc;
         if (i == 0) HIP_TRY(hipEventRecord(root->ev1, root->stream));
         tile_ptrs.push_back(c->tiles.ptr);
         streams.push_back(c->stream);

@@ -184,6 +184,27 @@ void cth_blit(uint32_t *fb, int width, int height) {
 
 void cth_raythread_reset(void) { RayThreadReset(); }
 
+// IntersectBVHClosest (closest != 0) / IntersectBVH on n rays of the scene's own tree, one call each, as
+// ClosestIntersection makes it (raythread.cpp:204-227): rays / hits are ctgpu_ray / ctgpu_hit records
+int cth_intersect_bvh(void *p, const void *rays_in, uint32_t n, int closest, void *hits_out) {
+    Handle *h = H(p);
+    ensure_packed(h);
+    const ctgpu_ray *rays = static_cast<const ctgpu_ray *>(rays_in);
+    ctgpu_hit *hits = static_cast<ctgpu_hit *>(hits_out);
+    for (uint32_t i = 0; i < n; i++) {
+        ray_t r;
+        r.origin = v3_t{rays[i].origin[0], rays[i].origin[1], rays[i].origin[2]};
+        r.direction = v3_t{rays[i].direction[0], rays[i].direction[1], rays[i].direction[2]};
+        r.t = rays[i].t;
+        float tclosest = 4294967296.0f;
+        uint32_t index = 0;
+        if (closest) IntersectBVHClosest(&r, h->packed.bvh.rootNodeIdx, &h->packed.bvh, &tclosest, &index);
+        else IntersectBVH(&r, h->packed.bvh.rootNodeIdx, &h->packed.bvh);
+        hits[i].t = r.t; hits[i].tclosest = tclosest; hits[i].triangle = index; hits[i].found = r.t != 1e30f;
+    }
+    return 0;
+}
+
 // First call renders; each byte of `keys` is then delivered as one key-down event followed
 // by one more RayThread call (one frame per key).  Returns the number of RayThread calls.
 int cth_raythread_frames(void *p, int width, int height, uint32_t *fb, const char *keys) {

@@ -44,6 +44,7 @@ struct GpuApi {
     decltype(&ctgpu_keep_framebuffer_pinned) keep_pinned = nullptr;
     decltype(&ctgpu_device_count) device_count = nullptr;
     decltype(&ctgpu_build_bvh) build_bvh = nullptr;
+    decltype(&ctgpu_trace_rays_packet) trace_rays_packet = nullptr;
 };
 
 [[noreturn]] void die(const char *what, const char *detail) {
@@ -83,6 +84,7 @@ GpuApi &gpu() {
     RESOLVE(keep_pinned, "ctgpu_keep_framebuffer_pinned");
     RESOLVE(device_count, "ctgpu_device_count");
     RESOLVE(build_bvh, "ctgpu_build_bvh");
+    RESOLVE(trace_rays_packet, "ctgpu_trace_rays_packet");
 #undef RESOLVE
     if (api.abi_version() != CTGPU_ABI_VERSION) die("libctgpu.so ABI mismatch", path.c_str());
     return api;
@@ -164,7 +166,10 @@ void RayThreadSetOptions(const ct_raythread_options *opt) {
     if (opt) boss().options = *opt;
 }
 
+namespace { void release_query_tree(); }
+
 void RayThreadReset(void) {
+    release_query_tree();
     BossState &b = boss();
     if (b.in_flight && !b.ctxs.empty()) (void)gpu().render_poll(b.ctxs[0], 1, nullptr, nullptr);
     for (ctgpu_ctx *c : b.ctxs) gpu().destroy(c);
@@ -282,4 +287,85 @@ bool RayThread(environment_t *env, scene_t *scene) {
         b.rand_consumed += 2 * half * traced_per_band * (uint64_t)frame.num_threads * 32u;
     }
     return true;
+}
+
+// ---- the operator-level boundary: bvh.h:31-32
+namespace {
+
+// the tree of the bvh_state_t queried last, resident on the GPU (one context, re-uploaded when another tree is asked about)
+struct QueryTree {
+    ctgpu_ctx *ctx = nullptr;
+    const bvh_node_t *nodes = nullptr;
+    const triangle_t *triangles = nullptr;
+    uint32_t nodes_used = 0, size = 0;
+};
+
+QueryTree &query_tree() {
+    static QueryTree q;
+    return q;
+}
+
+void release_query_tree() {
+    QueryTree &q = query_tree();
+    if (q.ctx) gpu().destroy(q.ctx);
+    q = QueryTree();
+}
+
+ctgpu_ctx *resident(bvh_state_t *state) {
+    QueryTree &q = query_tree();
+    GpuApi &api = gpu();
+    if (q.ctx && q.nodes == state->bvhNodes && q.triangles == state->triangles.data && q.nodes_used == state->nodesUsed &&
+        q.size == state->triangles.size)
+        return q.ctx;
+    if (!q.ctx && api.create(boss().options.device, &q.ctx) != CTGPU_OK) die("ctgpu_create", api.last_error());
+    const uint32_t n = state->triangles.size;
+    std::vector<double> vertices((size_t)n * 9);
+    for (uint32_t i = 0; i < n; i++) {
+        const triangle_t &t = state->triangles.data[i];
+        const double v[9] = {t.p1.x, t.p1.y, t.p1.z, t.p2.x, t.p2.y, t.p2.z, t.p3.x, t.p3.y, t.p3.z};
+        std::memcpy(&vertices[(size_t)i * 9], v, sizeof v);
+    }
+    std::vector<ctgpu_material> materials(n, ctgpu_material{0x00ffffffu, -1, 0.0f});
+    ctgpu_scene_desc d;
+    std::memset(&d, 0, sizeof d);
+    d.n_triangles = n;
+    d.n_nodes = state->nodesUsed;
+    d.vertices = vertices.data();
+    d.materials = materials.data();
+    d.nodes = reinterpret_cast<const ctgpu_node *>(state->bvhNodes);
+    d.indexes = state->triangles.indexes;
+    if (api.upload_scene(q.ctx, &d) != CTGPU_OK) die("ctgpu_upload_scene", api.last_error());
+    q.nodes = state->bvhNodes; q.triangles = state->triangles.data; q.nodes_used = state->nodesUsed; q.size = n;
+    return q.ctx;
+}
+
+ctgpu_hit one_ray(ray_t *ray, uint32_t node_index, bvh_state_t *state) {
+    if (!ray || !state || !state->bvhNodes || state->triangles.size == 0) die("IntersectBVH", "null ray or empty tree");
+    if (node_index != state->rootNodeIdx || state->rootNodeIdx != 0)
+        die("IntersectBVH", "only whole-tree queries (nodeIdx = rootNodeIdx = 0) are supported by the GPU walk");
+    ctgpu_ray r;
+    std::memset(&r, 0, sizeof r);
+    r.origin[0] = ray->origin.x; r.origin[1] = ray->origin.y; r.origin[2] = ray->origin.z;
+    r.direction[0] = ray->direction.x; r.direction[1] = ray->direction.y; r.direction[2] = ray->direction.z;
+    r.t = ray->t;
+    ctgpu_hit h;
+    if (gpu().trace_rays_packet(resident(state), &r, 1, 0u, &h) != CTGPU_OK) die("ctgpu_trace_rays_packet", gpu().last_error());
+    return h;
+}
+
+}  // namespace
+
+void IntersectBVH(ray_t *ray, uint32_t nodeIdx, bvh_state_t *bvhState) {
+    ray->t = one_ray(ray, nodeIdx, bvhState).t;                  // every IntersectTriangle's effect on ray.t (bvh.cpp:181-196)
+}
+
+void IntersectBVHClosest(ray_t *ray, uint32_t nodeIdx, bvh_state_t *bvhState, float *tclosest, uint32_t *closestIndex) {
+    if (!tclosest || !closestIndex) die("IntersectBVHClosest", "null output");
+    if (*tclosest != 4294967296.0f) die("IntersectBVHClosest", "*tclosest must be 4294967296.f on entry, as ClosestIntersection sets it");
+    const ctgpu_hit h = one_ray(ray, nodeIdx, bvhState);
+    ray->t = h.t;
+    if (h.tclosest != 4294967296.0f) {                           // a triangle was recorded (bvh.cpp:212-215)
+        *tclosest = h.tclosest;
+        *closestIndex = h.triangle;
+    }
 }

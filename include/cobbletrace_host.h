@@ -15,6 +15,7 @@
  *   ImportObject        objectLoader.h:4   (impl objectLoader.cpp:282-288)
  *   InitializeBVHState  bvh.h:29           (impl bvh.cpp:16-28)
  *   BuildBVH            bvh.h:30           (impl bvh.cpp:108-121)
+ *   IntersectBVH / IntersectBVHClosest   bvh.h:31-32   (impl bvh.cpp:181-222)
  *   scene_t & friends   scenefile.h:13-108, mymath.h:19-43
  *   environment_t       environment.h:7-20, eventQueue.h:9-42
  *   bvh_node_t ...      bvh.h:5-25
@@ -139,6 +140,14 @@ void ParseSceneFile(char *filename, scene_t *scene);
 void ImportObject(scene_object_t importObject, scene_t *scene);
 bvh_state_t InitializeBVHState(triangle_t *triangles, int size);
 void BuildBVH(bvh_state_t *bvhState);
+/* The operator-level boundary (bvh.h:31-32, impl bvh.cpp:181-222): one ray against a tree made by BuildBVH.  Here a
+ * thin host wrapper that sends the ray through the HIP library (the tree is uploaded once per bvh_state_t and kept;
+ * the walk is the frame kernel's, ctgpu_trace_rays_packet) -- there is no CPU walk in this build, so without the
+ * library or a GPU these exit(2) like RayThread.  Supported as the reference calls them: nodeIdx = the tree's root,
+ * *tclosest = 4294967296.f on entry (raythread.cpp:204-213); anything else is a fatal error, not a wrong answer.
+ * A call costs a kernel launch: they are for known-answer tests and tools, frames go through RayThread. */
+void IntersectBVH(ray_t *ray, uint32_t nodeIdx, bvh_state_t *bvhState);
+void IntersectBVHClosest(ray_t *ray, uint32_t nodeIdx, bvh_state_t *bvhState, float *tclosest, uint32_t *closestIndex);
 event_t *ReadEvent(eventManager_t *em);                 /* eventQueue.cpp:14-24 */
 void AddEvent(eventManager_t *em, event_t event);       /* eventQueue.cpp:5-12  */
 

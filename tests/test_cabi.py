@@ -102,7 +102,8 @@ def test_host_library_exports_the_reference_boundary():
     header = open(os.path.join(ROOT, "include", "cobbletrace_host.h")).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
     declared = set(re.findall(r"^(?:bool|void|uint64_t|bvh_state_t|event_t \*)\s*\*?([A-Z][A-Za-z]+)\(", header, flags=re.M))
-    assert {"RayThread", "InitSceneData", "ParseSceneFile", "ImportObject", "InitializeBVHState", "BuildBVH", "ReadEvent",
+    assert {"RayThread", "InitSceneData", "ParseSceneFile", "ImportObject", "InitializeBVHState", "BuildBVH", "IntersectBVH",
+            "IntersectBVHClosest", "ReadEvent",
             "AddEvent", "Blit", "RayThreadSetOptions", "RayThreadReset", "RayThreadBusy"} <= declared
     out = subprocess.run(["nm", "-D", "--defined-only", "--demangle", bindings.host_library_path()], capture_output=True,
                          text=True, check=True).stdout
@@ -110,5 +111,6 @@ def test_host_library_exports_the_reference_boundary():
     assert declared <= exported, sorted(declared - exported)
     # the signatures the reference calls with
     for signature in ("RayThread(environment_t*, scene_t*)", "ParseSceneFile(char*, scene_t*)", "Blit(environment_t*)",
-                      "AddEvent(eventManager_t*, event_t)", "BuildBVH(bvh_state_t*)"):
+                      "AddEvent(eventManager_t*, event_t)", "BuildBVH(bvh_state_t*)", "IntersectBVH(ray_t*, unsigned int, bvh_state_t*)",
+                      "IntersectBVHClosest(ray_t*, unsigned int, bvh_state_t*, float*, unsigned int*)"):
         assert signature in out, signature

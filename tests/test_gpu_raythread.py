@@ -208,3 +208,29 @@ def test_host_layer_builds_its_tree_on_the_device(assets, monkeypatch):
     device_built = ca.HostScene(path)
     got = (device_built.lib.cth_node_hash(device_built.handle), device_built.lib.cth_index_hash(device_built.handle), device_built.desc.n_nodes)
     assert got == want
+
+
+def test_operator_level_boundary(scenes):
+    """bvh.h:31-32 as exports of the host library: IntersectBVHClosest / IntersectBVH with the reference's signatures,
+    one ray per call through the GPU walk, against the oracle's ClosestIntersection on the same rays (exact t,
+    tclosest and index; the any-hit flavour only reports ray.t)."""
+    from oracle import oracle
+    scene = scenes("bunny")
+    rng = np.random.default_rng(4)
+    v = scene.vertices().reshape(-1, 3)
+    lo, hi = v.min(0), v.max(0)
+    rays = np.zeros(300, dtype=ca.bindings.RAY_DTYPE)
+    rays["origin"] = (lo + hi) / 2 + rng.normal(size=(300, 3)) * (hi - lo).max() * 1.5
+    rays["direction"] = lo + rng.random((300, 3)) * (hi - lo) - rays["origin"]
+    rays["t"] = np.float32(1e30)
+    want = oracle.trace_rays(scene.desc, rays)
+    got = np.zeros(300, dtype=ca.bindings.HIT_DTYPE)
+    assert scene.lib.cth_intersect_bvh(scene.handle, rays.ctypes.data, 300, 1, got.ctypes.data) == 0
+    assert want["found"].sum() > 30
+    for field in ("t", "tclosest"):
+        assert (got[field].view(np.uint32) == want[field].view(np.uint32)).all(), field
+    assert (got["triangle"] == want["triangle"]).all() and (got["found"] == want["found"]).all()
+    any_hit = np.zeros(300, dtype=ca.bindings.HIT_DTYPE)
+    assert scene.lib.cth_intersect_bvh(scene.handle, rays.ctypes.data, 300, 0, any_hit.ctypes.data) == 0
+    assert (any_hit["t"].view(np.uint32) == want["t"].view(np.uint32)).all()
+    ca.host_library().cth_raythread_reset()
