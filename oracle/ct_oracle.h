@@ -10,12 +10,20 @@
  * the reference lines it follows.  It deliberately keeps the reference's shape
  * (recursive traversal, one OS thread per row band) and none of the GPU design.
  *
- * PARITY PIN -- "parity unpinned" beyond the header slice.  The reference's renderer
- * cannot be compiled in this image under the task's rules: every translation unit
- * includes SDL.h (SDL2 is not installed; writing a stand-in header is not allowed) and
- * raythread.cpp:119 is a hard error on g++ 11.  So no oracle/_ref build of the renderer
- * exists, and the reference holds no tests, fixtures or golden vectors of its own.
- * What pins this oracle:
+ * PARITY PIN.  The reference's renderer cannot be compiled in this image under the task's rules: every translation
+ * unit includes SDL.h (SDL2 is not installed; writing a stand-in header is not allowed) and raythread.cpp:119 is a
+ * hard error on g++ 11.  So no oracle/_ref build of the renderer exists, and the reference holds no tests.  What it
+ * does hold are PICTURES of itself at work, and they pin this oracle at whole-frame level:
+ *   (0) tests/golden/reference_objectLoading2.png (README.md:24: scene_import.json in the reference's own 640x640
+ *       window, scene-file settings) and tests/golden/reference_screenshot2.png (README.md:23: utils/pc_big.json --
+ *       6,468 inline triangles under 66 lights), byte copies of the reference's files.  Everything on the path is
+ *       deterministic except the supersampling jitter (rand() drawn by racing workers), so
+ *       tests/test_reference_picture.py demands: the same written-pixel mask; every pixel whose neighbourhood in the
+ *       picture is one colour bit-equal (262,395 + 234,181 pixels, 34,583 + 15,116 of them on the objects); every
+ *       pixel on a plain colour ramp within 1 LSB; >= 98.5 % / 94 % of all pixels bit-equal (measured 99.05 % /
+ *       94.9 %: the rest sits on silhouette edges); and the pictures inside the envelope of this oracle's frames over
+ *       jitter seeds, with a remainder that halves as seeds double.  That pins parser, loader, placement, BVH,
+ *       traversal, lighting over many lights, pow, HSV and the 16-sample blend at once.
  *   (1) the parts of the reference that DO compile from their own files -- mymath.h,
  *       color.h (and eventQueue.cpp, against the host layer's event ring) -- built in place by oracle/Makefile into oracle/_ref/ and compared
  *       function by function (tests/test_oracle_vs_ref_headers.py), 5,500 of those
@@ -27,8 +35,7 @@
  *       67,022,780 IntersectAABB / 5,535,094 IntersectTriangle calls of one bunny frame.
  * The survey's FNV-1a-64 hashes of whole reference framebuffers are listed in
  * reference_kat.json as "hashes_unverified" and are NOT asserted: they could not be
- * reproduced with the hash the survey describes.  Traversal and lighting are therefore
- * pinned by counts and single pixels, not by a whole-frame golden of the reference.
+ * reproduced with the hash the survey describes.
  *
  * Descriptors are shared with include/ctgpu.h so that a test feeds the very same
  * bytes to the oracle and to the HIP library.
