@@ -43,7 +43,7 @@ B_NODE, B_TRI, B_HIT, B_PIXEL = 64, 76, 84, 4
 # the kernels' own records (ct_device.h): QuadNode 128 B, TriRecord 80 B
 B_QUAD, B_RECORD = 128, 80
 KERNELS = ("ct_sample_grid", "ct_walk_packet<primary>", "ct_light_gate", "ct_walk_packet<shadow>", "ct_shade")
-KERNEL_SOURCES = ("ct_pipeline.hip", "ct_device.h", "ct_params.h", "ct_raygen.h")      # the device code of the fast path
+KERNEL_SOURCES = ("ct_pipeline.hip", "ct_device.h", "ct_params.h", "ct_raygen.h", "ct_spheres.h")      # the device code of the fast path
 
 
 def parse_args(argv=None):
