@@ -14,10 +14,11 @@ namespace ctd {
 // tests, 5..14 diagnostic builds, 15 rays the packet walk walked again unfolded, 16 shadow rays not needed,
 // 17 / 18 primary / shadow rays the packet walk handed over to the per-lane walk
 constexpr int kCounterWords = 24;
-// ray-queue head words: walk 0 primary rays, walks 1..32 the shadow rays of up to 32 lights, walks 33 / 34 the
-// handed-over primary / shadow rays; 8 shards each, one 128-byte line per head word
-constexpr int kQueueWalks = 35;
-constexpr int kQueueWords = kQueueWalks * 8 * 16;
+// ray-queue head words: walk 0 primary rays, walks 1..L the shadow rays of the scene's L shadow-casting lights, walks
+// L+1 / L+2 the handed-over primary / shadow rays; 8 shards each, one 128-byte line per head word; then 32 words
+// for the two hand-over counters (everything cleared together, per frame)
+__host__ __device__ constexpr uint32_t queue_walks(uint32_t n_shadow_lights) { return n_shadow_lights + 3u; }
+__host__ __device__ constexpr size_t queue_words(uint32_t n_shadow_lights) { return (size_t)queue_walks(n_shadow_lights) * 8u * 16u; }
 constexpr int kCounterElided = 16;
 
 struct FrameParams {
@@ -79,7 +80,7 @@ struct PipelineParams {
     float2   *coords;            // [n_samples] jittered canvas position (supersampled frames)
     uint2    *hits;              // [n_samples] {ray.t bits, closest TriRecord slot | kNoNode | invalid}
     uint8_t  *shadow;            // [n_shadow_lights][n_samples] 1 = that light is blocked
-    unsigned long long *queue;   // [kQueueWalks][8 shards][16] head words (128-byte stride) of the ray queues
+    unsigned long long *queue;   // [queue_walks(n_shadow_lights)][8 shards][16] head words (128-byte stride) of the ray queues
     void     *spill;             // [walk_blocks][spill_depth][64] stack entries beyond the LDS part
     const uint32_t *shadow_lights;   // [n_shadow_lights] index into lights[]
     uint64_t n_samples;

@@ -436,7 +436,7 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk(const FrameParam
     // per light -- each with its own head word on its own 128-byte line (one head saturates near 90
     // dequeues/us chip-wide); a wave starts on the shard of its workgroup id (workgroups b and b+8
     // share an XCD under round-robin placement: speed only) and moves to the next when one runs dry.
-    // (LISTED: "samples" below are list positions, one run of kShards shards; the queue's head words are walk 33 / 34's, ct_params.h)
+    // (LISTED: "samples" below are list positions, one run of kShards shards; the queue's head words are the last two walks', ct_params.h)
     uint64_t listed = 0;
     if (LISTED) {
         listed = W.handed[KIND == 0 ? 0 : 16];
@@ -446,7 +446,7 @@ __global__ __launch_bounds__(kWave, CT_WALK_WAVES) void ct_walk(const FrameParam
     const unsigned long long *listed_ids = W.handed_ids[KIND == 0 ? 0 : 1];
     const uint64_t n_samples = LISTED ? listed : W.n_samples;
     const uint32_t n_shards = (KIND == 0 || LISTED) ? kShards : kShards * W.n_shadow_lights;
-    unsigned long long *heads = W.queue + (size_t)(LISTED ? (KIND == 0 ? 33u : 34u) * kShards : (KIND == 0 ? 0u : kShards)) * 16u;
+    unsigned long long *heads = W.queue + (size_t)(LISTED ? (W.n_shadow_lights + (KIND == 0 ? 1u : 2u)) * kShards : (KIND == 0 ? 0u : kShards)) * 16u;
     const uint64_t shard_span = ((n_samples + kShards - 1) / kShards + q_chunk - 1) / q_chunk * q_chunk;
     uint32_t shard = blockIdx.x % n_shards, shards_done = 0;
     uint64_t light_base = 0;                 // first ray id of the light the current chunk belongs to
@@ -1264,7 +1264,9 @@ struct ShadedPoint {
     d3 position, normal, view;
     Material material;
 };
-template <bool SS>
+// SPHERES: the frame draws spheres (CTGPU_F_SPHERES), so a hit may be one -- a template parameter because the sphere
+// branch (a binary64 square root) cost ct_light_gate a third of its time in frames that have none
+template <bool SS, bool SPHERES>
 __device__ __forceinline__ ShadedPoint shaded_point(const FrameParams &P, const PipelineParams &W, uint64_t id, uint2 h,
                                                     uint32_t xi, uint32_t yi) {
     const d3 eye = make_d3(P.cam[0], P.cam[1], P.cam[2]);
@@ -1276,7 +1278,7 @@ __device__ __forceinline__ ShadedPoint shaded_point(const FrameParams &P, const 
     ShadedPoint s;
     s.position = eye + scale((double)tclosest, dir);
     s.view = -dir;
-    if (is_sphere_hit(h.y)) {
+    if (SPHERES && is_sphere_hit(h.y)) {
         // NormalOfSceneObject, OT_SPHERE (raythread.cpp:331-334): n / Magnitude(n) = (1.0f / (D)F|n|) * n
         const ctgpu_sphere &sphere = P.spheres[h.y & ~kSphereTag];
         s.material.color = sphere.material.color; s.material.specular = sphere.material.specular; s.material.reflection = sphere.material.reflection;
@@ -1305,11 +1307,11 @@ __device__ __forceinline__ float specular_reach(const ShadedPoint &s, const d3 &
 }
 
 // colour of one sample from its closest hit and its shadow flags
-template <bool SS>
+template <bool SS, bool SPHERES>
 __device__ __forceinline__ uint32_t shade_sample(const FrameParams &P, const PipelineParams &W, uint64_t id, uint32_t xi, uint32_t yi) {
     const uint2 h = W.hits[id];
     if (__uint_as_float(h.x) == kNoHit) return kBackground;
-    const ShadedPoint s = shaded_point<SS>(P, W, id, h, xi, yi);
+    const ShadedPoint s = shaded_point<SS, SPHERES>(P, W, id, h, xi, yi);
 
     float intensity = 0.0f;
     uint32_t shadow_slot = 0;
@@ -1385,7 +1387,7 @@ __global__ __launch_bounds__(256) void ct_sphere_pass(const FrameParams P, const
 // light that cannot contribute -- the same float comparisons ct_shade makes afterwards, on the same
 // operands).  The shadow walk writes 1 where a light is blocked; ct_shade skips a light on 1 and 2.
 // ------------------------------------------------------------------------------------
-template <bool SS>
+template <bool SS, bool SPHERES>
 __global__ __launch_bounds__(256) void ct_light_gate(const FrameParams P, const PipelineParams W) {
     // (a fixed grid that strides over the samples, one counter atomic per block at the end: one atomic
     // per wave on a single word would take longer than the whole kernel, ~11 ns each)
@@ -1399,7 +1401,7 @@ __global__ __launch_bounds__(256) void ct_light_gate(const FrameParams P, const 
             const PixelOfSample px = pixel_of<SS>(P, id);
             uint32_t yi = 0;
             (void)pixel_in_frame(P, px.xi, px.local_row, yi);
-            s = shaded_point<SS>(P, W, id, h, px.xi, yi);
+            s = shaded_point<SS, SPHERES>(P, W, id, h, px.xi, yi);
         }
         for (uint32_t k = 0; k < W.n_shadow_lights; k++) {
             uint8_t verdict = 2;
@@ -1427,7 +1429,7 @@ __global__ __launch_bounds__(256) void ct_light_gate(const FrameParams P, const 
     }
 }
 
-template <bool SS>
+template <bool SS, bool SPHERES>
 __global__ __launch_bounds__(256) void ct_shade(const FrameParams P, const PipelineParams W) {
     if (!SS) {
         const uint64_t id = (uint64_t)blockIdx.x * 256u + threadIdx.x;
@@ -1435,7 +1437,7 @@ __global__ __launch_bounds__(256) void ct_shade(const FrameParams P, const Pipel
         const PixelOfSample px = pixel_of<false>(P, id);
         uint32_t yi;
         if (!pixel_in_frame(P, px.xi, px.local_row, yi)) return;
-        P.out[(size_t)px.local_row * P.square + px.xi] = shade_sample<false>(P, W, id, px.xi, yi);
+        P.out[(size_t)px.local_row * P.square + px.xi] = shade_sample<false, SPHERES>(P, W, id, px.xi, yi);
         return;
     }
     // Supersampled: first one lane per SAMPLE (consecutive lanes read consecutive hit / position /
@@ -1450,7 +1452,7 @@ __global__ __launch_bounds__(256) void ct_shade(const FrameParams P, const Pipel
         if (id < W.n_samples) {
             const PixelOfSample px = pixel_of<true>(P, id);
             uint32_t yi;
-            if (pixel_in_frame(P, px.xi, px.local_row, yi)) c = shade_sample<true>(P, W, id, px.xi, yi);
+            if (pixel_in_frame(P, px.xi, px.local_row, yi)) c = shade_sample<true, SPHERES>(P, W, id, px.xi, yi);
         }
         colour[(local >> 4) * 17u + (local & 15u)] = c;
     }
@@ -1503,6 +1505,13 @@ void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hip
     const uint32_t sample_blocks = (uint32_t)std::min<uint64_t>((W.n_samples + 255u) / 256u, 2048u);      // ct_light_gate strides
     const bool shadows = W.n_shadow_lights != 0;
     // the spheres' own passes (CTGPU_F_SPHERES frames of scenes that have any): their time goes to the walk before them
+    const bool sph = P.n_spheres != 0;
+    auto light_gate = [&]() {
+        if (ss && !sph) hipLaunchKernelGGL((ct_light_gate<true, false>), dim3(sample_blocks), dim3(256), 0, stream, P, W);
+        if (!ss && !sph) hipLaunchKernelGGL((ct_light_gate<false, false>), dim3(sample_blocks), dim3(256), 0, stream, P, W);
+        if (ss && sph) hipLaunchKernelGGL((ct_light_gate<true, true>), dim3(sample_blocks), dim3(256), 0, stream, P, W);
+        if (!ss && sph) hipLaunchKernelGGL((ct_light_gate<false, true>), dim3(sample_blocks), dim3(256), 0, stream, P, W);
+    };
     auto sphere_pass = [&](int kind) {
         if (!P.n_spheres) return;
         if (kind == 0 && ss) hipLaunchKernelGGL((ct_sphere_pass<true, 0>), dim3(sample_blocks), dim3(256), 0, stream, P, W);
@@ -1531,8 +1540,7 @@ void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hip
         if (handover && !ss) hipLaunchKernelGGL((ct_walk<0, false, true>), grid_l, wave, lds_l, stream, P, W);
         sphere_pass(0);
         mark(2);
-        if (shadows && ss) hipLaunchKernelGGL((ct_light_gate<true>), dim3(sample_blocks), dim3(256), 0, stream, P, W);
-        if (shadows && !ss) hipLaunchKernelGGL((ct_light_gate<false>), dim3(sample_blocks), dim3(256), 0, stream, P, W);
+        if (shadows) light_gate();
         mark(3);
         if (shadows && ss && !handover) hipLaunchKernelGGL((ct_walk_packet<1, true>), grid, wave, lds_p, stream, P, W);
         if (shadows && !ss && !handover) hipLaunchKernelGGL((ct_walk_packet<1, false>), grid, wave, lds_p, stream, P, W);
@@ -1546,16 +1554,17 @@ void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hip
         else hipLaunchKernelGGL((ct_walk<0, false>), grid, wave, lds, stream, P, W);
         sphere_pass(0);
         mark(2);
-        if (shadows && ss) hipLaunchKernelGGL((ct_light_gate<true>), dim3(sample_blocks), dim3(256), 0, stream, P, W);
-        if (shadows && !ss) hipLaunchKernelGGL((ct_light_gate<false>), dim3(sample_blocks), dim3(256), 0, stream, P, W);
+        if (shadows) light_gate();
         mark(3);
         if (shadows && ss) hipLaunchKernelGGL((ct_walk<1, true>), grid, wave, lds, stream, P, W);
         if (shadows && !ss) hipLaunchKernelGGL((ct_walk<1, false>), grid, wave, lds, stream, P, W);
     }
     if (shadows) sphere_pass(1);
     mark(4);
-    if (ss) hipLaunchKernelGGL((ct_shade<true>), dim3(pixel_blocks), dim3(256), 0, stream, P, W);
-    else hipLaunchKernelGGL((ct_shade<false>), dim3(pixel_blocks), dim3(256), 0, stream, P, W);
+    if (ss && !sph) hipLaunchKernelGGL((ct_shade<true, false>), dim3(pixel_blocks), dim3(256), 0, stream, P, W);
+    if (!ss && !sph) hipLaunchKernelGGL((ct_shade<false, false>), dim3(pixel_blocks), dim3(256), 0, stream, P, W);
+    if (ss && sph) hipLaunchKernelGGL((ct_shade<true, true>), dim3(pixel_blocks), dim3(256), 0, stream, P, W);
+    if (!ss && sph) hipLaunchKernelGGL((ct_shade<false, true>), dim3(pixel_blocks), dim3(256), 0, stream, P, W);
     mark(5);
 }
 

@@ -268,7 +268,7 @@ static int create_resources(ctgpu_ctx *ctx) {
     if (const char *t = std::getenv("CTGPU_FORCE_MEGAKERNEL")) ctx->force_megakernel = std::atoi(t) != 0;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->cu_count = prop.multiProcessorCount;
-    HIP_TRY(ctx->queue.resize(kQueueWords + 32));           // + the two hand-over counters (cleared with the queue, per frame)
+    HIP_TRY(ctx->queue.resize(queue_words(32) + 32));        // (grows with the scene's light count, fill_pipeline)
     HIP_TRY(ctx->walk_work.resize(64 * 8));
     HIP_TRY(hipMemset(ctx->walk_work.ptr, 0, 64 * 8 * sizeof(unsigned long long)));
     return CTGPU_OK;
@@ -879,15 +879,15 @@ int read_counters(ctgpu_ctx *ctx, ctgpu_stats *st) {
 // ------------------------------------------------------------------ one partition's trace
 namespace {
 
-// The wavefront pipeline covers what the shipped import scenes need; reflective materials and
-// more than 32 shadow-casting lights take the megakernel.
+// The wavefront pipeline covers every frame without reflection bounces (any number of lights, spheres included);
+// reflective materials take the general path, one kernel that follows TraceRay's recursion.
 bool pipeline_eligible(const ctgpu_ctx *ctx, const ctgpu_frame_desc *f) {
     if (ctx->force_megakernel) return false;
     const bool spheres = (f->flags & CTGPU_F_SPHERES) && ctx->scene->n_spheres;
     // reflective materials bounce (TraceRay's recursion): the general path.  A sphere's material counts only in frames
     // that draw spheres.
     if (f->max_depth > 0 && (ctx->scene->triangles_reflect || (spheres && ctx->scene->spheres_reflect))) return false;
-    return ctx->scene->n_shadow_lights <= 32;
+    return true;          // (any number of lights: the shadow walk's queue has a head-word set per light)
 }
 
 int fill_pipeline(ctgpu_ctx *ctx, uint64_t n_samples, PipelineParams &W, int kind = -1);
@@ -910,7 +910,7 @@ int launch_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, FrameParams &P, hipS
     HIP_TRY(ctx->shadow.resize(W.n_samples * std::max<uint32_t>(W.n_shadow_lights, 1)));
     W.coords = ctx->coords.ptr; W.hits = ctx->hits.ptr; W.shadow = ctx->shadow.ptr;
     if (begin) HIP_TRY(hipEventRecord(begin, stream));
-    HIP_TRY(hipMemsetAsync(ctx->queue.ptr, 0, (kQueueWords + 32) * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(ctx->queue.ptr, 0, (queue_words(W.n_shadow_lights) + 32) * sizeof(unsigned long long), stream));
     hipEvent_t *marks = nullptr;
     if (ctx->kernel_timing) {
         const size_t need = ctx->marks_used + kPipelineKernels + 1;
@@ -973,7 +973,9 @@ int fill_pipeline(ctgpu_ctx *ctx, uint64_t n_samples, PipelineParams &W, int kin
     // hand-over lists: room for half of the frame's primary rays and half of its possible shadow rays
     W.packet_budget = W.packet ? (uint32_t)ctx->packet_budget : 0u;
     W.packet_lanes = (uint32_t)ctx->packet_lanes;
-    W.handed = ctx->queue.ptr + kQueueWords;
+    HIP_TRY(ctx->queue.resize(queue_words(W.n_shadow_lights) + 32));
+    W.queue = ctx->queue.ptr;
+    W.handed = ctx->queue.ptr + queue_words(W.n_shadow_lights);
     W.handed_room = 0;
     if (W.packet_budget) {
         W.handed_room = std::max<uint64_t>(n_samples / 2u, 4096u);
@@ -1403,7 +1405,7 @@ extern "C" int ctgpu_trace_rays_packet(ctgpu_ctx *ctx, const ctgpu_ray *rays, ui
     hipError_t e = hipMalloc((void **)&d_hits, n * sizeof(ctgpu_hit));
     if (e != hipSuccess) { (void)hipFree(d_rays); return ctgpu_fail(CTGPU_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
     e = hipMemcpy(d_rays, rays, n * sizeof(ctgpu_ray), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemsetAsync(ctx->queue.ptr, 0, (kQueueWords + 32) * sizeof(unsigned long long), ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(ctx->queue.ptr, 0, (queue_words(W.n_shadow_lights) + 32) * sizeof(unsigned long long), ctx->stream);
     if (e == hipSuccess) {
         W.ray_list = d_rays;
         W.ray_hits = d_hits;
