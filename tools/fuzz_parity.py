@@ -37,7 +37,7 @@ while time.time() < t_end:
                          "radius": float("%.4g" % (scale * rng.choice([0.05, 0.4, 1.5]))), "color": [int(v) for v in rng.integers(0, 256, 3)],
                          "specular": int(rng.choice([-1, 10, 500])), "reflection": float(rng.choice([0, 0.4]))})
     lights = [{"type": "ambient", "intensity": float("%.3g" % rng.uniform(0, 0.5))}]
-    for _ in range(int(rng.integers(0, 4))):
+    for _ in range(int(rng.choice([0, 1, 2, 3, 3, 36]))):         # (36: beyond the 32 lights the fast path once stopped at)
         if rng.random() < 0.5:
             lights.append({"type": "point", "intensity": float("%.3g" % rng.uniform(0, 0.8)),
                            "position": [float("%.6g" % v) for v in rng.normal(size=3) * scale * 2]})
@@ -54,7 +54,7 @@ while time.time() < t_end:
                             "supersampling": bool(rng.random() < 0.5)}}, open(path, "w"))
     scene = ca.HostScene(path)
     ctx = ca.GpuContext(0)
-    ctx.upload(scene.desc)
+    ctx.upload(scene.desc, build_on_device=bool(seed % 2))     # every other scene: tree built and laid out on the GPU
     angles = [np.float32(a) for a in rng.uniform(-0.6, 0.6, 3)] if rng.random() < 0.5 else [np.float32(0)] * 3
     w, h = int(rng.choice([64, 97, 160])), int(rng.choice([48, 64, 121]))
     frame = scene.frame(w, h, rotation=oracle.camera_rotation(*angles), rng_seed=seed, spheres=use_spheres,
