@@ -150,6 +150,7 @@ _GPU_SYMBOLS = {
     "ctgpu_build_bvh": (C.c_int, [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]),
     "ctgpu_read_walk_work": (C.c_int, [C.c_void_p, C.POINTER(WalkWork)]),
     "ctgpu_walk_choice": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "ctgpu_bounce_choice": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ctgpu_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "ctgpu_read_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(KernelTimes)]),
     "ctgpu_read_phase_times": (C.c_int, [C.c_void_p, C.POINTER(PhaseTimes)]),
@@ -447,6 +448,12 @@ class GpuContext:
         lane, a, b = C.c_int(0), C.c_double(0), C.c_double(0)
         self._check(self.lib.ctgpu_walk_choice(self.handle, 1 if supersampled else 0, C.byref(lane), C.byref(a), C.byref(b)))
         return bool(lane.value), a.value, b.value
+
+    def bounce_choice(self, supersampled):
+        """(general path chosen?, last kernel ms on the bounce pipeline, on the general path) for reflective frames of a kind."""
+        general, a, b = C.c_int(0), C.c_double(0), C.c_double(0)
+        self._check(self.lib.ctgpu_bounce_choice(self.handle, 1 if supersampled else 0, C.byref(general), C.byref(a), C.byref(b)))
+        return bool(general.value), a.value, b.value
 
     def read_phase_times(self):
         t = PhaseTimes()

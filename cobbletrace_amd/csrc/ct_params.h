@@ -106,13 +106,39 @@ struct PipelineParams {
     uint64_t handed_room;        // ids each list can hold (a full list: the packet simply walks on)
     const ctgpu_ray *ray_list;   // ctgpu_trace_rays_packet: the caller's rays (n_samples of them) ...
     ctgpu_hit *ray_hits;         // ... and where their results go
+    // ray lists the frame makes for itself (reflection bounces, ct_pipeline.hip "bounce levels"):
+    const uint8_t *ray_live;     // which list entries are rays at all (NULL: every one)
+    uint32_t list_slots;         // 1: ray_hits[].triangle receives the TriRecord SLOT (kNoNode: none recorded), not the scene triangle
+    uint32_t list_counter;       // frame counter word the walk adds its ray count to (0: none; 1 shadow rays, 2 reflected rays)
+    const uint32_t *list_gate;   // when set and *list_gate == 0 the list holds no ray: the walk's waves leave at once
+};
+
+// Reflection bounces on the wavefront pipeline: level 0 is the camera ray's hit, level k the k-th reflected ray's
+// (TraceRay's recursion, raythread.cpp:353-386, unrolled into passes over the frame's samples).  All arrays are
+// indexed by sample id; `shadow_*` by light * n_samples + sample id like PipelineParams::shadow.
+struct BounceParams {
+    ctgpu_ray *rays;             // the current level's reflected ray of every sample that has one
+    uint8_t   *live;             // ... which samples those are
+    ctgpu_hit *hits;             // ... and what the closest-hit walk found (triangle = TriRecord slot | sphere tag | kNoNode)
+    ctgpu_ray *shadow_rays;      // the current level's shadow rays,
+    uint8_t   *shadow_live;      // which of them exist (the light can contribute at that point),
+    ctgpu_hit *shadow_hits;      // and whether something blocks them (found)
+    uint32_t  *local;            // [level][sample] colour computed at a level that went on reflecting ...
+    float     *refl;             // ... and its material's reflection: mixed with the deeper result on the way back
+    uint32_t  *terminal;         // [sample] colour of the deepest call (its local colour, or the background)
+    uint8_t   *pending;          // [sample] levels whose mix is still owed (0 .. max_depth)
+    uint32_t  *level_live;       // [max_depth + 2] samples with a reflected ray entering each level: an empty level's passes leave at once
+    uint32_t  level;             // the level being processed (1 .. max_depth)
+    uint32_t  max_depth;         // TraceRay's recursionDepth at the camera ray (10)
+    float     bounce_t;          // ray.t a reflected ray starts with: 0 (raythread.cpp:373) or 1e30f (CTGPU_F_REFLECT_FIX)
 };
 
 uint64_t pipeline_sample_count(const FrameParams &P, bool ss);
 int  pipeline_walk_occupancy(size_t lds_bytes);
 int  pipeline_packet_occupancy(uint32_t depth, uint32_t lds_levels);
 constexpr int kPipelineKernels = 5;      // ct_sample_grid, primary walk, ct_light_gate, shadow walk, ct_shade
-void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hipStream_t stream, hipEvent_t *marks);
+void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hipStream_t stream, hipEvent_t *marks,
+                     const BounceParams *bounce = nullptr);
 void launch_packet_ray_list(const FrameParams &P, const PipelineParams &W, bool any_hit, hipStream_t stream);
 
 void launch_trace_tiles(const FrameParams &P, uint32_t n_tiles, bool ss, bool reflect, bool count, hipStream_t stream);

@@ -743,6 +743,7 @@ template <int KIND, bool SS, bool HANDOVER = false>
 __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const FrameParams P, const PipelineParams W) {
     const uint32_t q_chunk = (KIND == 1) ? W.chunk_shadow : W.chunk;      // ray ids per queue atomic
     constexpr bool LIST = KIND >= 2;                 // rays come from W.ray_list instead of the frame's samples
+    if (LIST && W.list_gate && *W.list_gate == 0u) return;      // (a bounce level nobody reached)
     constexpr bool ANY_HIT = KIND == 1 || KIND == 3; // a ray leaves the walk at its first ray.t update
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const uint32_t depth = W.packet_depth;                      // most entries the folded tree leaves pending
@@ -848,6 +849,8 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                     if (!live) W.hits[id] = make_uint2(__float_as_uint(kNoHit), kInvalidSample);
                 } else if (KIND == 1) {
                     live = W.shadow[id] == 0;
+                } else if (W.ray_live) {
+                    live = W.ray_live[id] != 0;               // (the frame's own bounce lists: not every sample has a ray)
                 }
                 if (live) {
                     if (KIND != 0) ray_id = id;
@@ -922,7 +925,8 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
             const unsigned long long again = __ballot(redo);
             if (again == 0ull) break;
             if (lane == 0) atomicAdd(&P.counters[15], (unsigned long long)__popcll(again));    // diagnostic
-            if (redo) { t = kNoHit; slot = kNoNode; }
+            // (from the ray's own start value: a caller's / a bounce level's ray may start at 0, raythread.cpp:373)
+            if (redo) { t = (LIST && !ANY_HIT) ? W.ray_list[ray_id].t : kNoHit; slot = kNoNode; }
         }
         unsigned long long tracing = walk_pass == 0 ? __ballot(has_ray) : __ballot(redo);
         uint32_t cur = walk_pass == 0 ? P.quad_root : P.quad_root_flat;
@@ -1222,7 +1226,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                 ctgpu_hit h;
                 h.t = t;
                 h.tclosest = (slot != kNoNode) ? t : kFarAway;         // *tclosest == ray.t once a triangle is recorded
-                h.triangle = (slot != kNoNode) ? P.tris[slot].triangle : 0u;
+                h.triangle = W.list_slots ? slot : ((slot != kNoNode) ? P.tris[slot].triangle : 0u);
                 h.found = (t != kNoHit) ? 1u : 0u;
                 W.ray_hits[ray_id] = h;
             }
@@ -1238,6 +1242,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
         atomicAdd(&P.counters[14], __builtin_amdgcn_s_memtime() - pk_begin);
     }
 #endif
+    if (lane == 0 && LIST && W.list_counter && n_traced) atomicAdd(&P.counters[W.list_counter], (unsigned long long)n_traced);
     if (lane == 0 && !LIST) {
         atomicAdd(&P.counters[KIND == 0 ? 0 : 1], (unsigned long long)n_traced);
         // (64 slots on separate cache lines: atomics on one word would queue up at ~11 ns each)
@@ -1266,6 +1271,29 @@ struct ShadedPoint {
 };
 // SPHERES: the frame draws spheres (CTGPU_F_SPHERES), so a hit may be one -- a template parameter because the sphere
 // branch (a binary64 square root) cost ct_light_gate a third of its time in frames that have none
+// The point a ray (origin, dir) reaches at tclosest on the object `hit` names: a TriRecord slot, kNoNode (nothing was
+// recorded: scene triangle 0 at 2^32, the reference's closestIndex default) or a sphere tag.
+template <bool SPHERES>
+__device__ __forceinline__ ShadedPoint shaded_core(const FrameParams &P, const d3 &origin, const d3 &dir, float t_recorded, uint32_t hit) {
+    const float tclosest = (hit != kNoNode) ? t_recorded : kFarAway;
+    ShadedPoint s;
+    s.position = origin + scale((double)tclosest, dir);
+    s.view = -dir;
+    if (SPHERES && is_sphere_hit(hit)) {
+        // NormalOfSceneObject, OT_SPHERE (raythread.cpp:331-334): n / Magnitude(n) = (1.0f / (D)F|n|) * n
+        const ctgpu_sphere &sphere = P.spheres[hit & ~kSphereTag];
+        s.material.color = sphere.material.color; s.material.specular = sphere.material.specular; s.material.reflection = sphere.material.reflection;
+        const d3 n = s.position - load_d3(sphere.center);
+        s.normal = scale((double)1.0f / (double)lengthf(n), n);
+        return s;
+    }
+    const uint32_t rec_slot = (hit != kNoNode) ? hit : P.slot_of_triangle0;
+    const TriRecord *rec = P.tris + rec_slot;
+    s.material = P.materials[rec->triangle];
+    s.normal = cross(load_d3(rec->e1), load_d3(rec->e2));
+    if (!(dotf(s.normal, dir) < 0)) s.normal = -s.normal;
+    return s;
+}
 template <bool SS, bool SPHERES>
 __device__ __forceinline__ ShadedPoint shaded_point(const FrameParams &P, const PipelineParams &W, uint64_t id, uint2 h,
                                                     uint32_t xi, uint32_t yi) {
@@ -1273,25 +1301,7 @@ __device__ __forceinline__ ShadedPoint shaded_point(const FrameParams &P, const 
     float cx, cy;
     if (SS) { const float2 c = W.coords[id]; cx = c.x; cy = c.y; }
     else { cx = (float)((int)xi - P.half); cy = (float)((int)yi - P.half); }
-    const d3 dir = primary_direction(P, cx, cy);
-    const float tclosest = (h.y != kNoNode) ? __uint_as_float(h.x) : kFarAway;
-    ShadedPoint s;
-    s.position = eye + scale((double)tclosest, dir);
-    s.view = -dir;
-    if (SPHERES && is_sphere_hit(h.y)) {
-        // NormalOfSceneObject, OT_SPHERE (raythread.cpp:331-334): n / Magnitude(n) = (1.0f / (D)F|n|) * n
-        const ctgpu_sphere &sphere = P.spheres[h.y & ~kSphereTag];
-        s.material.color = sphere.material.color; s.material.specular = sphere.material.specular; s.material.reflection = sphere.material.reflection;
-        const d3 n = s.position - load_d3(sphere.center);
-        s.normal = scale((double)1.0f / (double)lengthf(n), n);
-        return s;
-    }
-    const uint32_t rec_slot = (h.y != kNoNode) ? h.y : P.slot_of_triangle0;
-    const TriRecord *rec = P.tris + rec_slot;
-    s.material = P.materials[rec->triangle];
-    s.normal = cross(load_d3(rec->e1), load_d3(rec->e2));
-    if (!(dotf(s.normal, dir) < 0)) s.normal = -s.normal;
-    return s;
+    return shaded_core<SPHERES>(P, eye, primary_direction(P, cx, cy), __uint_as_float(h.x), h.y);
 }
 // vector towards a non-ambient light (raythread.cpp:289-296)
 __device__ __forceinline__ d3 towards_light(const Light &L, const d3 &position) {
@@ -1306,13 +1316,10 @@ __device__ __forceinline__ float specular_reach(const ShadedPoint &s, const d3 &
     return dotf(reflected, s.view);
 }
 
-// colour of one sample from its closest hit and its shadow flags
-template <bool SS, bool SPHERES>
-__device__ __forceinline__ uint32_t shade_sample(const FrameParams &P, const PipelineParams &W, uint64_t id, uint32_t xi, uint32_t yi) {
-    const uint2 h = W.hits[id];
-    if (__uint_as_float(h.x) == kNoHit) return kBackground;
-    const ShadedPoint s = shaded_point<SS, SPHERES>(P, W, id, h, xi, yi);
-
+// ComputeLighting (raythread.cpp:275-327) at a shaded point, the shadow decisions read from `skip(k)` for the k-th
+// shadow-casting light (the ray found something, or the gate saw that the light adds nothing there)
+template <typename Skip>
+__device__ __forceinline__ float lighting(const FrameParams &P, const ShadedPoint &s, Skip skip) {
     float intensity = 0.0f;
     uint32_t shadow_slot = 0;
     for (uint32_t li = 0; li < P.n_lights; li++) {
@@ -1320,10 +1327,9 @@ __device__ __forceinline__ uint32_t shade_sample(const FrameParams &P, const Pip
         if (L.type == CTGPU_LIGHT_AMBIENT) { intensity += L.intensity; continue; }
         else if (L.type != CTGPU_LIGHT_POINT && L.type != CTGPU_LIGHT_DIRECTIONAL) continue;
         const d3 to_light = towards_light(L, s.position);
-        // 1: the shadow ray found something; 2: ct_light_gate saw that this light adds nothing here
-        const bool skip = W.shadow[(size_t)shadow_slot * W.n_samples + id] != 0;
+        const bool dark = skip(shadow_slot);
         shadow_slot += 1;
-        if (skip) continue;
+        if (dark) continue;
         const float n_dot_l = diffuse_reach(s, to_light);
         if (n_dot_l > 0) intensity += L.intensity * n_dot_l / (lengthf(s.normal) * lengthf(to_light));
         if (s.material.specular != -1) {
@@ -1335,6 +1341,17 @@ __device__ __forceinline__ uint32_t shade_sample(const FrameParams &P, const Pip
             }
         }
     }
+    return intensity;
+}
+
+// colour of one sample from its closest hit and its shadow flags
+template <bool SS, bool SPHERES>
+__device__ __forceinline__ uint32_t shade_sample(const FrameParams &P, const PipelineParams &W, uint64_t id, uint32_t xi, uint32_t yi) {
+    const uint2 h = W.hits[id];
+    if (__uint_as_float(h.x) == kNoHit) return kBackground;
+    const ShadedPoint s = shaded_point<SS, SPHERES>(P, W, id, h, xi, yi);
+    // 1: the shadow ray found something; 2: ct_light_gate saw that this light adds nothing here
+    const float intensity = lighting(P, s, [&](uint32_t k) { return W.shadow[(size_t)k * W.n_samples + id] != 0; });
     return shade_value(s.material.color, intensity);
 }
 
@@ -1468,6 +1485,211 @@ __global__ __launch_bounds__(256) void ct_shade(const FrameParams P, const Pipel
 }
 
 // ------------------------------------------------------------------------------------
+// Bounce levels: TraceRay's recursion (raythread.cpp:353-386) as passes over the frame's samples.
+//
+//   level 0   the camera ray: primary walk, gate, shadow walk as for any frame; then ct_bounce_first shades the
+//             sample (its LOCAL colour) and, where the material reflects and depth remains, parks that colour and the
+//             reflection factor and emits the reflected ray  {P, ReflectRay(-dir, N), t = 0}  (raythread.cpp:372-373)
+//   level k   the list walk (closest hit) over the reflected rays; ct_bounce_gate emits the shadow rays of the points
+//             they reach; the list walk (any hit) over those; ct_bounce_shade = the same decision one level down
+//   the end   ct_bounce_finish folds the parked colours back, innermost first (raythread.cpp:375-379), and blends the
+//             pixel's samples.
+// A sample is "live" while it has a reflected ray in flight.  Nothing is compacted: a level's passes run over all
+// sample ids and skip the ones that are not live (the list walk forms its packets from 64 consecutive ids).
+// With ray.t = 0 a reflected ray "finds" something always (ClosestIntersection reports ray.t != 1e30f): the first
+// triangle in walk order whose u, v test passes, at distance 0 -- or scene triangle 0 at 2^32 when none does
+// (SURVEY.md 9.8); the list walk takes such rays through its exact level.  CTGPU_F_REFLECT_FIX starts them at 1e30f.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ d3 reflect_ray(const ShadedPoint &s) {          // ReflectRay(-dir, normal), raythread.cpp:268-273
+    const double ni = (double)dotf(s.normal, s.view);
+    return scale(ni, scale(2.0, s.normal)) - s.view;
+}
+__device__ __forceinline__ void store_ray(ctgpu_ray *dst, const d3 &o, const d3 &d, float t) {
+    ctgpu_ray r;
+    r.origin[0] = o.x; r.origin[1] = o.y; r.origin[2] = o.z;
+    r.direction[0] = d.x; r.direction[1] = d.y; r.direction[2] = d.z;
+    r.t = t; r.pad_ = 0u;
+    *dst = r;
+}
+// what a level does with the colour it computed: reflect on (park colour and factor, emit the ray) or end here
+__device__ __forceinline__ void bounce_or_end(const BounceParams &B, uint64_t n_samples, uint64_t id, uint32_t level,
+                                              const ShadedPoint &s, uint32_t local) {
+    const bool reflects = level < B.max_depth && s.material.reflection > 0;
+    {   // how many samples go on to the next level: one atomic per wave (the lanes that are here together)
+        const unsigned long long together = __ballot(reflects);
+        if (reflects && (threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)together) - 1))
+            atomicAdd(B.level_live + level + 1u, (uint32_t)__popcll(together));
+    }
+    if (reflects) {
+        B.local[(size_t)level * n_samples + id] = local;
+        B.refl[(size_t)level * n_samples + id] = s.material.reflection;
+        B.pending[id] = (uint8_t)(level + 1u);
+        store_ray(B.rays + id, s.position, reflect_ray(s), B.bounce_t);
+        B.live[id] = 1;
+    } else {
+        B.terminal[id] = local;
+        B.live[id] = 0;
+    }
+}
+
+template <bool SS, bool SPHERES>
+__global__ __launch_bounds__(256) void ct_bounce_first(const FrameParams P, const PipelineParams W, const BounceParams B) {
+    for (uint64_t id = (uint64_t)blockIdx.x * 256u + threadIdx.x; id < W.n_samples; id += (uint64_t)gridDim.x * 256u) {
+        const uint2 h = W.hits[id];
+        B.pending[id] = 0;
+        if (__uint_as_float(h.x) == kNoHit) {                      // a miss, or a sample outside the frame
+            B.terminal[id] = kBackground;
+            B.live[id] = 0;
+            continue;
+        }
+        const PixelOfSample px = pixel_of<SS>(P, id);
+        uint32_t yi = 0;
+        (void)pixel_in_frame(P, px.xi, px.local_row, yi);
+        const ShadedPoint s = shaded_point<SS, SPHERES>(P, W, id, h, px.xi, yi);
+        const float intensity = lighting(P, s, [&](uint32_t k) { return W.shadow[(size_t)k * W.n_samples + id] != 0; });
+        bounce_or_end(B, W.n_samples, id, 0u, s, shade_value(s.material.color, intensity));
+    }
+}
+
+// did the level's reflected ray find anything, and the point it reached
+template <bool SPHERES>
+__device__ __forceinline__ bool bounce_point(const FrameParams &P, const BounceParams &B, uint64_t id, ShadedPoint &s) {
+    const ctgpu_hit h = B.hits[id];
+    const bool found = h.t != kNoHit || (SPHERES && is_sphere_hit(h.triangle));      // ClosestIntersection, raythread.cpp:227 (+ spheres)
+    if (!found) return false;
+    const ctgpu_ray r = B.rays[id];
+    s = shaded_core<SPHERES>(P, load_d3(r.origin), load_d3(r.direction), h.tclosest, h.triangle);
+    return true;
+}
+
+// the shadow rays of the points the level's reflected rays reached (ComputeLighting starts one per non-ambient light;
+// where the light cannot contribute the answer is never used: no ray, as in ct_light_gate)
+template <bool SPHERES>
+__global__ __launch_bounds__(256) void ct_bounce_gate(const FrameParams P, const PipelineParams W, const BounceParams B) {
+    if (B.level_live[B.level] == 0u) return;
+    __shared__ uint32_t block_elided[4];
+    uint32_t elided = 0;
+    for (uint64_t id = (uint64_t)blockIdx.x * 256u + threadIdx.x; id < W.n_samples; id += (uint64_t)gridDim.x * 256u) {
+        ShadedPoint s = ShadedPoint{};
+        const bool hit = B.live[id] && bounce_point<SPHERES>(P, B, id, s);
+        for (uint32_t k = 0; k < W.n_shadow_lights; k++) {
+            const size_t at = (size_t)k * W.n_samples + id;
+            bool needed = false;
+            if (hit) {
+                const Light L = P.lights[W.shadow_lights[k]];
+                const d3 to_light = towards_light(L, s.position);
+                needed = W.keep_every_shadow_ray || diffuse_reach(s, to_light) > 0;
+                if (!needed && s.material.specular != -1) {
+                    d3 reflected;
+                    needed = specular_reach(s, to_light, reflected) > 0;
+                }
+                elided += needed ? 0u : 1u;
+                if (needed) {
+                    store_ray(B.shadow_rays + at, s.position, to_light, kNoHit);
+                    B.shadow_hits[at].found = 0u;
+                }
+            }
+            B.shadow_live[at] = needed ? 1 : 0;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) elided += __shfl_down(elided, off);
+    if ((threadIdx.x & 63u) == 0) block_elided[threadIdx.x >> 6] = elided;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = block_elided[0] + block_elided[1] + block_elided[2] + block_elided[3];
+        if (total) atomicAdd(&P.counters[kCounterElided], (unsigned long long)total);
+    }
+}
+
+template <bool SPHERES>
+__global__ __launch_bounds__(256) void ct_bounce_shade(const FrameParams P, const PipelineParams W, const BounceParams B) {
+    if (B.level_live[B.level] == 0u) return;
+    for (uint64_t id = (uint64_t)blockIdx.x * 256u + threadIdx.x; id < W.n_samples; id += (uint64_t)gridDim.x * 256u) {
+        if (!B.live[id]) continue;
+        ShadedPoint s;
+        if (!bounce_point<SPHERES>(P, B, id, s)) {                 // the reflected ray found nothing: BACKGROUND_COLOR
+            B.terminal[id] = kBackground;
+            B.live[id] = 0;
+            continue;
+        }
+        // a light is left out when its shadow ray does not exist (it cannot contribute here) or found something
+        const float intensity = lighting(P, s, [&](uint32_t k) {
+            const size_t at = (size_t)k * W.n_samples + id;
+            return B.shadow_live[at] == 0 || B.shadow_hits[at].found != 0u;
+        });
+        bounce_or_end(B, W.n_samples, id, B.level, s, shade_value(s.material.color, intensity));
+    }
+}
+
+// spheres at a bounce level (CTGPU_F_SPHERES): reflected rays accept t in [0.001, inf) (raythread.cpp:373), their
+// shadow rays [0.001, 1] towards a point light, [0.001, inf) along a directional one
+template <int KIND>
+__global__ __launch_bounds__(256) void ct_bounce_spheres(const FrameParams P, const PipelineParams W, const BounceParams B) {
+    if (B.level_live[B.level] == 0u) return;
+    const uint64_t total = (KIND == 0) ? W.n_samples : W.n_samples * (uint64_t)W.n_shadow_lights;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256u + threadIdx.x; i < total; i += (uint64_t)gridDim.x * 256u) {
+        if (KIND == 0) {
+            if (!B.live[i]) continue;
+            const ctgpu_ray r = B.rays[i];
+            ctgpu_hit h = B.hits[i];
+            float tclosest = (h.triangle != kNoNode) ? h.tclosest : kFarAway;
+            int sphere = -1;
+            walk_spheres(P, load_d3(r.origin), load_d3(r.direction), 0.001f, kFarAway, tclosest, sphere);
+            if (sphere >= 0) {
+                h.tclosest = tclosest;
+                h.triangle = kSphereTag | (uint32_t)sphere;
+                B.hits[i] = h;
+            }
+        } else {
+            if (!B.shadow_live[i] || B.shadow_hits[i].found) continue;
+            const ctgpu_ray r = B.shadow_rays[i];
+            const Light L = P.lights[W.shadow_lights[i / W.n_samples]];
+            float nearest = kFarAway;
+            int sphere = -1;
+            walk_spheres(P, load_d3(r.origin), load_d3(r.direction), 0.001f, L.type == CTGPU_LIGHT_POINT ? 1.0f : kFarAway, nearest, sphere);
+            if (sphere >= 0) B.shadow_hits[i].found = 1u;
+        }
+    }
+}
+
+// the colour TraceRay returns for a sample: the deepest call's colour mixed back through the levels that reflected
+__device__ __forceinline__ uint32_t bounce_colour(const BounceParams &B, uint64_t n_samples, uint64_t id) {
+    uint32_t c = B.terminal[id];
+    for (uint32_t k = B.pending[id]; k > 0; k--)
+        c = mix_reflection(B.local[(size_t)(k - 1u) * n_samples + id], c, B.refl[(size_t)(k - 1u) * n_samples + id]);
+    return c;
+}
+// ct_shade's second half with the colours taken from the bounce levels
+template <bool SS>
+__global__ __launch_bounds__(256) void ct_bounce_finish(const FrameParams P, const PipelineParams W, const BounceParams B) {
+    if (!SS) {
+        const uint64_t id = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+        if (id >= W.n_samples) return;
+        const PixelOfSample px = pixel_of<false>(P, id);
+        uint32_t yi;
+        if (!pixel_in_frame(P, px.xi, px.local_row, yi)) return;
+        P.out[(size_t)px.local_row * P.square + px.xi] = bounce_colour(B, W.n_samples, id);
+        return;
+    }
+    __shared__ uint32_t colour[256 * 17];
+    const uint64_t block_first = (uint64_t)blockIdx.x * 4096u;
+    for (uint32_t j = 0; j < 16; j++) {
+        const uint32_t local = j * 256u + threadIdx.x;
+        const uint64_t id = block_first + local;
+        colour[(local >> 4) * 17u + (local & 15u)] = (id < W.n_samples) ? bounce_colour(B, W.n_samples, id) : kBackground;
+    }
+    __syncthreads();
+    const uint64_t first = block_first + (uint64_t)threadIdx.x * 16u;
+    if (first >= W.n_samples) return;
+    const PixelOfSample px = pixel_of<true>(P, first);
+    uint32_t yi;
+    if (!pixel_in_frame(P, px.xi, px.local_row, yi)) return;
+    uint32_t pixel_color = colour[threadIdx.x * 17u];
+    for (uint32_t smp = 1; smp < 16; smp++) pixel_color = blend_sample(pixel_color, colour[threadIdx.x * 17u + smp]);
+    P.out[(size_t)px.local_row * P.square + px.xi] = pixel_color;
+}
+
+// ------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------
 namespace ctd {
@@ -1495,7 +1717,8 @@ int pipeline_packet_occupancy(uint32_t depth, uint32_t lds_levels) {
     return a < b ? a : b;
 }
 
-void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hipStream_t stream, hipEvent_t *marks) {
+void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hipStream_t stream, hipEvent_t *marks,
+                     const BounceParams *bounce) {
     if (W.n_samples == 0) return;
     // marks (optional, kPipelineKernels + 1 events): one before each kernel and one after the last, so that the
     // time between marks k and k+1 is kernel k's (ctgpu_kernel_timing)
@@ -1561,10 +1784,51 @@ void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hip
     }
     if (shadows) sphere_pass(1);
     mark(4);
-    if (ss && !sph) hipLaunchKernelGGL((ct_shade<true, false>), dim3(pixel_blocks), dim3(256), 0, stream, P, W);
-    if (!ss && !sph) hipLaunchKernelGGL((ct_shade<false, false>), dim3(pixel_blocks), dim3(256), 0, stream, P, W);
-    if (ss && sph) hipLaunchKernelGGL((ct_shade<true, true>), dim3(pixel_blocks), dim3(256), 0, stream, P, W);
-    if (!ss && sph) hipLaunchKernelGGL((ct_shade<false, true>), dim3(pixel_blocks), dim3(256), 0, stream, P, W);
+    if (!bounce) {
+        if (ss && !sph) hipLaunchKernelGGL((ct_shade<true, false>), dim3(pixel_blocks), dim3(256), 0, stream, P, W);
+        if (!ss && !sph) hipLaunchKernelGGL((ct_shade<false, false>), dim3(pixel_blocks), dim3(256), 0, stream, P, W);
+        if (ss && sph) hipLaunchKernelGGL((ct_shade<true, true>), dim3(pixel_blocks), dim3(256), 0, stream, P, W);
+        if (!ss && sph) hipLaunchKernelGGL((ct_shade<false, true>), dim3(pixel_blocks), dim3(256), 0, stream, P, W);
+        mark(5);
+        return;
+    }
+
+    // ---- reflective materials: the bounce levels (their time is booked on ct_shade's mark)
+    BounceParams B = *bounce;
+    const dim3 strided(sample_blocks), threads(256);
+    (void)hipMemsetAsync(B.level_live, 0, (B.max_depth + 2u) * sizeof(uint32_t), stream);
+    if (ss && !sph) hipLaunchKernelGGL((ct_bounce_first<true, false>), strided, threads, 0, stream, P, W, B);
+    if (!ss && !sph) hipLaunchKernelGGL((ct_bounce_first<false, false>), strided, threads, 0, stream, P, W, B);
+    if (ss && sph) hipLaunchKernelGGL((ct_bounce_first<true, true>), strided, threads, 0, stream, P, W, B);
+    if (!ss && sph) hipLaunchKernelGGL((ct_bounce_first<false, true>), strided, threads, 0, stream, P, W, B);
+    // the list walks: the packet walk's caller-list kinds over the frame's own ray arrays, 64 consecutive ids a packet
+    const uint32_t depth_p = W.packet_depth;
+    const size_t lds_p = PacketStack::bytes(depth_p, W.packet_lds_levels < depth_p ? W.packet_lds_levels : depth_p);
+    const size_t queue_bytes = (queue_words(W.n_shadow_lights) + 32) * sizeof(unsigned long long);
+    PipelineParams Wc = W;                       // closest hit over the reflected rays
+    Wc.ray_list = B.rays; Wc.ray_hits = B.hits; Wc.ray_live = B.live; Wc.list_slots = 1u; Wc.list_counter = 2u;
+    PipelineParams Ws = W;                       // any hit over their shadow rays, [light][sample]
+    Ws.ray_list = B.shadow_rays; Ws.ray_hits = B.shadow_hits; Ws.ray_live = B.shadow_live; Ws.list_slots = 1u; Ws.list_counter = 1u;
+    Ws.n_samples = W.n_samples * (uint64_t)W.n_shadow_lights;
+    const auto list_grid = [&](uint64_t n) { return dim3((uint32_t)std::min<uint64_t>(W.walk_blocks, std::max<uint64_t>((n + 63u) / 64u, 1u))); };
+    for (uint32_t level = 1; level <= B.max_depth; level++) {
+        B.level = level;
+        Wc.list_gate = Ws.list_gate = B.level_live + level;
+        (void)hipMemsetAsync(W.queue, 0, queue_bytes, stream);
+        hipLaunchKernelGGL((ct_walk_packet<2, false>), list_grid(Wc.n_samples), wave, lds_p, stream, P, Wc);
+        if (sph) hipLaunchKernelGGL((ct_bounce_spheres<0>), strided, threads, 0, stream, P, W, B);
+        if (shadows) {
+            if (sph) hipLaunchKernelGGL((ct_bounce_gate<true>), strided, threads, 0, stream, P, W, B);
+            else hipLaunchKernelGGL((ct_bounce_gate<false>), strided, threads, 0, stream, P, W, B);
+            (void)hipMemsetAsync(W.queue, 0, queue_bytes, stream);
+            hipLaunchKernelGGL((ct_walk_packet<3, false>), list_grid(Ws.n_samples), wave, lds_p, stream, P, Ws);
+            if (sph) hipLaunchKernelGGL((ct_bounce_spheres<1>), strided, threads, 0, stream, P, W, B);
+        }
+        if (sph) hipLaunchKernelGGL((ct_bounce_shade<true>), strided, threads, 0, stream, P, W, B);
+        else hipLaunchKernelGGL((ct_bounce_shade<false>), strided, threads, 0, stream, P, W, B);
+    }
+    if (ss) hipLaunchKernelGGL((ct_bounce_finish<true>), dim3(pixel_blocks), dim3(256), 0, stream, P, W, B);
+    else hipLaunchKernelGGL((ct_bounce_finish<false>), dim3(pixel_blocks), dim3(256), 0, stream, P, W, B);
     mark(5);
 }
 

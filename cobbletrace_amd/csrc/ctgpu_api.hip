@@ -134,6 +134,25 @@ struct ctgpu_ctx {
     int packet_lds_levels = 14;                 // per-lane tmin levels kept in LDS by the packet walk
     int packet_budget = 0, packet_lanes = 12;   // CTGPU_PACKET_BUDGET: hand-over of incoherent packets to the per-lane walk (PipelineParams); 0 = off, the default
     DeviceArray<unsigned long long> handed_ids[2];
+    // reflection bounces on the pipeline (BounceParams)
+    DeviceArray<ctgpu_ray> b_rays, b_shadow_rays;
+    DeviceArray<ctgpu_hit> b_hits, b_shadow_hits;
+    DeviceArray<uint8_t> b_live, b_shadow_live, b_pending;
+    DeviceArray<uint32_t> b_local, b_terminal, b_level_live;
+    DeviceArray<float> b_refl;
+    bool bounce_on_pipeline = true;             // CTGPU_BOUNCE=0: reflective frames take the general path (one kernel), =1: the bounce levels
+    // Unset, reflective frames are measured on both and the faster is kept, per frame kind ([0] single sample, [1]
+    // supersampled): the bounce levels win where there is work per level (cube scene at 16 spp: 1.2 against 4.8 ms),
+    // the one kernel on small frames whose ten levels are mostly launches (scene_file_1 at 1 spp: 0.4 against 1.6 ms).
+    // Same pixels either way.  Order: two frames on the pipeline, two on the general path, the second of each counts.
+    bool bounce_auto = true;
+    struct BounceChoice {
+        uint32_t frames = 0;                    // reflective frames of this kind that reported a time
+        bool use_general = false;               // the settled choice
+        bool ran_general = false;               // what the frame in flight runs on
+        double pipeline_ms = 0.0, general_ms = 0.0;
+    } bounce_choice[2];
+    bool frame_is_reflective = false;           // ... the frame in flight
     unsigned long long handed_over[2] = {0, 0}; // rays handed over since the last ctgpu_read_walk_work
     bool keep_shadow_rays = false;              // CTGPU_KEEP_SHADOW_RAYS=1: trace the shadow rays whose answer cannot matter, too
     bool packet_walk = true;                    // ct_walk_packet (CTGPU_PACKET=0: per-lane walk)
@@ -161,6 +180,7 @@ struct ctgpu_ctx {
         std::chrono::steady_clock::time_point t0;
         uint64_t pixels = 0;
         int kind = -1;                          // 0 / 1: a single-sample / supersampled frame on the fast path (walk choice)
+        int reflective_kind = -1;               // 0 / 1: a reflective single-sample / supersampled frame (bounce choice)
     } pending;
     int probe_above = 100;                      // CTGPU_PROBE_ABOVE: fetches per packet beyond which the per-lane walk gets a trial frame
     uint32_t *pinned_fb = nullptr;              // the caller's framebuffer, page-locked by begin_frame for the asynchronous copy
@@ -266,6 +286,7 @@ static int create_resources(ctgpu_ctx *ctx) {
     if (const char *t = std::getenv("CTGPU_PACKET_LANES")) ctx->packet_lanes = std::min(64, std::max(1, std::atoi(t)));
     if (const char *t = std::getenv("CTGPU_PACKET_LDS_LEVELS")) ctx->packet_lds_levels = std::max(1, std::atoi(t));
     if (const char *t = std::getenv("CTGPU_FORCE_MEGAKERNEL")) ctx->force_megakernel = std::atoi(t) != 0;
+    if (const char *t = std::getenv("CTGPU_BOUNCE")) { ctx->bounce_on_pipeline = std::atoi(t) != 0; ctx->bounce_auto = false; }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->cu_count = prop.multiProcessorCount;
     HIP_TRY(ctx->queue.resize(queue_words(32) + 32));        // (grows with the scene's light count, fill_pipeline)
@@ -312,6 +333,9 @@ extern "C" void ctgpu_destroy(ctgpu_ctx *ctx) {
     ctx->rand_table.release(); ctx->row_ordinal.release();
     ctx->coords.release(); ctx->hits.release(); ctx->shadow.release(); ctx->queue.release(); ctx->spill.release();
     ctx->walk_work.release(); ctx->handed_ids[0].release(); ctx->handed_ids[1].release();
+    ctx->b_rays.release(); ctx->b_shadow_rays.release(); ctx->b_hits.release(); ctx->b_shadow_hits.release();
+    ctx->b_live.release(); ctx->b_shadow_live.release(); ctx->b_pending.release(); ctx->b_local.release();
+    ctx->b_terminal.release(); ctx->b_refl.release(); ctx->b_level_live.release();
     for (hipEvent_t e : ctx->marks) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->phase_marks) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -639,7 +663,8 @@ extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
     S.tree_depth = depth;
     S.has_reflection = reflective;
     ctx->scene = store;
-    ctx->choice[0] = ctx->choice[1] = ctgpu_ctx::WalkChoice();       // another scene: the walk choice starts over
+    ctx->choice[0] = ctx->choice[1] = ctgpu_ctx::WalkChoice();       // another scene: the measured choices start over
+    ctx->bounce_choice[0] = ctx->bounce_choice[1] = ctgpu_ctx::BounceChoice();
     return CTGPU_OK;
 }
 
@@ -654,6 +679,7 @@ extern "C" int ctgpu_share_scene(ctgpu_ctx *ctx, ctgpu_ctx *owner) {
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->scene = owner->scene;
     ctx->choice[0] = ctx->choice[1] = ctgpu_ctx::WalkChoice();
+    ctx->bounce_choice[0] = ctx->bounce_choice[1] = ctgpu_ctx::BounceChoice();
     return CTGPU_OK;
 }
 
@@ -881,12 +907,27 @@ namespace {
 
 // The wavefront pipeline covers every frame without reflection bounces (any number of lights, spheres included);
 // reflective materials take the general path, one kernel that follows TraceRay's recursion.
+// does TraceRay's recursion bounce in this frame: some material the frame draws reflects, and depth is allowed
+bool frame_reflects(const ctgpu_ctx *ctx, const ctgpu_frame_desc *f) {
+    const bool spheres = (f->flags & CTGPU_F_SPHERES) && ctx->scene->n_spheres;
+    // (a sphere's material counts only in frames that draw spheres)
+    return f->max_depth > 0 && (ctx->scene->triangles_reflect || (spheres && ctx->scene->spheres_reflect));
+}
+
 bool pipeline_eligible(const ctgpu_ctx *ctx, const ctgpu_frame_desc *f) {
     if (ctx->force_megakernel) return false;
-    const bool spheres = (f->flags & CTGPU_F_SPHERES) && ctx->scene->n_spheres;
-    // reflective materials bounce (TraceRay's recursion): the general path.  A sphere's material counts only in frames
-    // that draw spheres.
-    if (f->max_depth > 0 && (ctx->scene->triangles_reflect || (spheres && ctx->scene->spheres_reflect))) return false;
+    // reflective frames: the bounce levels ride on the packet walk's ray-list kernels, whose stack levels are lanes
+    // of a register (trees that leave more than 64 entries pending take the general path, like CTGPU_BOUNCE=0)
+    if (frame_reflects(ctx, f)) {
+        if (!ctx->bounce_on_pipeline || ctx->scene->quad_pending > 64u) return false;
+        if (!ctx->bounce_auto) return true;
+        // measured choice (BounceChoice): which path does the NEXT reflective frame of this kind take
+        const ctgpu_ctx::BounceChoice &c = ctx->bounce_choice[(f->flags & CTGPU_F_SUPERSAMPLE) ? 1 : 0];
+        const uint32_t phase = c.frames % 256u;
+        if (c.frames < 4u) return c.frames < 2u;                   // frames 0, 1: pipeline; 2, 3: general path
+        if (phase == 0u) return c.use_general;                     // every 256 frames: one frame on the other path
+        return !c.use_general;
+    }
     return true;          // (any number of lights: the shadow walk's queue has a head-word set per light)
 }
 
@@ -909,6 +950,25 @@ int launch_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, FrameParams &P, hipS
     HIP_TRY(ctx->hits.resize(W.n_samples));
     HIP_TRY(ctx->shadow.resize(W.n_samples * std::max<uint32_t>(W.n_shadow_lights, 1)));
     W.coords = ctx->coords.ptr; W.hits = ctx->hits.ptr; W.shadow = ctx->shadow.ptr;
+    BounceParams B;
+    const bool bounces = frame_reflects(ctx, f);
+    if (bounces) {
+        // per sample: the level's reflected ray, its hit, its shadow rays and their hits, and the colours parked on the
+        // way down (TraceRay's stack frames, one array per level)
+        const size_t n = (size_t)W.n_samples, lights = std::max<uint32_t>(W.n_shadow_lights, 1), levels = (size_t)f->max_depth;
+        HIP_TRY(ctx->b_rays.resize(n));           HIP_TRY(ctx->b_hits.resize(n));           HIP_TRY(ctx->b_live.resize(n));
+        HIP_TRY(ctx->b_shadow_rays.resize(n * lights)); HIP_TRY(ctx->b_shadow_hits.resize(n * lights)); HIP_TRY(ctx->b_shadow_live.resize(n * lights));
+        HIP_TRY(ctx->b_local.resize(n * levels)); HIP_TRY(ctx->b_refl.resize(n * levels));
+        HIP_TRY(ctx->b_terminal.resize(n));       HIP_TRY(ctx->b_pending.resize(n));
+        HIP_TRY(ctx->b_level_live.resize(levels + 2));
+        std::memset(&B, 0, sizeof B);
+        B.rays = ctx->b_rays.ptr; B.live = ctx->b_live.ptr; B.hits = ctx->b_hits.ptr;
+        B.shadow_rays = ctx->b_shadow_rays.ptr; B.shadow_live = ctx->b_shadow_live.ptr; B.shadow_hits = ctx->b_shadow_hits.ptr;
+        B.local = ctx->b_local.ptr; B.refl = ctx->b_refl.ptr; B.terminal = ctx->b_terminal.ptr; B.pending = ctx->b_pending.ptr;
+        B.level_live = ctx->b_level_live.ptr;
+        B.max_depth = (uint32_t)f->max_depth;
+        B.bounce_t = (f->flags & CTGPU_F_REFLECT_FIX) ? kNoHit : 0.0f;
+    }
     if (begin) HIP_TRY(hipEventRecord(begin, stream));
     HIP_TRY(hipMemsetAsync(ctx->queue.ptr, 0, (queue_words(W.n_shadow_lights) + 32) * sizeof(unsigned long long), stream));
     hipEvent_t *marks = nullptr;
@@ -922,7 +982,7 @@ int launch_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, FrameParams &P, hipS
         marks = ctx->marks.data() + ctx->marks_used;
         ctx->marks_used = need;
     }
-    launch_pipeline(P, W, ss, stream, marks);
+    launch_pipeline(P, W, ss, stream, marks, bounces ? &B : nullptr);
     HIP_TRY(hipGetLastError());
     return CTGPU_OK;
 }
@@ -1091,6 +1151,12 @@ int begin_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, uint32_t *host_fb
     }
 
     ctx->pending.kind = pipeline_eligible(ctx, frame) ? ((frame->flags & CTGPU_F_SUPERSAMPLE) ? 1 : 0) : -1;
+    ctx->frame_is_reflective = frame_reflects(ctx, frame);
+    if (ctx->frame_is_reflective) {
+        ctx->bounce_choice[(frame->flags & CTGPU_F_SUPERSAMPLE) ? 1 : 0].ran_general = ctx->pending.kind < 0;
+        ctx->pending.reflective_kind = (frame->flags & CTGPU_F_SUPERSAMPLE) ? 1 : 0;
+        ctx->pending.kind = -1;                  // (the walk choice is about frames without bounces)
+    } else ctx->pending.reflective_kind = -1;
     rc = launch_frame(ctx, frame, P, ctx->stream, ctx->ev0); if (rc) return rc;
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
     launch_assemble(P, ctx->tiles.ptr, ctx->fb.ptr, ctx->stream);
@@ -1172,6 +1238,13 @@ int finish_frame(ctgpu_ctx *ctx, bool wait, int *done, ctgpu_stats *stats) {
     if (stats) *stats = st;
     if (ctx->walk_auto && ctx->pending.kind >= 0) {
         int rc2 = walk_feedback(ctx, ctx->pending.kind, ms); if (rc2) return rc2;
+    }
+    if (ctx->bounce_auto && ctx->pending.reflective_kind >= 0) {
+        ctgpu_ctx::BounceChoice &c = ctx->bounce_choice[ctx->pending.reflective_kind];
+        (c.ran_general ? c.general_ms : c.pipeline_ms) = ms;
+        c.frames += 1;
+        // settled after the fourth frame (frames 1 and 3 are the second on each path), re-examined after each trial frame
+        if (c.frames == 4u || (c.frames > 4u && c.frames % 256u == 1u)) c.use_general = c.general_ms < c.pipeline_ms;
     }
     return CTGPU_OK;
 }
@@ -1455,6 +1528,15 @@ extern "C" int ctgpu_walk_choice(ctgpu_ctx *ctx, int supersampled, int *per_lane
     if (per_lane) *per_lane = ctx->walk_auto ? (c.use_lane ? 1 : 0) : (ctx->packet_walk ? 0 : 1);
     if (packet_ms) *packet_ms = c.packet_ms;
     if (lane_ms) *lane_ms = c.lane_ms;
+    return CTGPU_OK;
+}
+
+extern "C" int ctgpu_bounce_choice(ctgpu_ctx *ctx, int supersampled, int *general_path, double *pipeline_ms, double *general_ms) {
+    if (!ctx) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_bounce_choice: null argument");
+    const ctgpu_ctx::BounceChoice &c = ctx->bounce_choice[supersampled ? 1 : 0];
+    if (general_path) *general_path = ctx->bounce_auto ? (c.use_general ? 1 : 0) : (ctx->bounce_on_pipeline ? 0 : 1);
+    if (pipeline_ms) *pipeline_ms = c.pipeline_ms;
+    if (general_ms) *general_ms = c.general_ms;
     return CTGPU_OK;
 }
 

@@ -188,7 +188,9 @@ int  ctgpu_device_count(int *count);
  *                        than LANES rays per visit hand their rays to the per-lane kernel
  *   CTGPU_PACKET_LDS_LEVELS, CTGPU_LDS_DEPTH   stack levels kept in LDS (deeper ones go to HBM)
  *   CTGPU_FORCE_MEGAKERNEL   1: the general path (one kernel, reflection capable) for every frame
- *   CTGPU_PACK           host: re-lay-out an uploaded tree on the host (default: on the device) */
+ *   CTGPU_PACK           host: re-lay-out an uploaded tree on the host (default: on the device)
+ *   CTGPU_BOUNCE         frames whose materials reflect: 1 the bounce levels on the wavefront pipeline, 0 the general
+ *                        path's one kernel (unset: whichever was measured faster, ctgpu_bounce_choice) */
 int  ctgpu_create(int device, ctgpu_ctx **out);
 void ctgpu_destroy(ctgpu_ctx *ctx);
 
@@ -334,6 +336,11 @@ int  ctgpu_read_walk_work(ctgpu_ctx *ctx, ctgpu_walk_work *out);
  * 100) gets one frame on the per-lane walk, and whichever was faster is kept (same pixels either way); every 256
  * frames the other walk gets one frame again. */
 int  ctgpu_walk_choice(ctgpu_ctx *ctx, int supersampled, int *per_lane, double *packet_ms, double *lane_ms);
+/* The same for frames whose materials reflect: TraceRay's recursion runs either as bounce levels on the wavefront
+ * pipeline (level 0 through the frame walks, levels 1..depth through the packet walk's ray-list kernels) or in the
+ * general path's one kernel; without CTGPU_BOUNCE in the environment the context renders two frames of a kind on each
+ * and keeps the faster (same pixels), trying the other again every 256 frames. */
+int  ctgpu_bounce_choice(ctgpu_ctx *ctx, int supersampled, int *general_path, double *pipeline_ms, double *general_ms);
 int  ctgpu_kernel_timing(ctgpu_ctx *ctx, int enable);
 int  ctgpu_read_kernel_times(ctgpu_ctx *ctx, ctgpu_kernel_times *out);
 

@@ -775,6 +775,14 @@ def test_rays_with_nan_box_parameters(tmp_path):
                 _compare(got, want, "camera on the floor plane, packet=%s ss=%d sub=%d" % (packet, ss, sub))
             hits, ref = ctx.trace_rays(rays), _oracle().trace_rays(scene.desc, rays)
             assert (hits["triangle"] == ref["triangle"]).all() and (hits["t"].view(np.uint32) == ref["t"].view(np.uint32)).all()
+            # the same rays through the frame kernel's list mode, also starting at ray.t = 0 (a reflected ray's start,
+            # raythread.cpp:373): a ray that leaves the packet for the unfolded second pass restarts from ITS start value
+            for t_start in (1e30, 0.0):
+                listed = rays.copy()
+                listed["t"] = np.float32(t_start)
+                hits, ref = ctx.trace_rays_packet(listed), _oracle().trace_rays(scene.desc, listed)
+                assert (hits["triangle"] == ref["triangle"]).all() and (hits["t"].view(np.uint32) == ref["t"].view(np.uint32)).all()
+                assert (hits["tclosest"].view(np.uint32) == ref["tclosest"].view(np.uint32)).all(), t_start
         finally:
             ctx.close()
 

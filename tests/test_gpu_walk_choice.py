@@ -154,3 +154,69 @@ def test_spheres_stay_on_the_fast_path(tmp_path, monkeypatch):
     finally:
         fast.close()
         general.close()
+
+
+@pytest.mark.parametrize("spheres,reflect_fix", [(False, False), (True, False), (False, True), (True, True)])
+def test_reflection_bounces_on_the_fast_path(spheres, reflect_fix, assets, monkeypatch):
+    """Reflective materials (scene_file_cube.json, scene_file_1.json): TraceRay's recursion (raythread.cpp:353-386,
+    the t = 0 start of reflected rays included) as bounce levels on the wavefront pipeline -- level 0 through the frame
+    walks, levels 1..10 through the packet walk's ray-list kernels -- against the oracle (<= 1 LSB) and against the
+    general path's one kernel (identical pixels, identical ray counts)."""
+    import os
+    from oracle import oracle
+    monkeypatch.delenv("CTGPU_FORCE_MEGAKERNEL", raising=False)
+    monkeypatch.delenv("CTGPU_BOUNCE", raising=False)
+    shifts = np.array([0, 8, 16])
+    for name in ("scene_file_cube.json", "scene_file_1.json"):
+        scene = ca.HostScene(os.path.join(assets, name))
+        monkeypatch.setenv("CTGPU_PACKET", "1")
+        monkeypatch.setenv("CTGPU_BOUNCE", "1")
+        fast = ca.GpuContext(0)
+        fast.upload(scene.desc, build_on_device=True)
+        monkeypatch.setenv("CTGPU_BOUNCE", "0")
+        general = ca.GpuContext(0)
+        general.upload(scene.desc)
+        monkeypatch.delenv("CTGPU_BOUNCE")
+        try:
+            for ss, w, h in ((False, 640, 480), (True, 320, 240)):
+                frame = scene.frame(w, h, supersampling=ss, rng_seed=4, spheres=spheres, reflect_fix=reflect_fix)
+                fast.read_walk_work()
+                got, st = fast.render(frame)
+                work = fast.read_walk_work()
+                other, so = general.render(frame)
+                want, _ = oracle.render(scene.desc, frame, os_threads=8)
+                diff = np.abs(((got[..., None] >> shifts) & 255).astype(int) - ((want[..., None] >> shifts) & 255).astype(int)).max()
+                print("%s spheres=%d fix=%d ss=%d: fast path %.3f ms, general path %.3f ms; %d px differ from the oracle, %d from the general path; "
+                      "%d reflected rays" % (name, spheres, reflect_fix, ss, st.kernel_ms, so.kernel_ms, int((got != want).sum()),
+                                             int((got != other).sum()), st.rays_reflect))
+                assert diff <= 1 and ((got == 0) == (want == 0)).all()
+                assert (got == other).all()
+                assert work.packets[0] > 0                                  # the frame's primary rays went through the packet walk
+                assert (st.rays_primary, st.rays_reflect) == (so.rays_primary, so.rays_reflect) and st.rays_reflect > 0
+                assert st.rays_shadow + st.rays_shadow_elided == so.rays_shadow + so.rays_shadow_elided
+        finally:
+            fast.close()
+            general.close()
+
+
+def test_reflective_frames_take_the_faster_path(assets, monkeypatch):
+    """Without CTGPU_BOUNCE a context renders two reflective frames of a kind on the bounce pipeline, two on the
+    general path, and keeps whichever took less kernel time; the pixels never change."""
+    import os
+    monkeypatch.delenv("CTGPU_BOUNCE", raising=False)
+    monkeypatch.delenv("CTGPU_FORCE_MEGAKERNEL", raising=False)
+    scene = ca.HostScene(os.path.join(assets, "scene_file_cube.json"))
+    ctx = ca.GpuContext(0)
+    ctx.upload(scene.desc)
+    try:
+        for ss, w, h in ((True, 640, 480), (False, 320, 240)):
+            frame = scene.frame(w, h, supersampling=ss, rng_seed=1)
+            frames = [ctx.render(frame)[0] for _ in range(7)]
+            assert all((f == frames[0]).all() for f in frames[1:])
+            general, pipeline_ms, general_ms = ctx.bounce_choice(ss)
+            print("cube %dx%d ss=%d: bounce levels %.3f ms, general path %.3f ms -> %s" % (w, h, ss, pipeline_ms, general_ms,
+                  "general path" if general else "bounce levels"))
+            assert pipeline_ms > 0 and general_ms > 0
+            assert general == (general_ms < pipeline_ms) or abs(general_ms - pipeline_ms) < 0.15 * pipeline_ms      # (the figures move on after the decision)
+    finally:
+        ctx.close()
