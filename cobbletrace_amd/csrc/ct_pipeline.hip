@@ -857,7 +857,8 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                     has_ray = true;
                 }
             }
-            if (KIND != 1) break;          // primary / list packets: one aligned run of 64 ids, no top-up
+            if (KIND != 1) break;          // primary / list packets: one aligned run of 64 ids, no top-up (measured for the
+                                           // frame's own bounce lists, where many ids have no ray: 5-10 % slower with it)
         }
         n_traced += (uint32_t)__popcll(__ballot(has_ray));
         if (__ballot(has_ray) == 0ull) {
