@@ -6,7 +6,9 @@ import cobbletrace_amd as ca
 import __graft_entry__ as entry
 entry.prepare_assets(need_dragon=True)
 A = os.path.join(os.path.dirname(__file__), "..", "assets")
-CONFIGS = [("C2 scene_import.json 1920x1080", "scene_import.json", 1920, 1080),
+CONFIGS = [("C1 scene_file_cube.json 640x480 (reflective: bounce levels / general path, the faster)", "scene_file_cube.json", 640, 480),
+           ("   scene_file_1.json 640x480 (reflective)", "scene_file_1.json", 640, 480),
+           ("C2 scene_import.json 1920x1080", "scene_import.json", 1920, 1080),
            ("C3 scene_import_bunny.json 1920x1080", "scene_import_bunny.json", 1920, 1080),
            ("C4 scene_import_dragon.json (stand-in) 1920x1080", "scene_import_dragon.json", 1920, 1080),
            ("C5 scene_import_dragon.json (stand-in) 3840x2160", "scene_import_dragon.json", 3840, 2160)]
@@ -16,9 +18,9 @@ for label, f, w, h in CONFIGS:
     for ss in (True, False):
         frame = scene.frame(w, h, supersampling=ss)
         best = None
-        for _ in range(4):
+        for _ in range(6):
             fb, st = ctx.render(frame)
             if best is None or st.total_ms < best.total_ms: best = st
-        print("%-52s ss=%d T=%d: %9d rays  kernel %8.3f ms  to-host %8.3f ms  %8.1f Mrays/s" %
+        print("%-90s ss=%d T=%d: %9d rays  kernel %8.3f ms  to-host %8.3f ms  %8.1f Mrays/s" %
               (label, ss, frame.num_threads, best.rays, best.kernel_ms, best.total_ms, best.rays / best.total_ms / 1e3))
     ctx.close()
