@@ -290,7 +290,7 @@ def main():
     # a device framebuffer and a pinned host framebuffer.
     # (measured on one GPU with rank 0's share of the frame, tools/overlap.py: an eighth of the frame takes 0.49 ms with
     # three frames in flight and 0.46 ms with four; the whole frame is best with three)
-    inflight = args.inflight if args.inflight > 0 else (4 if world >= 8 else 3)
+    inflight = args.inflight if args.inflight > 0 else (4 if world >= 8 else 3)      # (tools/rank_share.py, profiles/r03_rank_share.log: within run-to-run noise)
     # Throughput tuning through the library's documented knobs (read at context creation): with several
     # frames in flight and only an eighth of the frame per rank, a smaller persistent grid per context
     # and 128-ray-id chunks beat the defaults, which are tuned for one frame's latency.
