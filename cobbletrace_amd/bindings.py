@@ -150,6 +150,7 @@ _GPU_SYMBOLS = {
     "ctgpu_build_bvh": (C.c_int, [C.c_int, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]),
     "ctgpu_read_walk_work": (C.c_int, [C.c_void_p, C.POINTER(WalkWork)]),
     "ctgpu_walk_choice": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "ctgpu_order_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int)]),
     "ctgpu_bounce_choice": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ctgpu_kernel_timing": (C.c_int, [C.c_void_p, C.c_int]),
     "ctgpu_read_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(KernelTimes)]),
@@ -454,6 +455,12 @@ class GpuContext:
         general, a, b = C.c_int(0), C.c_double(0), C.c_double(0)
         self._check(self.lib.ctgpu_bounce_choice(self.handle, 1 if supersampled else 0, C.byref(general), C.byref(a), C.byref(b)))
         return bool(general.value), a.value, b.value
+
+    def order_info(self):
+        """(list entries of the last frame's heavy classes [primary 0, primary 1, shadow 0, shadow 1], chunks cut into parts?)"""
+        entries, split = (C.c_uint32 * 8)(), C.c_int(0)
+        self._check(self.lib.ctgpu_order_info(self.handle, entries, C.byref(split)))
+        return list(entries), bool(split.value)
 
     def read_phase_times(self):
         t = PhaseTimes()

@@ -19,6 +19,10 @@ constexpr int kCounterWords = 24;
 // for the two hand-over counters (everything cleared together, per frame)
 __host__ __device__ constexpr uint32_t queue_walks(uint32_t n_shadow_lights) { return n_shadow_lights + 3u; }
 __host__ __device__ constexpr size_t queue_words(uint32_t n_shadow_lights) { return (size_t)queue_walks(n_shadow_lights) * 8u * 16u; }
+// ... and behind them: the two hand-over counters (32 words), then the head words of the heavy-chunk lists (ORDERED
+// walks: class 0 / 1 of the primary walk, class 0 / 1 of the shadow walk, 16 words apart).  One block, cleared per frame.
+__host__ __device__ constexpr size_t queue_order_heads(uint32_t n_shadow_lights) { return queue_words(n_shadow_lights) + 32u; }
+__host__ __device__ constexpr size_t queue_block_words(uint32_t n_shadow_lights) { return queue_words(n_shadow_lights) + 32u + 64u; }
 constexpr int kCounterElided = 16;
 
 struct FrameParams {
@@ -75,6 +79,24 @@ struct FrameParams {
     uint32_t *overflow;                    // set to 1 on traversal-stack overflow
 };
 
+// Heavy chunks first (ct_walk_packet<.., ORDERED>).  A frame's launch ends when its slowest packet does, and a packet is
+// one dependent chain of fetches: the frame before tells which chunks of ray ids (W.chunk / W.chunk_shadow consecutive
+// ids: the rays of one packet, or two) were heavy, and those are handed out FIRST -- and, in frames with few packets
+// per wave slot, cut into parts that different waves walk.  Who walks with whom never changes a ray's result, so the
+// pixels do not depend on any of this.  One set per walk (0 primary, 1 shadow).
+constexpr int kOrderClasses = 4;
+struct OrderParams {
+    uint32_t *cost_out;               // [chunks] fetches (QuadNodes + triangle records) this frame's packets of a chunk make
+    const uint8_t *listed;            // [chunks] 1: the chunk is on a heavy list, the run over all chunks skips it
+    const uint4 *list;                // [kOrderClasses][cap] the heavy lists, class 0 (heaviest) first: {first id within
+                                      //          the light, ids, light (shadow walk), chunk}; x = ~0: an entry nobody wrote
+    const uint32_t *count;            // [kOrderClasses] entries per class (may run past cap: the reader clamps)
+    unsigned long long *totals_out;   // [64 slots][2] {fetches, packets} of this frame, summed by the next frame's ct_order_build
+    uint32_t cap;
+    uint32_t chunk_shift;             // log2 of the walk's chunk (ORDERED needs a power of two)
+    uint32_t chunks_per_light;
+};
+
 // Buffers and knobs of the wavefront pipeline (ct_pipeline.hip); all pointers are device memory.
 struct PipelineParams {
     float2   *coords;            // [n_samples] jittered canvas position (supersampled frames)
@@ -111,6 +133,25 @@ struct PipelineParams {
     uint32_t list_slots;         // 1: ray_hits[].triangle receives the TriRecord SLOT (kNoNode: none recorded), not the scene triangle
     uint32_t list_counter;       // frame counter word the walk adds its ray count to (0: none; 1 shadow rays, 2 reflected rays)
     const uint32_t *list_gate;   // when set and *list_gate == 0 the list holds no ray: the walk's waves leave at once
+    uint32_t ordered;            // 1: the frame's packet walks are the ORDERED instantiations, order[] is set
+    OrderParams order[2];
+};
+
+// ct_order_build's arguments for one walk: last frame's costs in, this frame's heavy lists out
+struct OrderBuild {
+    const uint32_t *prev_cost;                // [chunks]
+    const unsigned long long *prev_totals;    // [64][2]
+    uint8_t  *listed;                         // [chunks]
+    uint4    *list;                           // [kOrderClasses][cap]
+    uint32_t *count;                          // [kOrderClasses], zero on entry (the build of the frame before, or a memset, left it so)
+    uint32_t *next_count;                     // [kOrderClasses] the next frame's, zeroed here
+    uint32_t *cost_out;                       // [chunks] this frame's cost words, zeroed here
+    unsigned long long *totals_out;           // [64][2] this frame's totals, zeroed here
+    uint32_t chunks, cap, chunk_shift, chunks_per_light;
+    uint32_t parts[kOrderClasses];            // parts a chunk of class k is cut into (1: handed out whole, but early)
+    float    heavy[kOrderClasses];            // a chunk is of class k from this many times the mean packet's fetches (descending)
+    uint32_t floor;                           // ... and never below this many fetches
+    uint64_t n_samples;
 };
 
 // Reflection bounces on the wavefront pipeline: level 0 is the camera ray's hit, level k the k-th reflected ray's
@@ -138,7 +179,7 @@ int  pipeline_walk_occupancy(size_t lds_bytes);
 int  pipeline_packet_occupancy(uint32_t depth, uint32_t lds_levels);
 constexpr int kPipelineKernels = 5;      // ct_sample_grid, primary walk, ct_light_gate, shadow walk, ct_shade
 void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hipStream_t stream, hipEvent_t *marks,
-                     const BounceParams *bounce = nullptr);
+                     const BounceParams *bounce = nullptr, const OrderBuild *order = nullptr);
 void launch_packet_ray_list(const FrameParams &P, const PipelineParams &W, bool any_hit, hipStream_t stream);
 
 void launch_trace_tiles(const FrameParams &P, uint32_t n_tiles, bool ss, bool reflect, bool count, hipStream_t stream);

@@ -83,10 +83,11 @@ __device__ __forceinline__ PixelOfSample pixel_of(const FrameParams &P, uint64_t
         r.local_row = row * 2u + (within >> 1);
     } else {
         r.sample = 0;
+        // (inside the tile in Z order: 4 consecutive ids are 2x2 pixels, 16 are 4x4 -- the parts a heavy tile is cut into)
         const uint32_t within = (uint32_t)(id & 63u), tile = (uint32_t)(id >> 6);
         small_divmod(tile, (P.square + 7u) >> 3, row, col);
-        r.xi = col * 8u + (within & 7u);
-        r.local_row = row * 8u + (within >> 3);
+        r.xi = col * 8u + ((within & 1u) | ((within >> 1) & 2u) | ((within >> 2) & 4u));
+        r.local_row = row * 8u + (((within >> 1) & 1u) | ((within >> 2) & 2u) | ((within >> 3) & 4u));
     }
     return r;
 }
@@ -739,7 +740,9 @@ extern "C" __attribute__((visibility("default"))) int ctgpu_debug_packet_trace(u
 // HANDOVER: the instantiation that may give a packet's rays up to the per-lane kernel (W.packet_budget; an experiment
 // that is off by default -- it is a template parameter because the bookkeeping alone, compiled in but switched off,
 // cost the primary walk 12 % through register pressure: profiles/r03_handover_sweep.log).
-template <int KIND, bool SS, bool HANDOVER = false>
+// ORDERED: chunks the frame before found heavy come first, in parts where that frame's packets were few (ct_params.h,
+// OrderParams), then every other chunk in the usual order; each packet adds its fetches to its chunk's cost word.
+template <int KIND, bool SS, bool HANDOVER = false, bool ORDERED = false>
 __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const FrameParams P, const PipelineParams W) {
     const uint32_t q_chunk = (KIND == 1) ? W.chunk_shadow : W.chunk;      // ray ids per queue atomic
     constexpr bool LIST = KIND >= 2;                 // rays come from W.ray_list instead of the frame's samples
@@ -785,6 +788,9 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
     uint32_t n_handed = 0;                         // rays given to the per-lane walk (their packets had stopped sharing)
     bool list_full = false;
     const uint32_t budget = (HANDOVER && !LIST) ? W.packet_budget : 0u;
+    // ORDERED: which heavy class is being handed out (2: none left, the run over all chunks), the current chunk's and
+    // the packet's cost word, and the wave's fetch count when the packet began
+    uint32_t order_phase = ORDERED ? 0u : 2u, order_at = blockIdx.x, chunk_cost_at = 0, cost_at = 0, cost_mark = 0;
 #ifdef CT_WALK_STATS
     unsigned long long pk_n[6] = {0, 0, 0, 0, 0, 0}, pk_cyc[3] = {0, 0, 0};
     const unsigned long long pk_begin = __builtin_amdgcn_s_memtime();
@@ -807,6 +813,34 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
             const unsigned long long m_i = __ballot(!has_ray);
             if (m_i == 0ull || wave_drained) break;
             if (chunk_next >= chunk_end) {
+                if (ORDERED && order_phase < 2u) {
+                    // the heavy lists, heaviest class first, as one sequence of which wave b takes entries b, b + grid, ...
+                    // (no queue: every wave of the launch asking one head word for a ticket costs more than the lists save)
+                    const OrderParams &O = W.order[KIND == 0 ? 0 : 1];
+                    uint32_t at = order_at, cls = 0;
+                    for (; cls < (uint32_t)kOrderClasses; cls++) {
+                        uint32_t listed_entries = (uint32_t)__builtin_amdgcn_readfirstlane((int)O.count[cls]);
+                        if (listed_entries > O.cap) listed_entries = O.cap;
+                        if (at < listed_entries) break;
+                        at -= listed_entries;
+                    }
+                    if (cls == (uint32_t)kOrderClasses) { order_phase = 2u; continue; }
+                    order_at += gridDim.x;
+                    const uint4 e = O.list[(size_t)cls * O.cap + at];
+                    const uint32_t e_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.x), e_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.y);
+                    const uint32_t e_light = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.z);
+                    if (e_lo == ~0u || e_lo >= n_samples || e_light >= (KIND == 1 ? W.n_shadow_lights : 1u)) continue;
+                    uint64_t hi = (uint64_t)e_lo + e_n;
+                    if (hi > n_samples) hi = n_samples;
+                    chunk_light_base = (uint64_t)e_light * n_samples;
+                    chunk_next = chunk_light_base + e_lo;
+                    chunk_end = chunk_light_base + hi;
+                    chunk_cost_at = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.w);
+                    if (KIND == 1) chunk_light_index = (uint32_t)__builtin_amdgcn_readfirstlane((int)W.shadow_lights[e_light]);
+                    if (KIND == 1 && m_i != ~0ull) break;
+                    goto chunk_ready;
+                }
+                {
                 unsigned long long offset = 0;
                 if (lane == 0) offset = atomicAdd(heads + (size_t)shard * 16u, (unsigned long long)q_chunk);
                 offset = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)offset) |
@@ -819,6 +853,11 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                     if (shards_done >= n_shards) wave_drained = true;
                     continue;
                 }
+                if (ORDERED) {
+                    const OrderParams &O = W.order[KIND == 0 ? 0 : 1];
+                    chunk_cost_at = light * O.chunks_per_light + (uint32_t)(lo >> O.chunk_shift);
+                    if (__builtin_amdgcn_readfirstlane((int)O.listed[chunk_cost_at]) != 0) continue;      // went out with the heavy lists
+                }
                 uint64_t hi = lo + q_chunk;
                 if (hi > ((uint64_t)part + 1u) * shard_span) hi = ((uint64_t)part + 1u) * shard_span;
                 if (hi > n_samples) hi = n_samples;
@@ -830,7 +869,9 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                 // this wave gets lies elsewhere in the image: topping up from it was measured, 5 % slower --
                 // it splits that chunk's rays over two packets, i.e. two walks through that region)
                 if (KIND == 1 && m_i != ~0ull) break;
+                }
             }
+chunk_ready:
             const uint64_t avail = chunk_end - chunk_next;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_i >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_i, 0u));
             const bool take = !has_ray && rank < avail;
@@ -838,6 +879,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
             if (KIND == 0) packet_base = chunk_next;      // every lane is free here: rank == lane
             light_base = chunk_light_base;                // (the packet's light: it only ever takes from chunks of one)
             light_index = chunk_light_index;
+            if (ORDERED) cost_at = chunk_cost_at;
             const uint64_t wanted = (uint64_t)__popcll(m_i);
             chunk_next += (wanted < avail) ? wanted : avail;
             // phase 1 (may run several times for a shadow packet): which ids become rays.  A shadow ray
@@ -866,6 +908,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
             continue;
         }
         n_packets += 1;
+        if (ORDERED) cost_mark = n_quads + n_records;
 #ifdef CT_PACKET_TRACE
         const unsigned long long trace_begin = wall_clock64();
         const uint32_t trace_quads = n_quads, trace_records = n_records;
@@ -1217,6 +1260,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
             }
         }
 #endif
+        if (ORDERED && lane == 0) atomicAdd(W.order[KIND == 0 ? 0 : 1].cost_out + cost_at, n_quads + n_records - cost_mark);
         if (KIND == 1) {
             const unsigned long long rays = __ballot(has_ray), blocked = __ballot(has_ray && t != kNoHit);
             n_blocked += (uint32_t)__popcll(blocked);
@@ -1252,6 +1296,11 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
         atomicAdd(work + 1, (unsigned long long)n_quads);
         atomicAdd(work + 2, (unsigned long long)n_records);
         if (n_handed) atomicAdd(&P.counters[KIND == 0 ? 17 : 18], (unsigned long long)n_handed);
+        if (ORDERED) {
+            unsigned long long *totals = W.order[KIND == 0 ? 0 : 1].totals_out + (size_t)(blockIdx.x & 63u) * 2u;
+            atomicAdd(totals + 0, (unsigned long long)(n_quads + n_records));
+            atomicAdd(totals + 1, (unsigned long long)n_packets);
+        }
         if (KIND == 1) {
             atomicAdd(W.walk_work + (size_t)(blockIdx.x & 63u) * 8u + 6u, (unsigned long long)n_blocked);
             atomicAdd(W.walk_work + (size_t)(blockIdx.x & 63u) * 8u + 7u, (unsigned long long)n_all_blocked);
@@ -1718,8 +1767,64 @@ int pipeline_packet_occupancy(uint32_t depth, uint32_t lds_levels) {
     return a < b ? a : b;
 }
 
+// ct_order_build: the heavy lists of this frame's two packet walks from the costs the frame before left (blockIdx.y:
+// the walk).  A chunk is heavy when its packets made `heavy[class]` times the mean packet's fetches (and at least
+// `floor`); it goes on its class's list in `parts[class]` pieces and is marked, so that the run over all chunks skips it.
+// A list that is full leaves the chunk where it was (and a sentinel in the slots it had drawn, if any lie below the end).
+__global__ __launch_bounds__(256) void ct_order_build(const OrderBuild primary, const OrderBuild shadow) {
+    const OrderBuild &A = blockIdx.y == 0 ? primary : shadow;
+    // last frame's totals: [64 slots][2] -> {fetches, packets} (lanes of equal parity add up; two waves hold the 128 words)
+    __shared__ unsigned long long sums[2][2];
+    if (threadIdx.x < 128) {
+        unsigned long long v = A.prev_totals[threadIdx.x];
+        for (int off = 2; off < 64; off <<= 1) v += __shfl_xor(v, off);
+        if ((threadIdx.x & 63u) < 2u) sums[threadIdx.x >> 6][threadIdx.x & 1u] = v;
+    }
+    __syncthreads();
+    const unsigned long long fetches = sums[0][0] + sums[1][0], packets = sums[0][1] + sums[1][1];
+    // (what the walks of THIS frame add to starts from zero; so do the list counters of the next frame's build)
+    if (blockIdx.x == 0 && threadIdx.x < 128) A.totals_out[threadIdx.x] = 0ull;
+    if (blockIdx.x == 0 && threadIdx.x < kOrderClasses) A.next_count[threadIdx.x] = 0u;
+    const uint32_t c = blockIdx.x * 256u + threadIdx.x;
+    const bool there = c < A.chunks;
+    if (there) A.cost_out[c] = 0u;
+    const float mean = packets ? (float)fetches / (float)packets : 0.0f;
+    const uint32_t cost = there ? A.prev_cost[c] : 0u;
+    int cls = kOrderClasses;
+    if (there && mean > 0.0f && cost >= A.floor)
+        for (cls = 0; cls < kOrderClasses; cls++)
+            if ((float)cost >= A.heavy[cls] * mean) break;
+    uint8_t listed = 0;
+    // (list slots are drawn once per wave and class -- thousands of single atomics on one word would take longer than
+    //  the walk -- and the four classes' draws go out together, from lanes 0..3)
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long m_mine = 0ull, m_lane = 0ull;
+    for (int k = 0; k < kOrderClasses; k++) {
+        const unsigned long long m = __ballot(cls == k);
+        if (cls == k) m_mine = m;
+        if (lane == (uint32_t)k) m_lane = m;
+    }
+    uint32_t drawn = 0;
+    if (lane < (uint32_t)kOrderClasses && m_lane != 0ull) drawn = atomicAdd(A.count + lane, (uint32_t)__popcll(m_lane) * A.parts[lane]);
+    const uint32_t base = __shfl(drawn, cls < kOrderClasses ? cls : 0);
+    const uint32_t at = base + (uint32_t)__popcll(m_mine & ((1ull << lane) - 1ull)) * (cls < kOrderClasses ? A.parts[cls] : 0u);
+    if (cls < kOrderClasses) {
+        const uint32_t parts = A.parts[cls];
+        uint4 *list = A.list + (size_t)cls * A.cap;
+        if ((uint64_t)at + parts <= A.cap) {
+            const uint32_t light = c / A.chunks_per_light, within = c - light * A.chunks_per_light;
+            const uint32_t ids = (1u << A.chunk_shift) / parts, first = within << A.chunk_shift;
+            for (uint32_t k = 0; k < parts; k++) list[at + k] = make_uint4(first + k * ids, ids, light, c);
+            listed = 1;
+        } else {
+            for (uint32_t k = 0; k < parts && (uint64_t)at + k < A.cap; k++) list[at + k] = make_uint4(~0u, 0u, 0u, 0u);
+        }
+    }
+    if (there) A.listed[c] = listed;
+}
+
 void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hipStream_t stream, hipEvent_t *marks,
-                     const BounceParams *bounce) {
+                     const BounceParams *bounce, const OrderBuild *order) {
     if (W.n_samples == 0) return;
     // marks (optional, kPipelineKernels + 1 events): one before each kernel and one after the last, so that the
     // time between marks k and k+1 is kernel k's (ctgpu_kernel_timing)
@@ -1745,6 +1850,11 @@ void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hip
     };
     mark(0);
     if (ss) hipLaunchKernelGGL(ct_sample_grid, dim3(pixel_blocks), dim3(256), 0, stream, P, W);
+    const bool ordered = W.ordered != 0u && order != nullptr;
+    if (ordered) {      // (booked on ct_sample_grid's mark)
+        const uint32_t most = std::max(order[0].chunks, shadows ? order[1].chunks : 0u);
+        hipLaunchKernelGGL(ct_order_build, dim3((most + 255u) / 256u, shadows ? 2u : 1u), dim3(256), 0, stream, order[0], order[1]);
+    }
     mark(1);
     const dim3 grid(W.walk_blocks), wave(kWave);
     if (W.packet) {
@@ -1756,8 +1866,10 @@ void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hip
         const size_t lds_l = (size_t)W.lds_depth * kWave * 12u;
         const dim3 grid_l(W.listed_blocks);
         const bool handover = W.packet_budget != 0u;
-        if (ss && !handover) hipLaunchKernelGGL((ct_walk_packet<0, true>), grid, wave, lds_p, stream, P, W);
-        if (!ss && !handover) hipLaunchKernelGGL((ct_walk_packet<0, false>), grid, wave, lds_p, stream, P, W);
+        if (ss && !handover && !ordered) hipLaunchKernelGGL((ct_walk_packet<0, true>), grid, wave, lds_p, stream, P, W);
+        if (!ss && !handover && !ordered) hipLaunchKernelGGL((ct_walk_packet<0, false>), grid, wave, lds_p, stream, P, W);
+        if (ss && !handover && ordered) hipLaunchKernelGGL((ct_walk_packet<0, true, false, true>), grid, wave, lds_p, stream, P, W);
+        if (!ss && !handover && ordered) hipLaunchKernelGGL((ct_walk_packet<0, false, false, true>), grid, wave, lds_p, stream, P, W);
         if (ss && handover) hipLaunchKernelGGL((ct_walk_packet<0, true, true>), grid, wave, lds_p, stream, P, W);
         if (!ss && handover) hipLaunchKernelGGL((ct_walk_packet<0, false, true>), grid, wave, lds_p, stream, P, W);
         if (handover && ss) hipLaunchKernelGGL((ct_walk<0, true, true>), grid_l, wave, lds_l, stream, P, W);
@@ -1766,8 +1878,10 @@ void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hip
         mark(2);
         if (shadows) light_gate();
         mark(3);
-        if (shadows && ss && !handover) hipLaunchKernelGGL((ct_walk_packet<1, true>), grid, wave, lds_p, stream, P, W);
-        if (shadows && !ss && !handover) hipLaunchKernelGGL((ct_walk_packet<1, false>), grid, wave, lds_p, stream, P, W);
+        if (shadows && ss && !handover && !ordered) hipLaunchKernelGGL((ct_walk_packet<1, true>), grid, wave, lds_p, stream, P, W);
+        if (shadows && !ss && !handover && !ordered) hipLaunchKernelGGL((ct_walk_packet<1, false>), grid, wave, lds_p, stream, P, W);
+        if (shadows && ss && !handover && ordered) hipLaunchKernelGGL((ct_walk_packet<1, true, false, true>), grid, wave, lds_p, stream, P, W);
+        if (shadows && !ss && !handover && ordered) hipLaunchKernelGGL((ct_walk_packet<1, false, false, true>), grid, wave, lds_p, stream, P, W);
         if (shadows && ss && handover) hipLaunchKernelGGL((ct_walk_packet<1, true, true>), grid, wave, lds_p, stream, P, W);
         if (shadows && !ss && handover) hipLaunchKernelGGL((ct_walk_packet<1, false, true>), grid, wave, lds_p, stream, P, W);
         if (shadows && handover && ss) hipLaunchKernelGGL((ct_walk<1, true, true>), grid_l, wave, lds_l, stream, P, W);
@@ -1805,7 +1919,7 @@ void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hip
     // the list walks: the packet walk's caller-list kinds over the frame's own ray arrays, 64 consecutive ids a packet
     const uint32_t depth_p = W.packet_depth;
     const size_t lds_p = PacketStack::bytes(depth_p, W.packet_lds_levels < depth_p ? W.packet_lds_levels : depth_p);
-    const size_t queue_bytes = (queue_words(W.n_shadow_lights) + 32) * sizeof(unsigned long long);
+    const size_t queue_bytes = queue_block_words(W.n_shadow_lights) * sizeof(unsigned long long);
     PipelineParams Wc = W;                       // closest hit over the reflected rays
     Wc.ray_list = B.rays; Wc.ray_hits = B.hits; Wc.ray_live = B.live; Wc.list_slots = 1u; Wc.list_counter = 2u;
     PipelineParams Ws = W;                       // any hit over their shadow rays, [light][sample]

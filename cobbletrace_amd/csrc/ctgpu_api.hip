@@ -169,6 +169,32 @@ struct ctgpu_ctx {
         unsigned long long packets = 0, fetches = 0;        // walk_work totals at the last look (they only grow between reads)
     } choice[2];
     bool force_megakernel = false;
+    // Heavy chunks first (OrderParams, ct_params.h): what the packets of each chunk of ray ids cost in the frame before
+    // decides the order -- and, in frames with few packets per wave, the size -- in which this frame hands them out.
+    // CTGPU_ORDER=0 turns it off; CTGPU_ORDER_HEAVY="a,b,floor": class 0 / 1 from a / b times the mean packet's fetches.
+    bool order_on = true, order_always = false;         // (CTGPU_ORDER=2: also frames whose heavy chunks are not cut up)
+    float order_heavy[kOrderClasses] = {8.0f, 4.0f, 2.0f, 1.0f};
+    int order_floor = 64;
+    int order_parts[kOrderClasses] = {4, 2, 1, 1};      // parts a heavy chunk of class k is cut into (frames with few packets per wave)
+    int order_split_below = 8;                  // chunks per wave of the grid below which heavy chunks are cut into parts
+    struct OrderHistory {
+        uint64_t key[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the frame geometry the costs belong to
+        bool valid = false, last_split = false;
+        int parity = 0;                         // cost[parity] is written by the next frame, cost[parity ^ 1] read
+        DeviceArray<uint32_t> cost[2][2];       // [parity][walk]
+        DeviceArray<unsigned long long> totals[2];      // [parity]: [walk][64][2]
+        DeviceArray<uint8_t> listed[2];
+        DeviceArray<uint4> list[2];
+        DeviceArray<uint32_t> count;            // [walk][2]
+        void release() {
+            for (int a = 0; a < 2; a++) {
+                for (int b = 0; b < 2; b++) cost[a][b].release();
+                totals[a].release(); listed[a].release(); list[a].release();
+            }
+            count.release();
+            valid = false;
+        }
+    } order;
 
     ctgpu_comm_state *comm = nullptr;           // ctgpu_comm_init: this rank's RCCL communicator
     std::vector<void *> multi_comms;            // ctgpu_render_multi: one communicator per device, kept by the root context
@@ -287,9 +313,23 @@ static int create_resources(ctgpu_ctx *ctx) {
     if (const char *t = std::getenv("CTGPU_PACKET_LDS_LEVELS")) ctx->packet_lds_levels = std::max(1, std::atoi(t));
     if (const char *t = std::getenv("CTGPU_FORCE_MEGAKERNEL")) ctx->force_megakernel = std::atoi(t) != 0;
     if (const char *t = std::getenv("CTGPU_BOUNCE")) { ctx->bounce_on_pipeline = std::atoi(t) != 0; ctx->bounce_auto = false; }
+    if (const char *t = std::getenv("CTGPU_ORDER")) { ctx->order_on = std::atoi(t) != 0; ctx->order_always = std::atoi(t) == 2; }
+    if (const char *t = std::getenv("CTGPU_ORDER_HEAVY")) {
+        float v[kOrderClasses];
+        if (std::sscanf(t, "%f,%f,%f,%f", &v[0], &v[1], &v[2], &v[3]) == kOrderClasses && v[0] >= v[1] && v[1] >= v[2] && v[2] >= v[3] && v[3] > 0.0f)
+            for (int k = 0; k < kOrderClasses; k++) ctx->order_heavy[k] = v[k];
+    }
+    if (const char *t = std::getenv("CTGPU_ORDER_FLOOR")) ctx->order_floor = std::max(0, std::atoi(t));
+    if (const char *t = std::getenv("CTGPU_ORDER_SPLIT_BELOW")) ctx->order_split_below = std::max(0, std::atoi(t));
+    if (const char *t = std::getenv("CTGPU_ORDER_PARTS")) {
+        int v[kOrderClasses];
+        const auto ok = [](int x) { return x == 1 || x == 2 || x == 4 || x == 8 || x == 16; };
+        if (std::sscanf(t, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == kOrderClasses && ok(v[0]) && ok(v[1]) && ok(v[2]) && ok(v[3]))
+            for (int k = 0; k < kOrderClasses; k++) ctx->order_parts[k] = v[k];
+    }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->cu_count = prop.multiProcessorCount;
-    HIP_TRY(ctx->queue.resize(queue_words(32) + 32));        // (grows with the scene's light count, fill_pipeline)
+    HIP_TRY(ctx->queue.resize(queue_block_words(32)));       // (grows with the scene's light count, fill_pipeline)
     HIP_TRY(ctx->walk_work.resize(64 * 8));
     HIP_TRY(hipMemset(ctx->walk_work.ptr, 0, 64 * 8 * sizeof(unsigned long long)));
     return CTGPU_OK;
@@ -336,6 +376,7 @@ extern "C" void ctgpu_destroy(ctgpu_ctx *ctx) {
     ctx->b_rays.release(); ctx->b_shadow_rays.release(); ctx->b_hits.release(); ctx->b_shadow_hits.release();
     ctx->b_live.release(); ctx->b_shadow_live.release(); ctx->b_pending.release(); ctx->b_local.release();
     ctx->b_terminal.release(); ctx->b_refl.release(); ctx->b_level_live.release();
+    ctx->order.release();
     for (hipEvent_t e : ctx->marks) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->phase_marks) (void)hipEventDestroy(e);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -933,6 +974,78 @@ bool pipeline_eligible(const ctgpu_ctx *ctx, const ctgpu_frame_desc *f) {
 
 int fill_pipeline(ctgpu_ctx *ctx, uint64_t n_samples, PipelineParams &W, int kind = -1);
 
+// Heavy chunks first: buffers, history and the arguments of ct_order_build for this frame (W.ordered = 1), or nothing
+// (W.ordered = 0: per-lane walk, hand-over experiment, a chunk size that is no power of two, CTGPU_ORDER=0).
+// The costs belong to one frame geometry on one partition; any other frame starts from "nothing is heavy".
+int setup_order(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, const FrameParams &P, PipelineParams &W, OrderBuild order[2], hipStream_t stream,
+                hipEvent_t begin) {
+    W.ordered = 0;
+    const auto pow2 = [](uint32_t v) { return v != 0 && (v & (v - 1)) == 0; };
+    if (!ctx->order_on || !W.packet || W.packet_budget || !pow2(W.chunk) || !pow2(W.chunk_shadow)) return CTGPU_OK;
+    ctgpu_ctx::OrderHistory &H = ctx->order;
+    const uint32_t chunk[2] = {W.chunk, W.chunk_shadow};
+    uint32_t per_light[2], chunks[2];
+    for (int w = 0; w < 2; w++) {
+        per_light[w] = (uint32_t)((W.n_samples + chunk[w] - 1) / chunk[w]);
+        const uint64_t all = (uint64_t)per_light[w] * (w == 0 ? 1u : std::max<uint32_t>(W.n_shadow_lights, 1));
+        if (all >= (1ull << 31)) return CTGPU_OK;
+        chunks[w] = (uint32_t)all;
+    }
+    const uint64_t key[8] = {W.n_samples, ((uint64_t)W.chunk << 32) | W.chunk_shadow, W.n_shadow_lights,
+                             ((uint64_t)P.part_index << 32) | P.part_count, ((uint64_t)(uint32_t)f->width << 32) | (uint32_t)f->height,
+                             ((uint64_t)f->flags << 32) | P.tile_rows, (uint64_t)(uintptr_t)ctx->scene.get(), P.rows_per_band};
+    // few packets per wave of the grid: the launch is as long as its heaviest packet -- cut the heavy ones up
+    const bool split = (uint64_t)chunks[0] < (uint64_t)ctx->order_split_below * W.walk_blocks;
+    H.last_split = split;
+    if (!split && !ctx->order_always) return CTGPU_OK;          // (a frame with many packets per wave: measured, the order alone only costs)
+    const bool same = H.valid && std::memcmp(key, H.key, sizeof key) == 0;
+    for (int w = 0; w < 2; w++) {
+        for (int par = 0; par < 2; par++) HIP_TRY(H.cost[par][w].resize(chunks[w]));
+        HIP_TRY(H.listed[w].resize(chunks[w]));
+        HIP_TRY(H.list[w].resize((size_t)kOrderClasses * std::max<uint32_t>(chunks[w], 4096u)));
+    }
+    for (int par = 0; par < 2; par++) HIP_TRY(H.totals[par].resize(2 * 64 * 2));
+    HIP_TRY(H.count.resize(2 * 2 * kOrderClasses));             // [parity][walk][class]
+    const int cur = H.parity, prev = H.parity ^ 1;
+    if (begin) HIP_TRY(hipEventRecord(begin, stream));           // (the frame's work starts here: see launch_frame)
+    if (!same) {          // nothing is known about this frame: no chunk is heavy, and no build has zeroed this frame's counters
+        for (int w = 0; w < 2; w++) HIP_TRY(hipMemsetAsync(H.cost[prev][w].ptr, 0, (size_t)chunks[w] * sizeof(uint32_t), stream));
+        HIP_TRY(hipMemsetAsync(H.totals[prev].ptr, 0, 2 * 64 * 2 * sizeof(unsigned long long), stream));
+        HIP_TRY(hipMemsetAsync(H.count.ptr, 0, 2 * 2 * kOrderClasses * sizeof(uint32_t), stream));
+        std::memcpy(H.key, key, sizeof key);
+        H.valid = true;
+    }
+    for (int w = 0; w < 2; w++) {
+        uint32_t shift = 0;
+        while ((1u << shift) < chunk[w]) shift++;
+        const uint32_t cap = std::max<uint32_t>(chunks[w], 4096u);
+        OrderBuild &B = order[w];
+        std::memset(&B, 0, sizeof B);
+        B.prev_cost = H.cost[prev][w].ptr;
+        B.prev_totals = H.totals[prev].ptr + (size_t)w * 128;
+        B.listed = H.listed[w].ptr;
+        B.list = H.list[w].ptr;
+        B.count = H.count.ptr + (size_t)(cur * 2 + w) * kOrderClasses;
+        B.next_count = H.count.ptr + (size_t)(prev * 2 + w) * kOrderClasses;
+        B.cost_out = H.cost[cur][w].ptr;
+        B.totals_out = H.totals[cur].ptr + (size_t)w * 128;
+        B.chunks = chunks[w]; B.cap = cap; B.chunk_shift = shift; B.chunks_per_light = per_light[w];
+        for (int k = 0; k < kOrderClasses; k++) {
+            B.parts[k] = split ? (uint32_t)ctx->order_parts[k] : 1u;
+            B.heavy[k] = ctx->order_heavy[k];
+        }
+        B.floor = (uint32_t)ctx->order_floor;
+        B.n_samples = W.n_samples;
+        OrderParams &O = W.order[w];
+        O.cost_out = H.cost[cur][w].ptr;
+        O.listed = B.listed; O.list = B.list; O.count = B.count;
+        O.totals_out = H.totals[cur].ptr + (size_t)w * 128;
+        O.cap = cap; O.chunk_shift = shift; O.chunks_per_light = per_light[w];
+    }
+    W.ordered = 1;
+    return CTGPU_OK;
+}
+
 // `begin` (optional): recorded on the stream right before the frame's first launch -- after the buffers have been
 // sized, so that a context's first frame of a size does not count its hipMallocs as kernel time
 int launch_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, FrameParams &P, hipStream_t stream, hipEvent_t begin = nullptr) {
@@ -969,8 +1082,10 @@ int launch_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, FrameParams &P, hipS
         B.max_depth = (uint32_t)f->max_depth;
         B.bounce_t = (f->flags & CTGPU_F_REFLECT_FIX) ? kNoHit : 0.0f;
     }
-    if (begin) HIP_TRY(hipEventRecord(begin, stream));
-    HIP_TRY(hipMemsetAsync(ctx->queue.ptr, 0, (queue_words(W.n_shadow_lights) + 32) * sizeof(unsigned long long), stream));
+    OrderBuild order[2];
+    rc = setup_order(ctx, f, P, W, order, stream, begin); if (rc) return rc;
+    if (begin && !W.ordered) HIP_TRY(hipEventRecord(begin, stream));
+    HIP_TRY(hipMemsetAsync(ctx->queue.ptr, 0, queue_block_words(W.n_shadow_lights) * sizeof(unsigned long long), stream));
     hipEvent_t *marks = nullptr;
     if (ctx->kernel_timing) {
         const size_t need = ctx->marks_used + kPipelineKernels + 1;
@@ -982,8 +1097,9 @@ int launch_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, FrameParams &P, hipS
         marks = ctx->marks.data() + ctx->marks_used;
         ctx->marks_used = need;
     }
-    launch_pipeline(P, W, ss, stream, marks, bounces ? &B : nullptr);
+    launch_pipeline(P, W, ss, stream, marks, bounces ? &B : nullptr, W.ordered ? order : nullptr);
     HIP_TRY(hipGetLastError());
+    if (W.ordered) ctx->order.parity ^= 1;
     return CTGPU_OK;
 }
 
@@ -1033,7 +1149,7 @@ int fill_pipeline(ctgpu_ctx *ctx, uint64_t n_samples, PipelineParams &W, int kin
     // hand-over lists: room for half of the frame's primary rays and half of its possible shadow rays
     W.packet_budget = W.packet ? (uint32_t)ctx->packet_budget : 0u;
     W.packet_lanes = (uint32_t)ctx->packet_lanes;
-    HIP_TRY(ctx->queue.resize(queue_words(W.n_shadow_lights) + 32));
+    HIP_TRY(ctx->queue.resize(queue_block_words(W.n_shadow_lights)));
     W.queue = ctx->queue.ptr;
     W.handed = ctx->queue.ptr + queue_words(W.n_shadow_lights);
     W.handed_room = 0;
@@ -1478,7 +1594,7 @@ extern "C" int ctgpu_trace_rays_packet(ctgpu_ctx *ctx, const ctgpu_ray *rays, ui
     hipError_t e = hipMalloc((void **)&d_hits, n * sizeof(ctgpu_hit));
     if (e != hipSuccess) { (void)hipFree(d_rays); return ctgpu_fail(CTGPU_ERR_HIP, "hipMalloc: %s", hipGetErrorString(e)); }
     e = hipMemcpy(d_rays, rays, n * sizeof(ctgpu_ray), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemsetAsync(ctx->queue.ptr, 0, (queue_words(W.n_shadow_lights) + 32) * sizeof(unsigned long long), ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(ctx->queue.ptr, 0, queue_block_words(W.n_shadow_lights) * sizeof(unsigned long long), ctx->stream);
     if (e == hipSuccess) {
         W.ray_list = d_rays;
         W.ray_hits = d_hits;
@@ -1528,6 +1644,18 @@ extern "C" int ctgpu_walk_choice(ctgpu_ctx *ctx, int supersampled, int *per_lane
     if (per_lane) *per_lane = ctx->walk_auto ? (c.use_lane ? 1 : 0) : (ctx->packet_walk ? 0 : 1);
     if (packet_ms) *packet_ms = c.packet_ms;
     if (lane_ms) *lane_ms = c.lane_ms;
+    return CTGPU_OK;
+}
+
+extern "C" int ctgpu_order_info(ctgpu_ctx *ctx, uint32_t entries[8], int *split) {
+    if (!ctx || !entries || !split) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_order_info: null argument");
+    static_assert(kOrderClasses == 4, "ctgpu_order_info reports four classes per walk");
+    for (int k = 0; k < 8; k++) entries[k] = 0;
+    *split = ctx->order.last_split ? 1 : 0;
+    if (!ctx->order.valid || !ctx->order.count.ptr) return CTGPU_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipMemcpy(entries, ctx->order.count.ptr + (size_t)(ctx->order.parity ^ 1) * 2 * kOrderClasses, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
     return CTGPU_OK;
 }
 

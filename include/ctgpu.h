@@ -189,6 +189,7 @@ int  ctgpu_device_count(int *count);
  *   CTGPU_PACKET_LDS_LEVELS, CTGPU_LDS_DEPTH   stack levels kept in LDS (deeper ones go to HBM)
  *   CTGPU_FORCE_MEGAKERNEL   1: the general path (one kernel, reflection capable) for every frame
  *   CTGPU_PACK           host: re-lay-out an uploaded tree on the host (default: on the device)
+ *   CTGPU_ORDER, CTGPU_ORDER_HEAVY, CTGPU_ORDER_SPLIT_BELOW   heavy chunks first (ctgpu_order_info)
  *   CTGPU_BOUNCE         frames whose materials reflect: 1 the bounce levels on the wavefront pipeline, 0 the general
  *                        path's one kernel (unset: whichever was measured faster, ctgpu_bounce_choice) */
 int  ctgpu_create(int device, ctgpu_ctx **out);
@@ -341,6 +342,16 @@ int  ctgpu_walk_choice(ctgpu_ctx *ctx, int supersampled, int *per_lane, double *
  * general path's one kernel; without CTGPU_BOUNCE in the environment the context renders two frames of a kind on each
  * and keeps the faster (same pixels), trying the other again every 256 frames. */
 int  ctgpu_bounce_choice(ctgpu_ctx *ctx, int supersampled, int *general_path, double *pipeline_ms, double *general_ms);
+/* Heavy chunks first.  The launch of a packet walk ends when its slowest packet does, so each frame notes what the
+ * packets of every chunk of ray ids cost (QuadNode + triangle-record fetches), and the NEXT frame of the same geometry
+ * hands the chunks that were heavy out first -- whole, or, when the frame has few packets per wave (single-sample
+ * frames), cut into 4 or 16 parts that different waves walk.  Same pixels and ray counts whatever the order (who walks
+ * with whom never changes a ray's result); a frame of another size, partition or scene starts from "nothing is heavy".
+ * entries[walk * 2 + class]: list entries the last frame built (walk 0 primary / 1 shadow, class 0 the heaviest);
+ * *split: whether that frame cut its heavy chunks into parts.  Knobs: CTGPU_ORDER=0 off; CTGPU_ORDER_HEAVY="a,b,floor"
+ * class 0 / 1 from a / b times the mean packet's fetches (default 6, 2.5) and never below `floor` fetches (64);
+ * CTGPU_ORDER_SPLIT_BELOW chunks per wave of the grid below which heavy chunks are cut up (8). */
+int  ctgpu_order_info(ctgpu_ctx *ctx, uint32_t entries[8], int *split);
 int  ctgpu_kernel_timing(ctgpu_ctx *ctx, int enable);
 int  ctgpu_read_kernel_times(ctgpu_ctx *ctx, ctgpu_kernel_times *out);
 
