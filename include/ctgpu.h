@@ -347,6 +347,8 @@ int  ctgpu_bounce_choice(ctgpu_ctx *ctx, int supersampled, int *general_path, do
  * hands the chunks that were heavy out first -- whole, or, when the frame has few packets per wave (single-sample
  * frames), cut into 4 or 16 parts that different waves walk.  Same pixels and ray counts whatever the order (who walks
  * with whom never changes a ray's result); a frame of another size, partition or scene starts from "nothing is heavy".
+ * Only frames that have the device to themselves are ordered (ctgpu_render, _begin / _poll, _multi): frames a caller
+ * pipelines on its own streams (ctgpu_render_partition, _sharded) fill each other's tails and are left as they are.
  * entries[walk * 2 + class]: list entries the last frame built (walk 0 primary / 1 shadow, class 0 the heaviest);
  * *split: whether that frame cut its heavy chunks into parts.  Knobs: CTGPU_ORDER=0 off; CTGPU_ORDER_HEAVY="a,b,floor"
  * class 0 / 1 from a / b times the mean packet's fetches (default 6, 2.5) and never below `floor` fetches (64);

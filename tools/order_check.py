@@ -25,7 +25,7 @@ def context(scene, order):
 
 
 for name in (sys.argv[1:] or ["dragon", "bunny"]):
-    scene = ca.HostScene(os.path.join(A, "scene_import_%s.json" % name))
+    scene = ca.HostScene(os.path.join(A, "scene_import.json" if name == "import" else "scene_import_%s.json" % name))
     off, on = context(scene, False), context(scene, True)
     for ss in (False, True):
         f = scene.frame(W, H, supersampling=ss)
