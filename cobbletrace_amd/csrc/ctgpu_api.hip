@@ -173,6 +173,7 @@ struct ctgpu_ctx {
     // decides the order -- and, in frames with few packets per wave, the size -- in which this frame hands them out.
     // CTGPU_ORDER=0 turns it off; CTGPU_ORDER_HEAVY="a,b,floor": class 0 / 1 from a / b times the mean packet's fetches.
     bool order_on = true, order_always = false;         // (CTGPU_ORDER=2: also frames whose heavy chunks are not cut up)
+    bool order_pipelined = false;                       // (CTGPU_ORDER=3: also frames the caller pipelines -- an experiment)
     float order_heavy[kOrderClasses] = {8.0f, 4.0f, 2.0f, 1.0f};
     int order_floor = 64;
     int order_parts[kOrderClasses] = {4, 2, 1, 1};      // parts a heavy chunk of class k is cut into (frames with few packets per wave)
@@ -313,7 +314,7 @@ static int create_resources(ctgpu_ctx *ctx) {
     if (const char *t = std::getenv("CTGPU_PACKET_LDS_LEVELS")) ctx->packet_lds_levels = std::max(1, std::atoi(t));
     if (const char *t = std::getenv("CTGPU_FORCE_MEGAKERNEL")) ctx->force_megakernel = std::atoi(t) != 0;
     if (const char *t = std::getenv("CTGPU_BOUNCE")) { ctx->bounce_on_pipeline = std::atoi(t) != 0; ctx->bounce_auto = false; }
-    if (const char *t = std::getenv("CTGPU_ORDER")) { ctx->order_on = std::atoi(t) != 0; ctx->order_always = std::atoi(t) == 2; }
+    if (const char *t = std::getenv("CTGPU_ORDER")) { ctx->order_on = std::atoi(t) != 0; ctx->order_always = std::atoi(t) == 2; ctx->order_pipelined = std::atoi(t) == 3; }
     if (const char *t = std::getenv("CTGPU_ORDER_HEAVY")) {
         float v[kOrderClasses];
         if (std::sscanf(t, "%f,%f,%f,%f", &v[0], &v[1], &v[2], &v[3]) == kOrderClasses && v[0] >= v[1] && v[1] >= v[2] && v[2] >= v[3] && v[3] > 0.0f)
@@ -1087,7 +1088,7 @@ int launch_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, FrameParams &P, hipS
     }
     OrderBuild order[2];
     W.ordered = 0;
-    if (alone) { rc = setup_order(ctx, f, P, W, order, stream, begin); if (rc) return rc; }
+    if (alone || ctx->order_pipelined) { rc = setup_order(ctx, f, P, W, order, stream, begin); if (rc) return rc; }
     if (begin && !W.ordered) HIP_TRY(hipEventRecord(begin, stream));
     HIP_TRY(hipMemsetAsync(ctx->queue.ptr, 0, queue_block_words(W.n_shadow_lights) * sizeof(unsigned long long), stream));
     hipEvent_t *marks = nullptr;

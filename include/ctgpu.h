@@ -348,7 +348,9 @@ int  ctgpu_bounce_choice(ctgpu_ctx *ctx, int supersampled, int *general_path, do
  * frames), cut into 4 or 16 parts that different waves walk.  Same pixels and ray counts whatever the order (who walks
  * with whom never changes a ray's result); a frame of another size, partition or scene starts from "nothing is heavy".
  * Only frames that have the device to themselves are ordered (ctgpu_render, _begin / _poll, _multi): frames a caller
- * pipelines on its own streams (ctgpu_render_partition, _sharded) fill each other's tails and are left as they are.
+ * pipelines on its own streams (ctgpu_render_partition, _sharded) fill each other's tails and are left as they are
+ * (CTGPU_ORDER=2: order also frames with many packets per wave, whole chunks; =3: also pipelined frames -- both
+ * measured, neither pays: profiles/r03_order_sweep.log).
  * entries[walk * 2 + class]: list entries the last frame built (walk 0 primary / 1 shadow, class 0 the heaviest);
  * *split: whether that frame cut its heavy chunks into parts.  Knobs: CTGPU_ORDER=0 off; CTGPU_ORDER_HEAVY="a,b,floor"
  * class 0 / 1 from a / b times the mean packet's fetches (default 6, 2.5) and never below `floor` fetches (64);
