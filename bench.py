@@ -49,8 +49,8 @@ KERNEL_SOURCES = ("ct_pipeline.hip", "ct_device.h", "ct_params.h", "ct_raygen.h"
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--scene", default="dragon", choices=["dragon", "bunny", "import", "cube"])
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
