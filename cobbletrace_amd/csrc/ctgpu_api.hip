@@ -180,7 +180,7 @@ struct ctgpu_ctx {
     int order_split_below = 8;                  // chunks per wave of the grid below which heavy chunks are cut into parts
     struct OrderHistory {
         uint64_t key[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // the frame geometry the costs belong to
-        bool valid = false, last_split = false;
+        bool valid = false, last_split = false, last_ordered = false;    // (last_*: what the context's latest frame did)
         int parity = 0;                         // cost[parity] is written by the next frame, cost[parity ^ 1] read
         DeviceArray<uint32_t> cost[2][2];       // [parity][walk]
         DeviceArray<unsigned long long> totals[2];      // [parity]: [walk][64][2]
@@ -1058,6 +1058,7 @@ int launch_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, FrameParams &P, hipS
         if (begin) HIP_TRY(hipEventRecord(begin, stream));
         launch_trace_tiles(P, tile_count(P), ss, ctx->scene->has_reflection && f->max_depth > 0, false, stream);
         HIP_TRY(hipGetLastError());
+        ctx->order.last_ordered = false;
         return CTGPU_OK;
     }
     PipelineParams W;
@@ -1105,6 +1106,7 @@ int launch_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, FrameParams &P, hipS
     launch_pipeline(P, W, ss, stream, marks, bounces ? &B : nullptr, W.ordered ? order : nullptr);
     HIP_TRY(hipGetLastError());
     if (W.ordered) ctx->order.parity ^= 1;
+    ctx->order.last_ordered = W.ordered != 0u;
     return CTGPU_OK;
 }
 
@@ -1656,8 +1658,8 @@ extern "C" int ctgpu_order_info(ctgpu_ctx *ctx, uint32_t entries[8], int *split)
     if (!ctx || !entries || !split) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_order_info: null argument");
     static_assert(kOrderClasses == 4, "ctgpu_order_info reports four classes per walk");
     for (int k = 0; k < 8; k++) entries[k] = 0;
-    *split = ctx->order.last_split ? 1 : 0;
-    if (!ctx->order.valid || !ctx->order.count.ptr) return CTGPU_OK;
+    *split = (ctx->order.last_ordered && ctx->order.last_split) ? 1 : 0;
+    if (!ctx->order.last_ordered || !ctx->order.count.ptr) return CTGPU_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     HIP_TRY(hipMemcpy(entries, ctx->order.count.ptr + (size_t)(ctx->order.parity ^ 1) * 2 * kOrderClasses, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));

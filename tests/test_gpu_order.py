@@ -124,6 +124,11 @@ def test_order_is_for_frames_with_few_packets_per_wave(scenes, monkeypatch):
         never.render(small)
         never.render(small)
         assert never.order_info() == ([0] * 8, False)
+        ctx.render(small)
+        ctx.render(small)
+        assert ctx.order_info()[1] and sum(ctx.order_info()[0]) > 0
+        ctx.render(big)                                                       # (the report is about the latest frame)
+        assert ctx.order_info() == ([0] * 8, False)
     finally:
         ctx.close()
         never.close()
