@@ -57,11 +57,25 @@ while time.time() < t_end:
     ctx.upload(scene.desc, build_on_device=bool(seed % 2))     # every other scene: tree built and laid out on the GPU
     angles = [np.float32(a) for a in rng.uniform(-0.6, 0.6, 3)] if rng.random() < 0.5 else [np.float32(0)] * 3
     w, h = int(rng.choice([64, 97, 160])), int(rng.choice([48, 64, 121]))
+    if len(lights) > 30 and n >= 300:
+        w, h = 64, 48             # (36 shadow rays per hit, ten bounces, 16 samples: minutes of oracle time on a larger frame)
     frame = scene.frame(w, h, rotation=oracle.camera_rotation(*angles), rng_seed=seed, spheres=use_spheres,
                         reflect_fix=bool(rng.random() < 0.3), rng_mode=(ca.RNG_LIBC if rng.random() < 0.2 else ca.RNG_HASH))
     if frame.rng_mode == ca.RNG_LIBC:
         frame.rng_seed = int(rng.integers(1, 1000))
     got, st = ctx.render(frame)
+    # the same frame again, twice: from the second frame on the context hands out heavy chunks first (run this tool with
+    # CTGPU_ORDER_HEAVY=0.8,0.6,0.4,0.2 CTGPU_ORDER_FLOOR=1 to have lists on frames this small) -- nothing may change
+    for _ in range(2):
+        again, st2 = ctx.render(frame)
+        # (reflective frames alternate between the bounce levels and the general path while the context measures them:
+        #  only the former leaves out the shadow rays whose answer cannot matter, so traced + left out is what agrees)
+        if not ((again == got).all() and (st2.rays_primary, st2.rays_shadow + st2.rays_shadow_elided, st2.rays_reflect) ==
+                (st.rays_primary, st.rays_shadow + st.rays_shadow_elided, st.rays_reflect)):
+            print("MISMATCH between two renders of one frame at seed %d: %d px differ; rays %s then %s; %d triangles %dx%d flags %d rng %d lights %d spheres %s; order %s" %
+                  (seed, int((again != got).sum()), (st.rays_primary, st.rays_shadow, st.rays_reflect), (st2.rays_primary, st2.rays_shadow, st2.rays_reflect),
+                   n, w, h, frame.flags, frame.rng_mode, len(lights), use_spheres, ctx.order_info()))
+            sys.exit(1)
     want, _ = oracle.render(scene.desc, frame, os_threads=4)
     shifts = np.array([0, 8, 16])
     diff = int(np.abs(((got[..., None] >> shifts) & 255).astype(int) - ((want[..., None] >> shifts) & 255).astype(int)).max())
@@ -86,7 +100,7 @@ while time.time() < t_end:
     ctx.close()
     scene.close()
     n_scenes += 1
-    n_frames += 1
+    n_frames += 3
     n_rays += 3 * m
     print("seed %d: %d triangles, scale %g, %dx%d ss=%d sub=%d flags %d rng %d lights %d: max diff %d, %d px differ, rays %s" %
           (seed, n, scale, w, h, bool(frame.flags & 1), bool(frame.flags & 2), frame.flags >> 2, frame.rng_mode, len(lights), diff, int((got != want).sum()),
