@@ -37,9 +37,12 @@ while time.time() < t_end:
     frame = scene.frame(w, h, threads=int(rng.choice([1, 4, 8, 32])) if h >= 32 else 1, supersampling=bool(rng.random() < 0.5),
                         subsampling=bool(rng.random() < 0.15), rotation=oracle.camera_rotation(*angles), rng_seed=seed)
     frame.cam_pos = (C.c_double * 3)(*cam)
+    # (the context carries the chunk costs of its last frame -- another view, often another size -- into this one, and
+    #  this frame's into the second render: heavy chunks first, on stale and on fresh history)
     got, _ = ctx.render(frame)
+    again, _ = ctx.render(frame)
     want, _ = oracle.render(scene.desc, frame, os_threads=16)
-    n_diff = int((got != want).sum())
+    n_diff = int((got != want).sum()) + int((again != want).sum())
     m = 16384
     rays = np.zeros(m, dtype=ca.bindings.RAY_DTYPE)
     rays["origin"] = cam + rng.normal(size=(m, 3)) * span * rng.choice([0.0, 0.001, 0.3])
