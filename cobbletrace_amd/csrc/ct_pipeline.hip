@@ -27,6 +27,7 @@
 // Scope: scenes without reflective materials and with at most 32 non-ambient lights.
 // Everything else takes the megakernel.  Semantics and citations: ct_device.h,
 // ct_kernels.hip header.
+#include <type_traits>
 #include "ct_params.h"
 #include "ct_raygen.h"
 #include "ct_spheres.h"
@@ -748,6 +749,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
     constexpr bool LIST = KIND >= 2;                 // rays come from W.ray_list instead of the frame's samples
     if (LIST && W.list_gate && *W.list_gate == 0u) return;      // (a bounce level nobody reached)
     constexpr bool ANY_HIT = KIND == 1 || KIND == 3; // a ray leaves the walk at its first ray.t update
+    constexpr bool OCTANTS = KIND < 2 && !HANDOVER;  // the frame walks: the shared walk once per octant (box_filter_f32_oct)
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const uint32_t depth = W.packet_depth;                      // most entries the folded tree leaves pending
     PacketStack st;
@@ -960,6 +962,17 @@ chunk_ready:
         // direction component and the origin exactly on a box plane -- the one case folding is not
         // proven for, DESIGN B2) leaves the packet, and pass 1 walks those rays again from the root
         // over the same tree UNFOLDED (two entries per node, the reference's own structure).
+        // the packet's octant: the signs of 1/d, when all its rays agree on every axis (else 8: the filter sorts the two
+        // parameters of each axis itself, as it must for rays that point different ways)
+        uint32_t octant = 8u;
+        if (OCTANTS) {
+            const unsigned long long rays = __ballot(has_ray);
+            const unsigned long long down_x = __ballot(has_ray && __float_as_int(rf.inv_xy.x) < 0);
+            const unsigned long long down_y = __ballot(has_ray && __float_as_int(rf.inv_xy.y) < 0);
+            const unsigned long long down_z = __ballot(has_ray && __float_as_int(rf.inv_z_e2.x) < 0);
+            if ((down_x == 0ull || down_x == rays) && (down_y == 0ull || down_y == rays) && (down_z == 0ull || down_z == rays))
+                octant = (down_x ? 1u : 0u) | (down_y ? 2u : 0u) | (down_z ? 4u : 0u);
+        }
         uint32_t visits = 0, lane_visits = 0;         // of this packet: nodes visited, rays that took part in them
         bool hand_over = false;
         for (int walk_pass = 0; walk_pass < 2; walk_pass++) {
@@ -985,6 +998,10 @@ chunk_ready:
 #endif
 
         // ---------------- the shared walk
+        // (instantiated once per octant the packet's rays can all point into, plus once for packets whose rays
+        //  disagree: box_filter_f32_oct)
+        auto shared_walk = [&](auto octant_tag) {
+        constexpr int OCT = decltype(octant_tag)::value;
         while (mask != 0ull) {
             // A packet whose rays have gone separate ways walks the union of 64 different paths one node at a time:
             // after `budget` visits with fewer than packet_lanes rays per visit it stops here and its rays are traced
@@ -1125,7 +1142,7 @@ chunk_ready:
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     float least, margin;
-                    box_filter_f32(rf, sq.planes(k, 0), sq.planes(k, 1), sq.planes(k, 2), t, tmin[k], least, margin);
+                    box_filter_f32_oct<OCT>(rf, sq.planes(k, 0), sq.planes(k, 1), sq.planes(k, 2), t, tmin[k], least, margin);
                     enter[k] = __ballot(least > margin) & mask;
                     const float slack = __builtin_fabsf(least) - margin;           // > 0: decided
                     worst = (k == 0) ? slack : __builtin_fminf(worst, slack);
@@ -1241,6 +1258,22 @@ chunk_ready:
                 cur = (uint32_t)__builtin_amdgcn_readlane(stack_ref, (int)sp);
                 PK_T1(2);
             }
+        }
+        };   // shared_walk
+        if (OCTANTS && walk_pass == 0) {
+            switch (octant) {
+                case 0: shared_walk(std::integral_constant<int, 0>{}); break;
+                case 1: shared_walk(std::integral_constant<int, 1>{}); break;
+                case 2: shared_walk(std::integral_constant<int, 2>{}); break;
+                case 3: shared_walk(std::integral_constant<int, 3>{}); break;
+                case 4: shared_walk(std::integral_constant<int, 4>{}); break;
+                case 5: shared_walk(std::integral_constant<int, 5>{}); break;
+                case 6: shared_walk(std::integral_constant<int, 6>{}); break;
+                case 7: shared_walk(std::integral_constant<int, 7>{}); break;
+                default: shared_walk(std::integral_constant<int, 8>{}); break;
+            }
+        } else {
+            shared_walk(std::integral_constant<int, 8>{});
         }
 
         if (hand_over) break;
