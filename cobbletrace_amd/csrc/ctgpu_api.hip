@@ -206,10 +206,19 @@ struct ctgpu_ctx {
         bool active = false;
         std::chrono::steady_clock::time_point t0;
         uint64_t pixels = 0;
+        uint32_t *deliver_to = nullptr;         // the caller's pageable framebuffer the staged rectangle goes to at the end
+        int width = 0, r0 = 0, r1 = -1, c0 = 0, c1 = -1;       // ... and that rectangle
         int kind = -1;                          // 0 / 1: a single-sample / supersampled frame on the fast path (walk choice)
         int reflective_kind = -1;               // 0 / 1: a reflective single-sample / supersampled frame (bounce choice)
     } pending;
     int probe_above = 100;                      // CTGPU_PROBE_ABOVE: fetches per packet beyond which the per-lane walk gets a trial frame
+    // A framebuffer the caller did not page-lock is never the target of a copy queued on a stream: such a frame lands
+    // in `stage` (page-locked, the context's own) and is copied into the caller's memory by the CPU once the frame
+    // is over.  (Letting the runtime pin pageable memory behind an asynchronous copy goes wrong when that memory sits
+    // in the C heap: the heap's top is given back to the system and grown again as arrays come and go, the runtime's
+    // mapping of the old pages stays, and a later copy to the same addresses ends in "Memory access fault by GPU".)
+    uint32_t *stage = nullptr;
+    size_t stage_count = 0;
     uint32_t *pinned_fb = nullptr;              // the caller's framebuffer, page-locked by begin_frame for the asynchronous copy
     size_t pinned_bytes = 0;
     bool keep_pin = false;                      // ctgpu_keep_framebuffer_pinned: the caller promises one long-lived framebuffer
@@ -384,6 +393,7 @@ extern "C" void ctgpu_destroy(ctgpu_ctx *ctx) {
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
     if (ctx->pinned_fb) (void)hipHostUnregister(ctx->pinned_fb);
+    if (ctx->stage) (void)hipHostFree(ctx->stage);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -1210,11 +1220,15 @@ extern "C" int ctgpu_assemble(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, con
     return CTGPU_OK;
 }
 
+namespace { bool page_locked(const void *p); }
+
 // the rectangle of the bitmap the reference writes (rendered rows x square columns, clipped: raythread.cpp:176-184,
 // draw2d.h:8-20), device framebuffer -> host framebuffer, asynchronous on `stream`
 extern "C" int ctgpu_download_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, const void *d_fb, uint32_t *host_fb, void *stream) {
     if (!ctx || !d_fb || !host_fb) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_download_frame: null argument");
     int rc = check_frame(frame); if (rc) return rc;
+    if (!page_locked(host_fb))
+        return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_download_frame: the host framebuffer must be page-locked (hipHostMalloc / hipHostRegister): the copy is queued on the caller's stream");
     HIP_TRY(hipSetDevice(ctx->device));
     const Geometry g = geometry(frame);
     const int row_hi = frame->height / 2 + g.half, row_lo = row_hi - (int)g.rendered_rows + 1;
@@ -1242,6 +1256,28 @@ extern "C" int ctgpu_read_counters(ctgpu_ctx *ctx, ctgpu_stats *stats) {
 // two back to back.  The reference's RayThread is non-blocking the same way: it dispatches its workers and looks
 // at their status on later calls (raythread.cpp:546-593).
 namespace {
+bool page_locked(const void *p) {
+    hipPointerAttribute_t known;
+    const bool yes = hipPointerGetAttributes(&known, p) == hipSuccess && known.type == hipMemoryTypeHost;
+    (void)hipGetLastError();                     // (plain pageable memory makes the query fail: that is the answer)
+    return yes;
+}
+
+int stage_reserve(ctgpu_ctx *ctx, size_t count) {
+    if (count <= ctx->stage_count && ctx->stage) return CTGPU_OK;
+    if (ctx->stage) (void)hipHostFree(ctx->stage);
+    ctx->stage = nullptr; ctx->stage_count = 0;
+    HIP_TRY(hipHostMalloc((void **)&ctx->stage, std::max<size_t>(count, 1) * sizeof(uint32_t), hipHostMallocDefault));
+    ctx->stage_count = count;
+    return CTGPU_OK;
+}
+
+// the written rectangle, staged copy -> the caller's framebuffer
+void stage_deliver(const uint32_t *stage, uint32_t *host_fb, int width, int r0, int r1, int c0, int c1) {
+    for (int r = r0; r <= r1; r++)
+        std::memcpy(host_fb + (size_t)r * width + c0, stage + (size_t)r * width + c0, (size_t)(c1 - c0 + 1) * sizeof(uint32_t));
+}
+
 int begin_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, uint32_t *host_fb, bool pin) {
     if (!ctx || !host_fb) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_render: null argument");
     if (!ctx->scene) return ctgpu_fail(CTGPU_ERR_NO_SCENE, "no scene uploaded");
@@ -1263,10 +1299,7 @@ int begin_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, uint32_t *host_fb
     if (pin && (ctx->pinned_fb != host_fb || ctx->pinned_bytes != fb_bytes)) {
         if (ctx->pinned_fb) (void)hipHostUnregister(ctx->pinned_fb);
         ctx->pinned_fb = nullptr;
-        hipPointerAttribute_t known;
-        const bool already_pinned = hipPointerGetAttributes(&known, host_fb) == hipSuccess && known.type == hipMemoryTypeHost;
-        (void)hipGetLastError();                     // (plain pageable memory makes the query fail: that is the answer)
-        if (!already_pinned) {                       // else the caller page-locked it: nothing to do, nothing to undo later
+        if (!page_locked(host_fb)) {                 // else the caller page-locked it: nothing to do, nothing to undo later
             HIP_TRY(hipHostRegister(host_fb, fb_bytes, hipHostRegisterDefault));
             ctx->pinned_fb = host_fb;
             ctx->pinned_bytes = fb_bytes;
@@ -1291,9 +1324,18 @@ int begin_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, uint32_t *host_fb
     const int row_lo = frame->height / 2 + g.half - (int)g.rendered_rows + 1;
     const int r0 = std::max(row_lo, 0), r1 = std::min(row_hi, frame->height - 1);
     const int c0 = std::max(frame->width / 2 - g.half, 0), c1 = std::min(frame->width / 2 + g.half - 1, frame->width - 1);
+    // (ctgpu_render_begin page-locked the framebuffer above; ctgpu_render's may be pageable: staged)
+    uint32_t *target = host_fb;
+    ctx->pending.deliver_to = nullptr;
+    if (!pin && !page_locked(host_fb)) {
+        rc = stage_reserve(ctx, (size_t)frame->width * frame->height); if (rc) return rc;
+        target = ctx->stage;
+        ctx->pending.deliver_to = host_fb;
+        ctx->pending.width = frame->width; ctx->pending.r0 = r0; ctx->pending.r1 = r1; ctx->pending.c0 = c0; ctx->pending.c1 = c1;
+    }
     if (r1 >= r0 && c1 >= c0) {
         const size_t off = (size_t)r0 * frame->width + c0;
-        HIP_TRY(hipMemcpy2DAsync(host_fb + off, (size_t)frame->width * 4, ctx->fb.ptr + off, (size_t)frame->width * 4,
+        HIP_TRY(hipMemcpy2DAsync(target + off, (size_t)frame->width * 4, ctx->fb.ptr + off, (size_t)frame->width * 4,
                                  (size_t)(c1 - c0 + 1) * 4, (size_t)(r1 - r0 + 1), hipMemcpyDeviceToHost, ctx->stream));
     }
     HIP_TRY(hipEventRecord(ctx->ev_done, ctx->stream));
@@ -1344,6 +1386,9 @@ int finish_frame(ctgpu_ctx *ctx, bool wait, int *done, ctgpu_stats *stats) {
     if (!wait && hipEventQuery(ctx->ev_done) == hipErrorNotReady) { if (done) *done = 0; return CTGPU_OK; }
     // from here on the frame is over, whatever is reported: the context must accept the next one
     const hipError_t waited = hipEventSynchronize(ctx->ev_done);
+    if (waited == hipSuccess && ctx->pending.deliver_to)
+        stage_deliver(ctx->stage, ctx->pending.deliver_to, ctx->pending.width, ctx->pending.r0, ctx->pending.r1, ctx->pending.c0, ctx->pending.c1);
+    ctx->pending.deliver_to = nullptr;
     const auto t1 = std::chrono::steady_clock::now();
     ctx->pending.active = false;
     if (!ctx->keep_pin) release_pin(ctx);
@@ -1487,12 +1532,16 @@ extern "C" int ctgpu_render_multi(ctgpu_ctx *const *ctxs, int n_ctx, const ctgpu
     const int row_hi = frame->height / 2 + g.half, row_lo = row_hi - (int)g.rendered_rows + 1;
     const int r0 = std::max(row_lo, 0), r1 = std::min(row_hi, frame->height - 1);
     const int c0 = std::max(frame->width / 2 - g.half, 0), c1 = std::min(frame->width / 2 + g.half - 1, frame->width - 1);
+    uint32_t *target = host_fb;
+    const bool staged = !page_locked(host_fb);            // (see ctgpu_ctx::stage)
+    if (staged) { rc = stage_reserve(root, (size_t)frame->width * frame->height); if (rc) return rc; target = root->stage; }
     if (r1 >= r0 && c1 >= c0) {
         const size_t off = (size_t)r0 * frame->width + c0;
-        HIP_TRY(hipMemcpy2DAsync(host_fb + off, (size_t)frame->width * 4, root->fb.ptr + off, (size_t)frame->width * 4,
+        HIP_TRY(hipMemcpy2DAsync(target + off, (size_t)frame->width * 4, root->fb.ptr + off, (size_t)frame->width * 4,
                                  (size_t)(c1 - c0 + 1) * 4, (size_t)(r1 - r0 + 1), hipMemcpyDeviceToHost, root->stream));
     }
     HIP_TRY(hipStreamSynchronize(root->stream));
+    if (staged) stage_deliver(root->stage, host_fb, frame->width, r0, r1, c0, c1);
     const auto t1 = std::chrono::steady_clock::now();
 
     ctgpu_stats total;

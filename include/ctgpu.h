@@ -223,7 +223,10 @@ int  ctgpu_scene_info(ctgpu_ctx *ctx, ctgpu_scene_info_t *out);
 int  ctgpu_debug_scene_array(ctgpu_ctx *ctx, int which, void *out, uint64_t bytes, uint64_t *needed);
 
 /* One whole frame on this context's GPU into a caller-owned host framebuffer
- * (width*height uint32).  Synchronous.  stats may be NULL. */
+ * (width*height uint32).  Synchronous.  stats may be NULL.  host_fb may be ordinary pageable memory: the frame then
+ * arrives in a page-locked buffer of the context's own and is copied over by the CPU (no copy queued on a stream ever
+ * targets pageable memory: the runtime's own pinning of C-heap memory goes stale as the heap's top is returned to the
+ * system and grown again, and ends in "Memory access fault by GPU"); page-locked memory is written directly. */
 int  ctgpu_render(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, uint32_t *host_fb, ctgpu_stats *stats);
 
 /* The same frame without blocking the caller (raythread.cpp:546-593: the reference's RayThread dispatches its
@@ -282,7 +285,8 @@ int  ctgpu_render_sharded(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, int til
 
 /* ctgpu_download_frame: the part of the device framebuffer d_fb the reference ever writes (rendered rows x the
  *   centred square, clipped to the bitmap) -> the same pixels of the caller's host framebuffer, asynchronous on
- *   `stream` (truly so when host_fb is page-locked).  What ctgpu_render does after assembling. */
+ *   `stream`.  host_fb must be page-locked (hipHostMalloc / hipHostRegister): CTGPU_ERR_ARG otherwise.  What
+ *   ctgpu_render does after assembling. */
 int  ctgpu_download_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, const void *d_fb, uint32_t *host_fb, void *stream);
 
 /* Ray counters accumulated by render calls since the last read (resets them). Synchronises. */

@@ -112,3 +112,45 @@ def test_framebuffer_pin_ends_with_the_frame(scenes):
             ctx.render_poll()
     finally:
         ctx.close()
+
+
+def test_pageable_framebuffers_in_the_c_heap():
+    """ctgpu_render into arrays that live in the C heap and come and go while the heap's top is given back to the system
+    and grown again: the frame is staged in page-locked memory of the context's own and copied over by the CPU, so no
+    copy queued on a stream ever targets such memory (the runtime's own pinning of it went stale in exactly this
+    pattern: "Memory access fault by GPU" late in long test sessions).  ctgpu_download_frame, whose copy IS queued on
+    the caller's stream, insists on page-locked memory.  In a process of its own: it changes malloc's thresholds."""
+    code = textwrap.dedent("""
+        import ctypes, os, sys
+        import numpy as np
+        libc = ctypes.CDLL(None)
+        assert libc.mallopt(-3, 1 << 30) == 1            # M_MMAP_THRESHOLD: arrays of every size from the brk heap
+        assert libc.mallopt(-1, 64 << 10) == 1           # M_TRIM_THRESHOLD: give the top back as soon as 64 KB are free
+        sys.path.insert(0, %r)
+        import cobbletrace_amd as ca
+        scene = ca.HostScene(os.path.join(%r, "assets", "scene_import.json"))
+        ctx = ca.GpuContext(0)
+        ctx.upload(scene.desc, build_on_device=True)
+        frames = [scene.frame(w, h, threads=8, supersampling=ss, rng_seed=3) for (w, h, ss) in ((640, 480, False), (960, 540, False), (320, 240, True))]
+        want = [ctx.render(f)[0].copy() for f in frames]
+        rng = np.random.default_rng(1)
+        for k in range(60):
+            ballast = np.ones(int(rng.integers(1, 24)) << 18, dtype=np.uint32)         # 1 .. 24 MB below the framebuffer
+            i = k %% len(frames)
+            fb = np.zeros((frames[i].height, frames[i].width), dtype=np.uint32)
+            got, _ = ctx.render(frames[i], fb)
+            assert got is fb and (fb == want[i]).all(), k
+            if k %% 3 == 0:
+                del ballast                                                        # the top of the heap goes back ...
+            del fb, got                                                            # ... and comes again next round
+        try:
+            ctx.download_frame(frames[0], 1, np.zeros((480, 640), dtype=np.uint32).ctypes.data)
+        except RuntimeError as e:
+            assert "page-locked" in str(e), e
+        else:
+            raise AssertionError("ctgpu_download_frame took pageable memory")
+        ctx.close()
+        print("ok")
+    """) % (ROOT, ROOT)
+    proc = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 0 and proc.stdout.strip().endswith("ok"), proc.stdout[-2000:] + proc.stderr[-4000:]
