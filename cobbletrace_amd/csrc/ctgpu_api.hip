@@ -896,8 +896,10 @@ int fill_params(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, const ctgpu_partition
             ctx->ordinal_host = ordinal;
             HIP_TRY(ctx->rand_table.resize(ctx->rand_host.size()));
             HIP_TRY(ctx->row_ordinal.resize(ctx->ordinal_host.size()));
-            HIP_TRY(hipMemcpyAsync(ctx->rand_table.ptr, ctx->rand_host.data(), ctx->rand_host.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-            HIP_TRY(hipMemcpyAsync(ctx->row_ordinal.ptr, ctx->ordinal_host.data(), ctx->ordinal_host.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+            // (blocking copies: the tables sit in pageable C-heap memory, which no copy queued on a stream may touch --
+            //  ctgpu_ctx::stage; the stream is idle here, and the table is built once per seed and frame geometry)
+            HIP_TRY(hipMemcpy(ctx->rand_table.ptr, ctx->rand_host.data(), ctx->rand_host.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(ctx->row_ordinal.ptr, ctx->ordinal_host.data(), ctx->ordinal_host.size() * sizeof(int32_t), hipMemcpyHostToDevice));
             std::memcpy(ctx->rand_key, key, sizeof key);
         }
         P.rand_table = ctx->rand_table.ptr;
