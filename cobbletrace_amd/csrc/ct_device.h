@@ -274,7 +274,11 @@ struct RayFilter {
     f32x2 inv_xy, noi_xy;         // {inv.x, inv.y}, {noi.x, noi.y}
     f32x2 inv_z_e2, noi_z_e;      // {inv.z, 2 e},   {noi.z, e}
 };
-__device__ __forceinline__ RayFilter ray_filter(const d3 &o, const d3 &d, const d3 &inv, const float *plane_bound) {
+// e_limit: rays whose slab parameters could exceed e_limit * 2^24 in magnitude are not taken (infinite margin: the
+// exact levels decide for them).  2^80 by default; the any-hit walks pass 2^60, which keeps every parameter of the
+// rays they do take below 2^84 -- far below the 1e30f such a ray carries as ray.t for as long as it is traced, so that
+// "tmin < ray.t" needs no look (box_filter_f32<.., true>, and no per-lane tmin has to wait on the stack).
+__device__ __forceinline__ RayFilter ray_filter(const d3 &o, const d3 &d, const d3 &inv, const float *plane_bound, float e_limit = 0x1p80f) {
     const float fi[3] = {(float)inv.x, (float)inv.y, (float)inv.z};
     const float fo[3] = {-(float)(o.x * inv.x), -(float)(o.y * inv.y), -(float)(o.z * inv.z)};
     auto ok = [](double c) {
@@ -286,7 +290,7 @@ __device__ __forceinline__ RayFilter ray_filter(const d3 &o, const d3 &d, const 
         const float ea = __builtin_fmaf(plane_bound[a] * __builtin_fabsf(fi[a]), 0x1p-23f, __builtin_fabsf(fo[a]) * 0x1p-24f);
         E = (ea > E || !(ea == ea)) ? ea : E;          // a NaN sticks
     }
-    const bool usable = ok(d.x) && ok(d.y) && ok(d.z) && E < 0x1p80f;
+    const bool usable = ok(d.x) && ok(d.y) && ok(d.z) && E < e_limit;
     const float e = usable ? __builtin_fmaf(E, 1.5f, 0x1p-120f) : __builtin_inff();
     RayFilter f;
     f.inv_xy = f32x2{fi[0], fi[1]};  f.noi_xy = f32x2{fo[0], fo[1]};
@@ -318,6 +322,9 @@ __device__ __forceinline__ void box_verdict_f32(float tmin, float tmax, float tw
 // because min / max on values the compiler did not produce itself get a canonicalising
 // `v_max x, x` in front of each operand (6 per box), and because the scalar unit is the scarcer
 // resource here -- everything per-lane stays in the vector unit until the two compares.
+// NO_ROOM (the any-hit walks): ray_t is 1e30f and every parameter below 2^84 (ray_filter's e_limit), so
+// ray_t - tmin is never the least of the three and is not computed: min(gap, tmax) is min3(gap, room, tmax), bit for bit.
+template <bool NO_ROOM = false>
 __device__ __forceinline__ void box_filter_f32(const RayFilter &f, f32x2 px, f32x2 py, f32x2 pz, float ray_t,
                                                float &tmin, float &least, float &margin) {
     f32x2 tx, ty, tz;
@@ -336,8 +343,12 @@ __device__ __forceinline__ void box_filter_f32(const RayFilter &f, f32x2 px, f32
     asm("v_max_f32 %0, |%1|, |%2|" : "=v"(big) : "v"(tmin), "v"(tmax));
     asm("v_fma_f32 %0, %1, %2, %3" : "=v"(margin) : "v"(big), "s"(0x1p-20f), "v"(f.inv_z_e2.y));
     asm("v_sub_f32 %0, %1, %2" : "=v"(gap) : "v"(tmax), "v"(tmin));
-    asm("v_sub_f32 %0, %1, %2" : "=v"(room) : "v"(ray_t), "v"(tmin));
-    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(least) : "v"(gap), "v"(room), "v"(tmax));
+    if (NO_ROOM) {
+        asm("v_min_f32 %0, %1, %2" : "=v"(least) : "v"(gap), "v"(tmax));
+    } else {
+        asm("v_sub_f32 %0, %1, %2" : "=v"(room) : "v"(ray_t), "v"(tmin));
+        asm("v_min3_f32 %0, %1, %2, %3" : "=v"(least) : "v"(gap), "v"(room), "v"(tmax));
+    }
 }
 // The same for a packet whose rays all point into one octant (OCT bit 0 / 1 / 2: the x / y / z component of every
 // direction is negative): which plane of an axis is the near one is then known beforehand -- the minimum plane where
@@ -346,9 +357,10 @@ __device__ __forceinline__ void box_filter_f32(const RayFilter &f, f32x2 px, f32
 // 1/d > 0 and falling for 1/d < 0, and min <= max, so min(t_lo, t_hi) IS t of the plane chosen here (equal planes give
 // equal parameters).  Rays with a zero component (1/d = +-inf, parameters inf or NaN) do not rely on any of it: their
 // margin is infinite and every verdict of theirs goes to the exact levels, as before.
-template <int OCT>
+template <int OCT, bool NO_ROOM = false>
 __device__ __forceinline__ void box_filter_f32_oct(const RayFilter &f, f32x2 px, f32x2 py, f32x2 pz, float ray_t,
                                                    float &tmin, float &least, float &margin) {
+    if (OCT == 8) { box_filter_f32<NO_ROOM>(f, px, py, pz, ray_t, tmin, least, margin); return; }
     f32x2 tx, ty, tz;
     float tmax, big, gap, room;
     asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(tx) : "s"(px), "v"(f.inv_xy), "v"(f.noi_xy));
@@ -359,13 +371,12 @@ __device__ __forceinline__ void box_filter_f32_oct(const RayFilter &f, f32x2 px,
     asm("v_max_f32 %0, |%1|, |%2|" : "=v"(big) : "v"(tmin), "v"(tmax));
     asm("v_fma_f32 %0, %1, %2, %3" : "=v"(margin) : "v"(big), "s"(0x1p-20f), "v"(f.inv_z_e2.y));
     asm("v_sub_f32 %0, %1, %2" : "=v"(gap) : "v"(tmax), "v"(tmin));
-    asm("v_sub_f32 %0, %1, %2" : "=v"(room) : "v"(ray_t), "v"(tmin));
-    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(least) : "v"(gap), "v"(room), "v"(tmax));
-}
-template <>
-__device__ __forceinline__ void box_filter_f32_oct<8>(const RayFilter &f, f32x2 px, f32x2 py, f32x2 pz, float ray_t,
-                                                      float &tmin, float &least, float &margin) {
-    box_filter_f32(f, px, py, pz, ray_t, tmin, least, margin);
+    if (NO_ROOM) {
+        asm("v_min_f32 %0, %1, %2" : "=v"(least) : "v"(gap), "v"(tmax));
+    } else {
+        asm("v_sub_f32 %0, %1, %2" : "=v"(room) : "v"(ray_t), "v"(tmin));
+        asm("v_min3_f32 %0, %1, %2, %3" : "=v"(least) : "v"(gap), "v"(room), "v"(tmax));
+    }
 }
 // the deferred  tmin < ray.t  of a pushed child (ray.t may have dropped since): decided -> keep
 __device__ __forceinline__ bool deferred_verdict_f32(float tmin, float e, float ray_t, bool &keep) {

@@ -941,7 +941,7 @@ chunk_ready:
             t = t_start;
             slot = kNoNode;
             const d3 inv = make_d3(quick_reciprocal(d.x), quick_reciprocal(d.y), quick_reciprocal(d.z));
-            rf = ray_filter(RAY_O, d, inv, P.plane_bound);
+            rf = ray_filter(RAY_O, d, inv, P.plane_bound, ANY_HIT ? 0x1p60f : 0x1p80f);
             // every frame ray starts at ray.t = 1e30f and only drops to hits > 0.0001f, which the
             // approximate levels rely on; a caller's ray with another start (the reference's
             // reflected rays start at 0, raythread.cpp:373) takes the exact level throughout
@@ -1142,7 +1142,7 @@ chunk_ready:
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     float least, margin;
-                    box_filter_f32_oct<OCT>(rf, sq.planes(k, 0), sq.planes(k, 1), sq.planes(k, 2), t, tmin[k], least, margin);
+                    box_filter_f32_oct<OCT, ANY_HIT>(rf, sq.planes(k, 0), sq.planes(k, 1), sq.planes(k, 2), t, tmin[k], least, margin);
                     enter[k] = __ballot(least > margin) & mask;
                     const float slack = __builtin_fabsf(least) - margin;           // > 0: decided
                     worst = (k == 0) ? slack : __builtin_fminf(worst, slack);
@@ -1156,7 +1156,7 @@ chunk_ready:
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         float tmin_again, least, margin;
-                        box_filter_f32(rf, sq.planes(k, 0), sq.planes(k, 1), sq.planes(k, 2), t, tmin_again, least, margin);
+                        box_filter_f32<ANY_HIT>(rf, sq.planes(k, 0), sq.planes(k, 1), sq.planes(k, 2), t, tmin_again, least, margin);
                         unsure_of[k] = ((uint32_t)k < n_entries) ? (__ballot(!(__builtin_fabsf(least) > margin)) & mask) : 0ull;
                     }
                     // level 1 (some lane sits inside the bound): binary64 planes, one-step margins;
@@ -1212,7 +1212,7 @@ chunk_ready:
                             stack_mask_lo = level ? (int)(uint32_t)next_mask : stack_mask_lo;
                             stack_mask_hi = level ? (int)(uint32_t)(next_mask >> 32) : stack_mask_hi;
                             st.parent[sp] = node_id * 4u + next_entry;                // every lane, same word: read on the exact path only
-                            st.put_tmin(sp, lane, next_tmin);
+                            if (!ANY_HIT) st.put_tmin(sp, lane, next_tmin);      // (an any-hit ray's tmin < ray.t holds for as long as it is traced)
                             sp += 1;
                         }
                         next_ref = sq.ref(k);
@@ -1236,8 +1236,12 @@ chunk_ready:
                 if (pushed == 0ull) continue;
                 bool keep = false;
                 if (__builtin_amdgcn_inverse_ballot_w64(pushed)) {
-                    const float tmin = st.get_tmin(sp, lane);          // the filter's tmin, good to M(tmin)
-                    if (!deferred_verdict_f32(tmin, rf.noi_z_e.y, t, keep)) {
+                    // the deferred  tmin < ray.t : from the filter's tmin, good to M(tmin) -- and settled beforehand for an
+                    // any-hit ray the filter takes (ray.t = 1e30f while it is traced, |tmin| < 2^84: ray_filter's e_limit)
+                    bool settled;
+                    if (ANY_HIT) { keep = true; settled = rf.noi_z_e.y != __builtin_inff(); }
+                    else settled = deferred_verdict_f32(st.get_tmin(sp, lane), rf.noi_z_e.y, t, keep);
+                    if (!settled) {
                         // too close to ray.t to trust (or a ray the filter does not take: e = inf): tmin from
                         // the binary64 box, one step off at most -- and if that is still too close, the whole
                         // test exactly

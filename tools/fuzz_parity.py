@@ -57,7 +57,7 @@ while time.time() < t_end:
     ctx.upload(scene.desc, build_on_device=bool(seed % 2))     # every other scene: tree built and laid out on the GPU
     angles = [np.float32(a) for a in rng.uniform(-0.6, 0.6, 3)] if rng.random() < 0.5 else [np.float32(0)] * 3
     w, h = int(rng.choice([64, 97, 160])), int(rng.choice([48, 64, 121]))
-    if len(lights) > 30 and n >= 300:
+    if len(lights) > 30:
         w, h = 64, 48             # (36 shadow rays per hit, ten bounces, 16 samples: minutes of oracle time on a larger frame)
     frame = scene.frame(w, h, rotation=oracle.camera_rotation(*angles), rng_seed=seed, spheres=use_spheres,
                         reflect_fix=bool(rng.random() < 0.3), rng_mode=(ca.RNG_LIBC if rng.random() < 0.2 else ca.RNG_HASH))
