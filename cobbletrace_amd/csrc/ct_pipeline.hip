@@ -768,7 +768,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
     uint32_t shard = blockIdx.x % n_shards, shards_done = 0;
     uint64_t light_base = 0, chunk_light_base = 0;       // first ray id of the packet's / the current chunk's light
     uint32_t light_index = 0, chunk_light_index = 0;     // lights[] entry of the shadow rays in the packet / chunk
-    const d3 eye = make_d3(P.cam[0], P.cam[1], P.cam[2]);
+    d3 eye = make_d3(P.cam[0], P.cam[1], P.cam[2]);
 
     // ray origin: the eye for every primary ray (kept in scalar registers), per lane for shadow rays
     d3 shadow_o = eye, d = make_d3(0, 0, 1);
@@ -806,6 +806,10 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
 #endif
 
     for (;;) {
+        // (the eye as a value the compiler has to take as new for every packet: what it otherwise computes once per
+        //  launch from it -- the root box relative to the eye, in binary64, i.e. in vector registers -- it keeps in
+        //  scratch and reloads per packet, 0.3 GB of traffic per launch; six additions per packet are cheaper)
+        if (KIND == 0) asm volatile("" : "+s"(eye.x), "+s"(eye.y), "+s"(eye.z));
         // ---------------- fetch a packet: every lane gets a ray (or stays empty at the end)
         has_ray = false;
         root_pass = false;

@@ -227,7 +227,7 @@ bool RayThread(environment_t *env, scene_t *scene) {
             }
             // env->bitmap is the application's one framebuffer for its whole life (cobbletrace.cpp:60-75): its page-lock
             // stays between frames; RayThreadReset / ctgpu_destroy ends it
-            if (b.options.async && api.keep_pinned(ctx, 1) != CTGPU_OK) die("ctgpu_keep_framebuffer_pinned", api.last_error());
+            if (api.keep_pinned(ctx, 1) != CTGPU_OK) die("ctgpu_keep_framebuffer_pinned", api.last_error());
             b.ctxs.push_back(ctx);
             device_of.push_back(device);
         }
@@ -267,10 +267,20 @@ bool RayThread(environment_t *env, scene_t *scene) {
     frame.rng_offset = b.rand_consumed;
     frame.max_depth = 10;                 // TraceRay(..., 10, ...) raythread.cpp:474,508
 
-    if (b.options.async && b.ctxs.size() == 1) {
+    if (b.ctxs.size() == 1) {
+        // (begin / poll also when the caller wants the frame before RayThread returns: the bitmap is page-locked once
+        //  and the frame is copied straight into it; ctgpu_render would stage a pageable bitmap and copy it over)
         if (api.render_begin(b.ctxs[0], &frame, (uint32_t *)env->bitmap->memory) != CTGPU_OK)
             die("ctgpu_render_begin", api.last_error());
         b.in_flight = true;
+        if (!b.options.async) {
+            int done = 0;
+            ctgpu_stats stats;
+            if (api.render_poll(b.ctxs[0], 1, &done, &stats) != CTGPU_OK) die("ctgpu_render_poll", api.last_error());
+            b.in_flight = false;
+            b.last_stats = stats;
+            b.frames_finished++;
+        }
     } else {
         ctgpu_stats stats;
         if (api.render_multi(b.ctxs.data(), (int)b.ctxs.size(), &frame, (uint32_t *)env->bitmap->memory, &stats) != CTGPU_OK)
