@@ -819,6 +819,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
             const unsigned long long m_i = __ballot(!has_ray);
             if (m_i == 0ull || wave_drained) break;
             if (chunk_next >= chunk_end) {
+                bool from_list = false;
                 if (ORDERED && order_phase < 2u) {
                     // the heavy lists, heaviest class first, as one sequence of which wave b takes entries b, b + grid, ...
                     // (no queue: every wave of the launch asking one head word for a ticket costs more than the lists save)
@@ -843,10 +844,9 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                     chunk_end = chunk_light_base + hi;
                     chunk_cost_at = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.w);
                     if (KIND == 1) chunk_light_index = (uint32_t)__builtin_amdgcn_readfirstlane((int)W.shadow_lights[e_light]);
-                    if (KIND == 1 && m_i != ~0ull) break;
-                    goto chunk_ready;
+                    from_list = true;
                 }
-                {
+                if (!from_list) {
                 unsigned long long offset = 0;
                 if (lane == 0) offset = atomicAdd(heads + (size_t)shard * 16u, (unsigned long long)q_chunk);
                 offset = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)offset) |
@@ -871,13 +871,12 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                 chunk_next = chunk_light_base + lo;
                 chunk_end = chunk_light_base + hi;
                 if (KIND == 1) chunk_light_index = (uint32_t)__builtin_amdgcn_readfirstlane((int)W.shadow_lights[light]);
+                }
                 // a packet never mixes lights (its rays should point the same way) nor chunks (the next chunk
                 // this wave gets lies elsewhere in the image: topping up from it was measured, 5 % slower --
                 // it splits that chunk's rays over two packets, i.e. two walks through that region)
                 if (KIND == 1 && m_i != ~0ull) break;
-                }
             }
-chunk_ready:
             const uint64_t avail = chunk_end - chunk_next;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_i >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_i, 0u));
             const bool take = !has_ray && rank < avail;
