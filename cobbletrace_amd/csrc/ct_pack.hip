@@ -317,7 +317,119 @@ int build_quads(const ctgpu_node *d_nodes, bool root_is_inner, uint32_t n_inner,
     return CTGPU_OK;
 }
 
+// ---- triangle boxes for the leaf cull (ct_device.h "triangle boxes", DESIGN appendix D)
+// next binary32 value below / above a finite x (zero steps to the smallest denormal of the other / same sign)
+__device__ __forceinline__ float float_down(float x) {
+    const uint32_t b = __float_as_uint(x);
+    if (x > 0.0f) return __uint_as_float(b - 1u);
+    if (x < 0.0f) return __uint_as_float(b + 1u);
+    return __uint_as_float(0x80000001u);
+}
+__device__ __forceinline__ float float_up(float x) { return -float_down(-x); }
+
+// One thread per TriRecord slot: the box of the triangle {p1, p1 + e1, p1 + e2} (the vertices the reference's test
+// works with, bvh.cpp:148-149), grown on every side by (1.01 / 256) of its extent on that axis -- the 2 * eta * extent of
+// appendix D with eta = 2^-9 -- plus 2^-45 of the largest coordinate (which swallows the binary64 roundings made here),
+// then rounded OUTWARD to binary32.  Also: the last-of-leaf flags of the slot's group, and the scene's magnitudes
+// (largest |e1|, |e2| component, largest |vertex coordinate|, largest |box plane| per axis) for the gate and the filter.
+__global__ void k_tri_boxes(const TriRecord *recs, uint32_t n, QuadNode *tri_quads, QuadNode *tri_groups, uint32_t *stats) {
+    const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
+    float edge = 0.0f, coord = 0.0f, plane[3] = {0.0f, 0.0f, 0.0f};
+    bool bad = false;
+    if (slot < n) {
+        const TriRecord t = recs[slot];
+        float lo_f[3], hi_f[3];
+        for (int a = 0; a < 3; a++) {
+            const double v0 = t.p1[a], v1 = t.p1[a] + t.e1[a], v2 = t.p1[a] + t.e2[a];
+            const double lo = fmin(v0, fmin(v1, v2)), hi = fmax(v0, fmax(v1, v2));
+            const double big = fmax(fabs(lo), fabs(hi));
+            const double pad = (hi - lo) * (1.01 / 256.0) + big * 0x1p-45;
+            if (!(big <= 1e30) || !(fabs(t.e1[a]) <= 1e30) || !(fabs(t.e2[a]) <= 1e30)) bad = true;      // also NaN
+            lo_f[a] = float_down((float)(lo - pad));
+            hi_f[a] = float_up((float)(hi + pad));
+            edge = fmaxf(edge, float_up((float)fmax(fabs(t.e1[a]), fabs(t.e2[a]))));
+            coord = fmaxf(coord, float_up((float)big));
+            plane[a] = fmaxf(fabsf(lo_f[a]), fabsf(hi_f[a]));
+        }
+        QuadNode *q = tri_quads + (slot >> 2);
+        for (int a = 0; a < 3; a++) { q->plane[slot & 3u][a][0] = lo_f[a]; q->plane[slot & 3u][a][1] = hi_f[a]; }
+        q->ref[slot & 3u] = t.remaining;
+        if (t.remaining == 1u) atomicOr(&tri_groups[slot >> 4].count, 1u << (slot & 15u));
+    }
+    // (non-negative floats order like their bit patterns)
+    uint32_t v[5] = {__float_as_uint(edge), __float_as_uint(coord), __float_as_uint(plane[0]), __float_as_uint(plane[1]), __float_as_uint(plane[2])};
+    for (int k = 0; k < 5; k++) {
+        for (int off = 32; off > 0; off >>= 1) { const uint32_t other = __shfl_xor(v[k], off); v[k] = other > v[k] ? other : v[k]; }
+        if ((threadIdx.x & 63) == 0 && v[k]) atomicMax(stats + k, v[k]);
+    }
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicMax(stats + 5, 1u);
+}
+// one thread per group of four slots: the union of their boxes (slots beyond the last triangle do not count)
+__global__ void k_tri_group_boxes(const QuadNode *tri_quads, uint32_t n, QuadNode *tri_groups) {
+    const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
+    if ((uint64_t)g * 4u >= n) return;
+    const QuadNode q = tri_quads[g];
+    float lo[3], hi[3];
+    for (int a = 0; a < 3; a++) { lo[a] = q.plane[0][a][0]; hi[a] = q.plane[0][a][1]; }
+    for (uint32_t k = 1; k < 4 && (uint64_t)g * 4u + k < n; k++)
+        for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], q.plane[k][a][0]); hi[a] = fmaxf(hi[a], q.plane[k][a][1]); }
+    QuadNode *G = tri_groups + (g >> 2);
+    for (int a = 0; a < 3; a++) { G->plane[g & 3u][a][0] = lo[a]; G->plane[g & 3u][a][1] = hi[a]; }
+}
+// leaf references of a QuadNode tree whose leaves hold at least big_min triangles get kBigLeafBit
+__global__ void k_mark_big_leaves(QuadNode *quads, uint32_t n_quads, const TriRecord *recs, uint32_t n, uint32_t big_min, uint32_t *marked) {
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n_quads * 4u) return;
+    QuadNode &q = quads[i >> 2];
+    const uint32_t k = i & 3u;
+    if (k >= q.count) return;
+    const uint32_t ref = q.ref[k];
+    if (!(ref & kLeafBit)) return;
+    const uint32_t first = ref & kSlotMask;
+    if (first < n && recs[first].remaining >= big_min) { q.ref[k] = ref | kBigLeafBit; atomicAdd(marked, 1u); }
+}
+
 }  // namespace
+
+// The leaf cull's arrays from the packed scene (whoever packed it: ct_pack's kernels or the host restatement), and the
+// big-leaf marks in both QuadNode trees.  big_min = 0: no leaf is marked (the arrays are made all the same, the marks decide).
+int ctgpu_pack_cull_on_device(int device, const void *d_tris, uint32_t n, void *d_quads, uint32_t n_quads, void *d_quads_flat,
+                              uint32_t n_quads_flat, uint32_t big_min, ctgpu_cull_scene *out) {
+    if (!d_tris || !d_quads || !d_quads_flat || !out || n == 0) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_pack_cull_on_device: null argument");
+    HIP_TRY(hipSetDevice(device));
+    Owned owned;
+    const uint32_t n_tri_quads = (n + 3u) / 4u, n_groups = (n + 15u) / 16u;
+    QuadNode *tri_quads = nullptr, *tri_groups = nullptr;
+    uint32_t *d_stats = nullptr;
+    HIP_TRY(owned.alloc(tri_quads, n_tri_quads));
+    HIP_TRY(owned.alloc(tri_groups, n_groups));
+    HIP_TRY(owned.alloc(d_stats, 8));
+    HIP_TRY(hipMemsetAsync(tri_quads, 0, (size_t)n_tri_quads * sizeof(QuadNode), nullptr));
+    HIP_TRY(hipMemsetAsync(tri_groups, 0, (size_t)n_groups * sizeof(QuadNode), nullptr));
+    HIP_TRY(hipMemsetAsync(d_stats, 0, 8 * sizeof(uint32_t), nullptr));
+    const TriRecord *recs = (const TriRecord *)d_tris;
+    hipLaunchKernelGGL(k_tri_boxes, dim3(blocks_for(n)), dim3(kBlock), 0, nullptr, recs, n, tri_quads, tri_groups, d_stats);
+    hipLaunchKernelGGL(k_tri_group_boxes, dim3(blocks_for(n_tri_quads)), dim3(kBlock), 0, nullptr, (const QuadNode *)tri_quads, n, tri_groups);
+    if (big_min) {
+        hipLaunchKernelGGL(k_mark_big_leaves, dim3(blocks_for((uint64_t)n_quads * 4u)), dim3(kBlock), 0, nullptr, (QuadNode *)d_quads, n_quads, recs, n, big_min, d_stats + 6);
+        hipLaunchKernelGGL(k_mark_big_leaves, dim3(blocks_for((uint64_t)n_quads_flat * 4u)), dim3(kBlock), 0, nullptr, (QuadNode *)d_quads_flat, n_quads_flat, recs, n, big_min, d_stats + 7);
+    }
+    HIP_TRY(hipGetLastError());
+    uint32_t stats[8];
+    HIP_TRY(hipMemcpy(stats, d_stats, sizeof stats, hipMemcpyDeviceToHost));
+    std::memcpy(&out->edge_bound, &stats[0], 4);
+    std::memcpy(&out->vertex_bound, &stats[1], 4);
+    std::memcpy(out->plane_bound, &stats[2], 12);
+    out->usable = stats[5] == 0u;
+    out->n_big_leaves = stats[6];
+    out->n_tri_quads = n_tri_quads;
+    out->n_groups = n_groups;
+    owned.keep(tri_quads);
+    owned.keep(tri_groups);
+    out->tri_quads = tri_quads;
+    out->tri_groups = tri_groups;
+    return CTGPU_OK;
+}
 
 int ctgpu_pack_on_device(int device, const ctgpu_node *d_nodes, uint32_t m, const uint32_t *d_indexes, const double *d_verts,
                          uint32_t n, ctgpu_packed_scene *out) {

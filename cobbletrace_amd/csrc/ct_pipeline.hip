@@ -743,7 +743,9 @@ extern "C" __attribute__((visibility("default"))) int ctgpu_debug_packet_trace(u
 // cost the primary walk 12 % through register pressure: profiles/r03_handover_sweep.log).
 // ORDERED: chunks the frame before found heavy come first, in parts where that frame's packets were few (ct_params.h,
 // OrderParams), then every other chunk in the usual order; each packet adds its fetches to its chunk's cost word.
-template <int KIND, bool SS, bool HANDOVER = false, bool ORDERED = false>
+// BIGLEAF: leaves marked kBigLeafBit go through their triangle boxes (scenes that have such leaves; a scene without
+// them runs the instantiation that does not carry the code).
+template <int KIND, bool SS, bool HANDOVER = false, bool ORDERED = false, bool BIGLEAF = false>
 __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const FrameParams P, const PipelineParams W) {
     const uint32_t q_chunk = (KIND == 1) ? W.chunk_shadow : W.chunk;      // ray ids per queue atomic
     constexpr bool LIST = KIND >= 2;                 // rays come from W.ray_list instead of the frame's samples
@@ -959,6 +961,17 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
             }
         }
 
+        // which of the packet's rays may use the leaf cull (ct_device.h "triangle boxes", DESIGN appendix D): magnitudes
+        // inside the frame's gate; a caller's closest-hit ray only when it starts at 1e30f like a frame's ray (with any
+        // other start a "hit" that does not lower ray.t still records its triangle, bvh.cpp:212)
+        unsigned long long cull_lanes = 0ull;
+        if (BIGLEAF) {
+            const double d_lim = (double)P.cull.d_lim, o_lim = (double)P.cull.o_lim;
+            bool ok = has_ray && __builtin_fabs(d.x) <= d_lim && __builtin_fabs(d.y) <= d_lim && __builtin_fabs(d.z) <= d_lim;
+            if (KIND != 0) ok = ok && __builtin_fabs(shadow_o.x) <= o_lim && __builtin_fabs(shadow_o.y) <= o_lim && __builtin_fabs(shadow_o.z) <= o_lim;
+            if (KIND == 2) ok = ok && t == kNoHit;
+            cull_lanes = __ballot(ok);
+        }
         // lanes still tracing (a shadow ray stops at its first hit, raythread.cpp:303-307); every
         // lane mask below is wave-uniform and stays inside it
         // Pass 0 walks the folded tree.  A ray that meets a NaN box parameter there (0/0: a zero
@@ -1045,9 +1058,73 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                     visits = 0u; lane_visits = 0u;             // still sharing well: look again after another `budget`
                 }
             }
-            if (cur & kLeafBit) {
+            if (BIGLEAF && (cur & (kLeafBit | kBigLeafBit)) == (kLeafBit | kBigLeafBit)) {
+                // A leaf of many triangles, by way of its triangle boxes: the reference tests every triangle of the leaf
+                // in index order (bvh.cpp:208-218); a lane skips the ones whose (grown) box its ray certainly misses --
+                // there IntersectTriangle returns false or leaves ray.t alone (appendix D) -- and makes the others' tests,
+                // in the same order.  Sixteen slots a step: the group's four boxes (four slots each), then the boxes of
+                // the groups some lane may hit, then the records.  Every lane computes every box (the masked-out ones on
+                // stale rays, as in the node visit); the masks are wave-uniform.
+                PK_T0();
+                uint32_t s = cur & kSlotMask;
+                for (;;) {
+                    unsigned long long act = mask;
+                    if (ANY_HIT) act &= __ballot(t == kNoHit);
+                    if (act == 0ull) break;                              // (any-hit: every ray of the leaf has met its blocker)
+                    const uint32_t group = s >> 4;
+                    const ScalarQuad gq = scalar_load_quad(P.tri_groups + group);
+                    n_quads += 1;
+                    // the leaf's slots in this group: from s up to the first last-of-leaf flag
+                    const uint32_t flags = gq.count() >> (s & 15u);
+                    const uint32_t stop = flags != 0u ? s + (uint32_t)__builtin_ctz(flags) + 1u : (group + 1u) << 4;
+                    // a closest hit prunes boxes beyond ray.t (1 + 2^-12) once ray.t has reached tau (appendix D.4)
+                    const float t_cull = ANY_HIT ? t : ((t >= P.cull.tau) ? t * (1.0f + 0x1p-12f) : __builtin_inff());
+                    unsigned long long live[4];
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        float tmin_j, least, margin;
+                        box_filter_f32_oct<OCT, ANY_HIT>(rf, gq.planes(j, 0), gq.planes(j, 1), gq.planes(j, 2), t_cull, tmin_j, least, margin);
+                        live[j] = act & ~(__ballot(least < -margin) & cull_lanes);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t base = (group << 4) + 4u * (uint32_t)j;
+                        const uint32_t lo = s > base ? s : base, hi = stop < base + 4u ? stop : base + 4u;
+                        if (lo >= hi || live[j] == 0ull) continue;
+                        const ScalarQuad tq = scalar_load_quad(P.tri_quads + (base >> 2));
+                        n_quads += 1;
+                        unsigned long long wants[4];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            float tmin_k, least, margin;
+                            box_filter_f32_oct<OCT, ANY_HIT>(rf, tq.planes(k, 0), tq.planes(k, 1), tq.planes(k, 2), t_cull, tmin_k, least, margin);
+                            wants[k] = live[j] & ~(__ballot(least < -margin) & cull_lanes);
+                        }
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const uint32_t at = base + (uint32_t)k;
+                            if (at < lo || at >= hi || wants[k] == 0ull) continue;
+                            const ScalarTri tr = scalar_load_tri(P.tris + at);
+                            n_records += 1;
+                            if (__builtin_amdgcn_inverse_ballot_w64(wants[k]) && (!ANY_HIT || t == kNoHit)) {
+                                const d3 p1 = make_d3(tr.f64(0), tr.f64(1), tr.f64(2)), e1 = make_d3(tr.f64(3), tr.f64(4), tr.f64(5)),
+                                         e2 = make_d3(tr.f64(6), tr.f64(7), tr.f64(8));
+                                const float before = t;
+                                const bool hit = triangle_test(RAY_O, d, t, p1, e1, e2);
+                                const float tclosest = (slot != kNoNode) ? before : kFarAway;      // bvh.cpp:212-215
+                                if (hit && t != kNoHit && t < tclosest) slot = at;
+                            }
+                        }
+                    }
+                    if (flags != 0u) break;
+                    s = stop;
+                }
+                if (ANY_HIT) tracing &= __ballot(t == kNoHit);
+                mask = 0ull;               // on to the pop below
+                PK_T1(1);
+            } else if (cur & kLeafBit) {
                 // leaf: every triangle in index order, each lane keeps its own closest hit
-                const uint32_t first = cur & ~kLeafBit;
+                const uint32_t first = cur & kSlotMask;
                 const bool mine = __builtin_amdgcn_inverse_ballot_w64(mask);
                 PK_T0();
                 uint32_t count = 1;        // the first record says how many the leaf holds
@@ -1804,6 +1881,10 @@ int pipeline_packet_occupancy(uint32_t depth, uint32_t lds_levels) {
     int a = 0, b = 0;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, ct_walk_packet<0, true>, kWave, PacketStack::bytes(depth, lds_levels));
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, ct_walk_packet<1, true>, kWave, PacketStack::bytes(depth, lds_levels));
+    int c = a, e = b;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, ct_walk_packet<0, true, false, false, true>, kWave, PacketStack::bytes(depth, lds_levels));
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&e, ct_walk_packet<1, true, false, false, true>, kWave, PacketStack::bytes(depth, lds_levels));
+    a = std::min(a, c); b = std::min(b, e);
     return a < b ? a : b;
 }
 
@@ -1863,6 +1944,23 @@ __global__ __launch_bounds__(256) void ct_order_build(const OrderBuild primary, 
     if (there) A.listed[c] = listed;
 }
 
+// the frame's packet walk of one kind: the instantiation for its sampling, order and leaves (the hand-over experiment
+// has none with the leaf cull: its marked leaves are walked record by record)
+template <int KIND>
+static void launch_frame_walk(bool ss, bool handover, bool ordered, bool big, dim3 grid, dim3 wave, size_t lds, hipStream_t stream,
+                              const FrameParams &P, const PipelineParams &W) {
+#define CT_WALK(SS_, HO_, ORD_, BIG_) hipLaunchKernelGGL((ct_walk_packet<KIND, SS_, HO_, ORD_, BIG_>), grid, wave, lds, stream, P, W)
+    if (handover) { if (ss) CT_WALK(true, true, false, false); else CT_WALK(false, true, false, false); return; }
+    if (ss) {
+        if (ordered) { if (big) CT_WALK(true, false, true, true); else CT_WALK(true, false, true, false); }
+        else { if (big) CT_WALK(true, false, false, true); else CT_WALK(true, false, false, false); }
+    } else {
+        if (ordered) { if (big) CT_WALK(false, false, true, true); else CT_WALK(false, false, true, false); }
+        else { if (big) CT_WALK(false, false, false, true); else CT_WALK(false, false, false, false); }
+    }
+#undef CT_WALK
+}
+
 void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hipStream_t stream, hipEvent_t *marks,
                      const BounceParams *bounce, const OrderBuild *order) {
     if (W.n_samples == 0) return;
@@ -1906,24 +2004,14 @@ void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hip
         const size_t lds_l = (size_t)W.lds_depth * kWave * 12u;
         const dim3 grid_l(W.listed_blocks);
         const bool handover = W.packet_budget != 0u;
-        if (ss && !handover && !ordered) hipLaunchKernelGGL((ct_walk_packet<0, true>), grid, wave, lds_p, stream, P, W);
-        if (!ss && !handover && !ordered) hipLaunchKernelGGL((ct_walk_packet<0, false>), grid, wave, lds_p, stream, P, W);
-        if (ss && !handover && ordered) hipLaunchKernelGGL((ct_walk_packet<0, true, false, true>), grid, wave, lds_p, stream, P, W);
-        if (!ss && !handover && ordered) hipLaunchKernelGGL((ct_walk_packet<0, false, false, true>), grid, wave, lds_p, stream, P, W);
-        if (ss && handover) hipLaunchKernelGGL((ct_walk_packet<0, true, true>), grid, wave, lds_p, stream, P, W);
-        if (!ss && handover) hipLaunchKernelGGL((ct_walk_packet<0, false, true>), grid, wave, lds_p, stream, P, W);
+        launch_frame_walk<0>(ss, handover, ordered, W.big_leaves != 0u, grid, wave, lds_p, stream, P, W);
         if (handover && ss) hipLaunchKernelGGL((ct_walk<0, true, true>), grid_l, wave, lds_l, stream, P, W);
         if (handover && !ss) hipLaunchKernelGGL((ct_walk<0, false, true>), grid_l, wave, lds_l, stream, P, W);
         sphere_pass(0);
         mark(2);
         if (shadows) light_gate();
         mark(3);
-        if (shadows && ss && !handover && !ordered) hipLaunchKernelGGL((ct_walk_packet<1, true>), grid, wave, lds_p, stream, P, W);
-        if (shadows && !ss && !handover && !ordered) hipLaunchKernelGGL((ct_walk_packet<1, false>), grid, wave, lds_p, stream, P, W);
-        if (shadows && ss && !handover && ordered) hipLaunchKernelGGL((ct_walk_packet<1, true, false, true>), grid, wave, lds_p, stream, P, W);
-        if (shadows && !ss && !handover && ordered) hipLaunchKernelGGL((ct_walk_packet<1, false, false, true>), grid, wave, lds_p, stream, P, W);
-        if (shadows && ss && handover) hipLaunchKernelGGL((ct_walk_packet<1, true, true>), grid, wave, lds_p, stream, P, W);
-        if (shadows && !ss && handover) hipLaunchKernelGGL((ct_walk_packet<1, false, true>), grid, wave, lds_p, stream, P, W);
+        if (shadows) launch_frame_walk<1>(ss, handover, ordered, W.big_leaves != 0u, grid, wave, lds_p, stream, P, W);
         if (shadows && handover && ss) hipLaunchKernelGGL((ct_walk<1, true, true>), grid_l, wave, lds_l, stream, P, W);
         if (shadows && handover && !ss) hipLaunchKernelGGL((ct_walk<1, false, true>), grid_l, wave, lds_l, stream, P, W);
     } else {
@@ -1970,13 +2058,15 @@ void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hip
         B.level = level;
         Wc.list_gate = Ws.list_gate = B.level_live + level;
         (void)hipMemsetAsync(W.queue, 0, queue_bytes, stream);
-        hipLaunchKernelGGL((ct_walk_packet<2, false>), list_grid(Wc.n_samples), wave, lds_p, stream, P, Wc);
+        if (W.big_leaves) hipLaunchKernelGGL((ct_walk_packet<2, false, false, false, true>), list_grid(Wc.n_samples), wave, lds_p, stream, P, Wc);
+        else hipLaunchKernelGGL((ct_walk_packet<2, false>), list_grid(Wc.n_samples), wave, lds_p, stream, P, Wc);
         if (sph) hipLaunchKernelGGL((ct_bounce_spheres<0>), strided, threads, 0, stream, P, W, B);
         if (shadows) {
             if (sph) hipLaunchKernelGGL((ct_bounce_gate<true>), strided, threads, 0, stream, P, W, B);
             else hipLaunchKernelGGL((ct_bounce_gate<false>), strided, threads, 0, stream, P, W, B);
             (void)hipMemsetAsync(W.queue, 0, queue_bytes, stream);
-            hipLaunchKernelGGL((ct_walk_packet<3, false>), list_grid(Ws.n_samples), wave, lds_p, stream, P, Ws);
+            if (W.big_leaves) hipLaunchKernelGGL((ct_walk_packet<3, false, false, false, true>), list_grid(Ws.n_samples), wave, lds_p, stream, P, Ws);
+            else hipLaunchKernelGGL((ct_walk_packet<3, false>), list_grid(Ws.n_samples), wave, lds_p, stream, P, Ws);
             if (sph) hipLaunchKernelGGL((ct_bounce_spheres<1>), strided, threads, 0, stream, P, W, B);
         }
         if (sph) hipLaunchKernelGGL((ct_bounce_shade<true>), strided, threads, 0, stream, P, W, B);
@@ -1992,8 +2082,14 @@ void launch_packet_ray_list(const FrameParams &P, const PipelineParams &W, bool 
     if (W.n_samples == 0) return;
     const uint32_t depth_p = W.packet_depth;
     const size_t lds_p = PacketStack::bytes(depth_p, W.packet_lds_levels < depth_p ? W.packet_lds_levels : depth_p);
-    if (any_hit) hipLaunchKernelGGL((ct_walk_packet<3, false>), dim3(W.walk_blocks), dim3(kWave), lds_p, stream, P, W);
-    else hipLaunchKernelGGL((ct_walk_packet<2, false>), dim3(W.walk_blocks), dim3(kWave), lds_p, stream, P, W);
+    const dim3 grid(W.walk_blocks), wave(kWave);
+    if (any_hit) {
+        if (W.big_leaves) hipLaunchKernelGGL((ct_walk_packet<3, false, false, false, true>), grid, wave, lds_p, stream, P, W);
+        else hipLaunchKernelGGL((ct_walk_packet<3, false>), grid, wave, lds_p, stream, P, W);
+    } else {
+        if (W.big_leaves) hipLaunchKernelGGL((ct_walk_packet<2, false, false, false, true>), grid, wave, lds_p, stream, P, W);
+        else hipLaunchKernelGGL((ct_walk_packet<2, false>), grid, wave, lds_p, stream, P, W);
+    }
 }
 
 }  // namespace ctd

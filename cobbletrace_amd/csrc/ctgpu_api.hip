@@ -14,7 +14,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -43,6 +45,8 @@ int ctgpu_fail(int code, const char *fmt, ...) {
         hipError_t e_ = (expr);                                                                    \
         if (e_ != hipSuccess) return ctgpu_fail(CTGPU_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));  \
     } while (0)
+
+static void ctgpu_own_pin_forget(const void *p);     // (the registry of this library's own page-locks, further down)
 
 // ------------------------------------------------------------------ context
 template <typename T>
@@ -78,6 +82,12 @@ struct SceneStore {
     uint32_t n_quads = 0, n_quads_flat = 0;
     float plane_bound[3] = {0, 0, 0};
     DeviceArray<TriRecord> tris;
+    // the leaf cull (ct_device.h "triangle boxes"): boxes per 4 / 16 TriRecord slots, the scene's magnitudes for its gate
+    DeviceArray<QuadNode> tri_quads, tri_groups;
+    float edge_bound = 0, vertex_bound = 0;
+    bool cull_usable = false;
+    uint32_t big_leaf_min = 0;                  // leaves of at least this many triangles are walked through the boxes (0: none)
+    uint32_t n_big_leaves = 0;
     DeviceArray<Material> materials;
     DeviceArray<Light> lights;
     DeviceArray<ctgpu_sphere> spheres;          // CTGPU_F_SPHERES
@@ -94,7 +104,7 @@ struct SceneStore {
     ~SceneStore() {
         (void)hipSetDevice(device);
         nodes.release(); quads.release(); quads_flat.release(); quad_boxes.release(); quad_boxes_flat.release();
-        tris.release(); materials.release(); lights.release(); spheres.release(); sphere_nodes.release();
+        tris.release(); tri_quads.release(); tri_groups.release(); materials.release(); lights.release(); spheres.release(); sphere_nodes.release();
         sphere_indexes.release(); shadow_lights.release(); ref_nodes.release(); ref_indexes.release();
     }
 };
@@ -211,6 +221,7 @@ struct ctgpu_ctx {
         int kind = -1;                          // 0 / 1: a single-sample / supersampled frame on the fast path (walk choice)
         int reflective_kind = -1;               // 0 / 1: a reflective single-sample / supersampled frame (bounce choice)
     } pending;
+    int big_leaf_min = 0;                       // CTGPU_BIG_LEAF: leaves of at least this many triangles go through the triangle boxes (0: off)
     int probe_above = 100;                      // CTGPU_PROBE_ABOVE: fetches per packet beyond which the per-lane walk gets a trial frame
     // A framebuffer the caller did not page-lock is never the target of a copy queued on a stream: such a frame lands
     // in `stage` (page-locked, the context's own) and is copied into the caller's memory by the CPU once the frame
@@ -318,6 +329,7 @@ static int create_resources(ctgpu_ctx *ctx) {
     if (const char *t = std::getenv("CTGPU_PACKET")) { ctx->packet_walk = std::atoi(t) != 0; ctx->walk_auto = false; }
     if (const char *t = std::getenv("CTGPU_KEEP_SHADOW_RAYS")) ctx->keep_shadow_rays = std::atoi(t) != 0;
     if (const char *t = std::getenv("CTGPU_PROBE_ABOVE")) ctx->probe_above = std::max(0, std::atoi(t));
+    if (const char *t = std::getenv("CTGPU_BIG_LEAF")) ctx->big_leaf_min = std::max(0, std::atoi(t));
     if (const char *t = std::getenv("CTGPU_PACKET_BUDGET")) ctx->packet_budget = std::max(0, std::atoi(t));
     if (const char *t = std::getenv("CTGPU_PACKET_LANES")) ctx->packet_lanes = std::min(64, std::max(1, std::atoi(t)));
     if (const char *t = std::getenv("CTGPU_PACKET_LDS_LEVELS")) ctx->packet_lds_levels = std::max(1, std::atoi(t));
@@ -392,7 +404,7 @@ extern "C" void ctgpu_destroy(ctgpu_ctx *ctx) {
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->ev_done) (void)hipEventDestroy(ctx->ev_done);
-    if (ctx->pinned_fb) (void)hipHostUnregister(ctx->pinned_fb);
+    if (ctx->pinned_fb) { (void)hipHostUnregister(ctx->pinned_fb); ctgpu_own_pin_forget(ctx->pinned_fb); }
     if (ctx->stage) (void)hipHostFree(ctx->stage);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -652,6 +664,23 @@ extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
     }
     if (depth > CTGPU_MAX_TREE_DEPTH) return ctgpu_fail(CTGPU_ERR_STACK, "tree depth %u exceeds %d", depth, CTGPU_MAX_TREE_DEPTH);
 
+    {   // the leaf cull: triangle boxes, big-leaf marks in the two QuadNode trees (whichever way those were packed)
+        ctgpu_cull_scene cull;
+        const uint32_t big_min = (uint32_t)ctx->big_leaf_min;
+        int rc = ctgpu_pack_cull_on_device(ctx->device, S.tris.ptr, N, S.quads.ptr, S.n_quads, S.quads_flat.ptr, S.n_quads_flat, big_min, &cull);
+        if (rc) return rc;
+        S.tri_quads.adopt((QuadNode *)cull.tri_quads, cull.n_tri_quads);
+        S.tri_groups.adopt((QuadNode *)cull.tri_groups, cull.n_groups);
+        S.edge_bound = cull.edge_bound; S.vertex_bound = cull.vertex_bound; S.cull_usable = cull.usable && big_min != 0u;
+        S.n_big_leaves = cull.n_big_leaves;
+        // (a tree that is ONE leaf: its reference is the root itself)
+        if (S.cull_usable && (S.quad_root & kLeafBit) && N >= big_min) { S.quad_root |= kBigLeafBit; S.quad_root_flat |= kBigLeafBit; S.n_big_leaves = 1; }
+        if (S.n_big_leaves == 0u) S.cull_usable = false;          // nothing to cull: the walks without the code run
+        S.big_leaf_min = S.cull_usable ? big_min : 0u;
+        // the binary32 filter's bound covers the triangle boxes' planes too
+        if (cull.usable) for (int c = 0; c < 3; c++) S.plane_bound[c] = std::max(S.plane_bound[c], std::nextafterf(cull.plane_bound[c], INFINITY));
+    }
+
     bool reflective = false;
     for (uint32_t i = 0; i < N; i++) reflective = reflective || (s->materials[i].reflection > 0);
     S.triangles_reflect = reflective;
@@ -764,12 +793,13 @@ extern "C" int ctgpu_scene_info(ctgpu_ctx *ctx, ctgpu_scene_info_t *out) {
     out->shared_by = (uint32_t)ctx->scene.use_count();
     out->hbm_bytes = S.nodes.count * sizeof(WideNode) + (S.quads.count + S.quads_flat.count) * sizeof(QuadNode) +
                      (S.quad_boxes.count + S.quad_boxes_flat.count) * sizeof(double) + S.tris.count * sizeof(TriRecord) +
-                     S.materials.count * sizeof(Material) + S.ref_nodes.count * sizeof(ctgpu_node) + S.ref_indexes.count * 4;
+                     S.materials.count * sizeof(Material) + S.ref_nodes.count * sizeof(ctgpu_node) + S.ref_indexes.count * 4 +
+                     (S.tri_quads.count + S.tri_groups.count) * sizeof(QuadNode);
     return CTGPU_OK;
 }
 
 // The packed arrays themselves, for comparing the device packing with the host's (which: 0 WideNodes, 1 QuadNodes,
-// 2 their boxes, 3 unfolded QuadNodes, 4 their boxes, 5 TriRecords).  bytes = room in out; *needed = size of the array.
+// 2 their boxes, 3 unfolded QuadNodes, 4 their boxes, 5 TriRecords, 6 / 7 the leaf cull's boxes per 4 / 16 slots).  bytes = room in out; *needed = size of the array.
 extern "C" int ctgpu_debug_scene_array(ctgpu_ctx *ctx, int which, void *out, uint64_t bytes, uint64_t *needed) {
     if (!ctx || !needed) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_debug_scene_array: null argument");
     if (!ctx->scene) return ctgpu_fail(CTGPU_ERR_NO_SCENE, "no scene uploaded");
@@ -783,6 +813,8 @@ extern "C" int ctgpu_debug_scene_array(ctgpu_ctx *ctx, int which, void *out, uin
         case 3: src = S.quads_flat.ptr; size = (uint64_t)S.n_quads_flat * sizeof(QuadNode); break;
         case 4: src = S.quad_boxes_flat.ptr; size = (uint64_t)S.n_quads_flat * 24 * sizeof(double); break;
         case 5: src = S.tris.ptr; size = (uint64_t)S.n_triangles * sizeof(TriRecord); break;
+        case 6: src = S.tri_quads.ptr; size = (uint64_t)S.tri_quads.count * sizeof(QuadNode); break;
+        case 7: src = S.tri_groups.ptr; size = (uint64_t)S.tri_groups.count * sizeof(QuadNode); break;
         default: return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_debug_scene_array: unknown array %d", which);
     }
     *needed = size;
@@ -843,6 +875,30 @@ void traced_row_ordinals(const ctgpu_frame_desc *f, const Geometry &g, std::vect
     }
 }
 
+// Which rays may use the leaf cull, and from which ray.t on a closest hit prunes triangle boxes (DESIGN appendix D):
+// with K >= every |e1|, |e2| component, V >= every |vertex coordinate|, the eye at `cam`,
+//   o_lim = max |cam_i| + 2 V     (the eye, every surface point and anything as near pass),   S = o_lim + V >= |o - p1|,
+//   d_lim = 2^20 / (K max(K, S))  (so that K K D and S D K stay below 2^20: the reference's rounding errors in a, u, v
+//                                  then stay below 2^-12, far inside the 2^-9 the grown boxes guarantee),
+//   tau   = 2^-20.5 K K S         (a closest hit at ray.t >= tau prunes boxes beyond ray.t (1 + 2^-12)),
+// and no cull at all unless K K S <= 2^20 (then a plane hit behind the origin computes t <= 0.0001f).
+CullLimits cull_limits(const SceneStore &S, const double cam[3]) {
+    CullLimits c;
+    c.d_lim = 0.0f; c.o_lim = 0.0f; c.tau = INFINITY;
+    if (!S.cull_usable) return c;
+    const double K = S.edge_bound, V = S.vertex_bound;
+    const double eye = std::max(std::fabs(cam[0]), std::max(std::fabs(cam[1]), std::fabs(cam[2])));
+    if (!(eye <= 1e30)) return c;
+    const double o_lim = eye + 2.0 * V, s_lim = (o_lim + V) * (1.0 + 0x1p-40);
+    if (!(K * K * s_lim <= 0x1p20)) return c;
+    const double denom = K * std::max(K, s_lim);
+    const double d_lim = denom > 0.0 ? std::min(0x1p20 / denom, 0x1p80) : 0x1p80;
+    c.d_lim = std::nextafterf((float)d_lim, 0.0f);          // (rounded towards zero: the comparison is made in binary32)
+    c.o_lim = std::nextafterf((float)o_lim, INFINITY);      // (up: the eye itself must pass; S above has the slack)
+    c.tau = std::nextafterf((float)(0x1p-20 * 0.7072 * K * K * s_lim), INFINITY);
+    return c;
+}
+
 // `stream`: the stream the frame's kernels will run on -- the LIBC jitter table is uploaded in that stream's
 // order (a frame still running there may be reading the previous table).  One context serves one frame at a
 // time; frames in flight on different streams use a context each.
@@ -864,6 +920,8 @@ int fill_params(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, const ctgpu_partition
     P.stack_depth = std::max<uint32_t>(ctx->scene->tree_depth, 2);
     (void)count_mode;
     std::memcpy(P.plane_bound, ctx->scene->plane_bound, 12);
+    P.tri_quads = ctx->scene->tri_quads.ptr; P.tri_groups = ctx->scene->tri_groups.ptr;
+    P.cull = cull_limits(*ctx->scene, f->cam_pos);
     std::memcpy(P.root_min, ctx->scene->root_min, 24);
     std::memcpy(P.root_max, ctx->scene->root_max, 24);
     P.width = f->width; P.height = f->height; P.half = g.half;
@@ -1140,6 +1198,7 @@ int fill_pipeline(ctgpu_ctx *ctx, uint64_t n_samples, PipelineParams &W, int kin
         c.probe = false;
         if (c.ran_lane) W.packet = 0u;
     }
+    W.big_leaves = ctx->scene->big_leaf_min != 0u ? 1u : 0u;
     W.packet_depth = ctx->scene->quad_pending;
     W.packet_lds_levels = std::min<uint32_t>((uint32_t)ctx->packet_lds_levels, W.packet_depth);
     int per_cu = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu
@@ -1222,14 +1281,14 @@ extern "C" int ctgpu_assemble(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, con
     return CTGPU_OK;
 }
 
-namespace { bool page_locked(const void *p); }
+namespace { bool page_locked(const void *p, size_t bytes); }
 
 // the rectangle of the bitmap the reference writes (rendered rows x square columns, clipped: raythread.cpp:176-184,
 // draw2d.h:8-20), device framebuffer -> host framebuffer, asynchronous on `stream`
 extern "C" int ctgpu_download_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, const void *d_fb, uint32_t *host_fb, void *stream) {
     if (!ctx || !d_fb || !host_fb) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_download_frame: null argument");
     int rc = check_frame(frame); if (rc) return rc;
-    if (!page_locked(host_fb))
+    if (!page_locked(host_fb, (size_t)frame->width * frame->height * sizeof(uint32_t)))
         return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_download_frame: the host framebuffer must be page-locked (hipHostMalloc / hipHostRegister): the copy is queued on the caller's stream");
     HIP_TRY(hipSetDevice(ctx->device));
     const Geometry g = geometry(frame);
@@ -1258,11 +1317,43 @@ extern "C" int ctgpu_read_counters(ctgpu_ctx *ctx, ctgpu_stats *stats) {
 // two back to back.  The reference's RayThread is non-blocking the same way: it dispatches its workers and looks
 // at their status on later calls (raythread.cpp:546-593).
 namespace {
-bool page_locked(const void *p) {
+// Page-locks this LIBRARY put on callers' memory (begin_frame, any context of the process).  A registration can outlive
+// the memory it covers -- a keep_pin context whose framebuffer was freed -- and the allocator may hand the same
+// addresses out again, as part of a larger array even; the runtime would still call the first byte "host memory".  So
+// a pointer inside one of these ranges counts as page-locked only for the context that holds exactly that range.
+std::mutex g_own_pins_lock;
+std::map<uintptr_t, size_t> g_own_pins;          // start -> bytes
+void own_pin_add(const void *p, size_t bytes) { std::lock_guard<std::mutex> hold(g_own_pins_lock); g_own_pins[(uintptr_t)p] = bytes; }
+void own_pin_remove(const void *p) { std::lock_guard<std::mutex> hold(g_own_pins_lock); g_own_pins.erase((uintptr_t)p); }
+bool overlaps_own_pin(const void *p, size_t bytes) {
+    std::lock_guard<std::mutex> hold(g_own_pins_lock);
+    const uintptr_t lo = (uintptr_t)p, hi = lo + std::max<size_t>(bytes, 1);
+    auto it = g_own_pins.lower_bound(hi);        // first range starting at or beyond our end
+    while (it != g_own_pins.begin()) {
+        --it;
+        if (it->first + it->second <= lo) break; // (ranges do not nest: hipHostRegister refuses overlapping ones)
+        return true;
+    }
+    return false;
+}
+
+bool host_type(const void *p) {
     hipPointerAttribute_t known;
     const bool yes = hipPointerGetAttributes(&known, p) == hipSuccess && known.type == hipMemoryTypeHost;
     (void)hipGetLastError();                     // (plain pageable memory makes the query fail: that is the answer)
     return yes;
+}
+// Did the CALLER page-lock [p, p + bytes)?  Both ends must be host memory the runtime knows, and none of it may be a
+// registration of this library's own (see above): anything else is staged.
+bool page_locked(const void *p, size_t bytes) {
+    if (overlaps_own_pin(p, bytes)) return false;
+    return host_type(p) && host_type((const char *)p + (bytes ? bytes - 1 : 0));
+}
+
+void release_pin(ctgpu_ctx *ctx) {
+    if (ctx->pinned_fb) { (void)hipHostUnregister(ctx->pinned_fb); own_pin_remove(ctx->pinned_fb); }
+    ctx->pinned_fb = nullptr;
+    ctx->pinned_bytes = 0;
 }
 
 int stage_reserve(ctgpu_ctx *ctx, size_t count) {
@@ -1296,17 +1387,27 @@ int begin_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, uint32_t *host_fb
     HIP_TRY(ctx->fb.resize((size_t)frame->width * frame->height));
     P.out = ctx->tiles.ptr;
 
-    // an asynchronous copy needs page-locked memory: the caller's framebuffer is registered once and stays so
+    // an asynchronous copy needs page-locked memory: the caller's framebuffer is registered for the frame (and stays
+    // so between frames only under ctgpu_keep_framebuffer_pinned).  The copy goes straight into host_fb only when this
+    // context holds a registration of exactly [host_fb, host_fb + fb_bytes) or the caller page-locked all of it.
     const size_t fb_bytes = (size_t)frame->width * frame->height * sizeof(uint32_t);
     if (pin && (ctx->pinned_fb != host_fb || ctx->pinned_bytes != fb_bytes)) {
-        if (ctx->pinned_fb) (void)hipHostUnregister(ctx->pinned_fb);
-        ctx->pinned_fb = nullptr;
-        if (!page_locked(host_fb)) {                 // else the caller page-locked it: nothing to do, nothing to undo later
-            HIP_TRY(hipHostRegister(host_fb, fb_bytes, hipHostRegisterDefault));
-            ctx->pinned_fb = host_fb;
-            ctx->pinned_bytes = fb_bytes;
+        release_pin(ctx);
+        // (caller-pinned memory: nothing to do, nothing to undo later.  Memory under another context's registration --
+        //  a stale one, or a second context drawing into the same bitmap -- or memory the runtime will not register: staged)
+        if (!page_locked(host_fb, fb_bytes) && !overlaps_own_pin(host_fb, fb_bytes)) {
+            if (hipHostRegister(host_fb, fb_bytes, hipHostRegisterDefault) == hipSuccess) {
+                ctx->pinned_fb = host_fb;
+                ctx->pinned_bytes = fb_bytes;
+                own_pin_add(host_fb, fb_bytes);
+            } else (void)hipGetLastError();
         }
     }
+    // (whatever fails from here on: a page-lock taken for this frame does not outlive the call)
+    struct PinGuard {
+        ctgpu_ctx *ctx; bool armed;
+        ~PinGuard() { if (armed && !ctx->keep_pin) release_pin(ctx); }
+    } pin_guard{ctx, true};
 
     ctx->pending.kind = pipeline_eligible(ctx, frame) ? ((frame->flags & CTGPU_F_SUPERSAMPLE) ? 1 : 0) : -1;
     ctx->frame_is_reflective = frame_reflects(ctx, frame);
@@ -1329,7 +1430,8 @@ int begin_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, uint32_t *host_fb
     // (ctgpu_render_begin page-locked the framebuffer above; ctgpu_render's may be pageable: staged)
     uint32_t *target = host_fb;
     ctx->pending.deliver_to = nullptr;
-    if (!pin && !page_locked(host_fb)) {
+    const bool own_pin = ctx->pinned_fb == host_fb && ctx->pinned_bytes == fb_bytes;
+    if (!own_pin && !page_locked(host_fb, fb_bytes)) {
         rc = stage_reserve(ctx, (size_t)frame->width * frame->height); if (rc) return rc;
         target = ctx->stage;
         ctx->pending.deliver_to = host_fb;
@@ -1343,6 +1445,7 @@ int begin_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, uint32_t *host_fb
     HIP_TRY(hipEventRecord(ctx->ev_done, ctx->stream));
     ctx->pending.pixels = (r1 >= r0 && c1 >= c0) ? (uint64_t)(r1 - r0 + 1) * (uint64_t)(c1 - c0 + 1) : 0;
     ctx->pending.active = true;
+    pin_guard.armed = false;                     // the frame is in flight: finish_frame ends the page-lock
     return CTGPU_OK;
 }
 
@@ -1374,12 +1477,6 @@ int walk_feedback(ctgpu_ctx *ctx, int kind, double kernel_ms) {
     c.packets = packets; c.fetches = fetches;
     if (per_packet > (double)ctx->probe_above) c.probe = true;
     return CTGPU_OK;
-}
-
-void release_pin(ctgpu_ctx *ctx) {
-    if (ctx->pinned_fb) (void)hipHostUnregister(ctx->pinned_fb);
-    ctx->pinned_fb = nullptr;
-    ctx->pinned_bytes = 0;
 }
 
 int finish_frame(ctgpu_ctx *ctx, bool wait, int *done, ctgpu_stats *stats) {
@@ -1420,6 +1517,8 @@ int finish_frame(ctgpu_ctx *ctx, bool wait, int *done, ctgpu_stats *stats) {
 }
 }  // namespace
 
+static void ctgpu_own_pin_forget(const void *p) { own_pin_remove(p); }
+
 extern "C" int ctgpu_render(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, uint32_t *host_fb, ctgpu_stats *stats) {
     int rc = begin_frame(ctx, frame, host_fb, false); if (rc) return rc;
     return finish_frame(ctx, true, nullptr, stats);
@@ -1447,6 +1546,8 @@ extern "C" int ctgpu_keep_framebuffer_pinned(ctgpu_ctx *ctx, int keep) {
 // that own all devices: every context traces its interleaved row tiles on its own device and
 // stream, the tile buffers travel to the first context's device with peer-to-peer copies over
 // xGMI (the gather), and that device assembles and hands the frame to the host.
+static int render_multi_queued(ctgpu_ctx *const *ctxs, int n_ctx, const ctgpu_frame_desc *frame, uint32_t *host_fb, ctgpu_stats *stats);
+
 extern "C" int ctgpu_render_multi(ctgpu_ctx *const *ctxs, int n_ctx, const ctgpu_frame_desc *frame, uint32_t *host_fb,
                                   ctgpu_stats *stats) {
     if (!ctxs || n_ctx < 1 || !host_fb) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_render_multi: bad argument");
@@ -1457,6 +1558,29 @@ extern "C" int ctgpu_render_multi(ctgpu_ctx *const *ctxs, int n_ctx, const ctgpu
         if (ctxs[i]->pending.active) return ctgpu_fail(CTGPU_ERR_ARG, "context %d has a frame in flight (ctgpu_render_poll)", i);
     }
     int rc = check_frame(frame); if (rc) return rc;
+    rc = render_multi_queued(ctxs, n_ctx, frame, host_fb, stats);
+    if (rc != CTGPU_OK) {
+        // Work may already sit on some of the streams (kernels, peer copies, a partly queued gather): nothing of it may
+        // still be running when the caller hears of the failure and frees the framebuffer or reuses the contexts.  A
+        // gather some devices never joined would wait for good, so the communicators go first (ncclCommAbort).
+        const std::string message = g_last_error;
+        ctgpu_ctx *root = ctxs[0];
+        if (!root->multi_comms.empty()) {
+            ctgpu_multi_comms_release(root->multi_comms, true);
+            root->multi_devices.clear();
+        }
+        for (int i = 0; i < n_ctx; i++) {
+            (void)hipSetDevice(ctxs[i]->device);
+            (void)hipStreamSynchronize(ctxs[i]->stream);
+        }
+        (void)hipGetLastError();
+        g_last_error = message;
+    }
+    return rc;
+}
+
+static int render_multi_queued(ctgpu_ctx *const *ctxs, int n_ctx, const ctgpu_frame_desc *frame, uint32_t *host_fb, ctgpu_stats *stats) {
+    int rc = CTGPU_OK;
     const auto t0 = std::chrono::steady_clock::now();
     const Geometry g = geometry(frame);
     ctgpu_ctx *root = ctxs[0];
@@ -1535,7 +1659,7 @@ extern "C" int ctgpu_render_multi(ctgpu_ctx *const *ctxs, int n_ctx, const ctgpu
     const int r0 = std::max(row_lo, 0), r1 = std::min(row_hi, frame->height - 1);
     const int c0 = std::max(frame->width / 2 - g.half, 0), c1 = std::min(frame->width / 2 + g.half - 1, frame->width - 1);
     uint32_t *target = host_fb;
-    const bool staged = !page_locked(host_fb);            // (see ctgpu_ctx::stage)
+    const bool staged = !page_locked(host_fb, (size_t)frame->width * frame->height * sizeof(uint32_t));            // (see ctgpu_ctx::stage)
     if (staged) { rc = stage_reserve(root, (size_t)frame->width * frame->height); if (rc) return rc; target = root->stage; }
     if (r1 >= r0 && c1 >= c0) {
         const size_t off = (size_t)r0 * frame->width + c0;

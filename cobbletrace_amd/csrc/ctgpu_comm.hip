@@ -224,10 +224,12 @@ int ctgpu_multi_comms(const int *devices, int n, std::vector<void *> &comms) {
     return CTGPU_OK;
 }
 
-void ctgpu_multi_comms_release(std::vector<void *> &comms) {
+// abort: the communicators may have a collective queued that not every device joined (a failure in mid-frame):
+// ncclCommDestroy would wait for it, ncclCommAbort ends it
+void ctgpu_multi_comms_release(std::vector<void *> &comms, bool abort) {
     if (rccl().lib)
         for (void *c : comms)
-            if (c) (void)rccl().comm_destroy((ncclComm_t)c);
+            if (c) (void)(abort ? rccl().comm_abort((ncclComm_t)c) : rccl().comm_destroy((ncclComm_t)c));
     comms.clear();
 }
 

@@ -23,7 +23,7 @@ int main(int argc, char **argv) {
     if (argc < 2) usage();
     int width = 640, height = 640;
     std::string out = "cobbletrace.ppm", keys;
-    ct_raythread_options opt{CTGPU_RNG_HASH, 0, 0, 1, 0, 0u};
+    ct_raythread_options opt{CTGPU_RNG_HASH, 0, 0, 1, 0, 0u, 1};      // (the bitmap below lives as long as the process)
     for (int i = 2; i < argc; i++) {
         const std::string a = argv[i];
         auto need = [&](const char *name) -> const char * {

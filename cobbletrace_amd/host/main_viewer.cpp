@@ -60,7 +60,7 @@ int main(int argc, char *argv[]) {
     env.events.capacity = kEventQueueSize;
     env.events.queue = (event_t *)std::calloc(env.events.capacity, sizeof(event_t));
 
-    ct_raythread_options options{CTGPU_RNG_HASH, 0, 0, 1, 1, 0u};
+    ct_raythread_options options{CTGPU_RNG_HASH, 0, 0, 1, 1, 0u, 1};
     for (int i = 2; i < argc; i++) {
         if (!std::strcmp(argv[i], "--spheres")) options.frame_flags |= CTGPU_F_SPHERES;
         else if (!std::strcmp(argv[i], "--reflect-fix")) options.frame_flags |= CTGPU_F_REFLECT_FIX;

@@ -97,7 +97,7 @@ struct BossState {
     ct::PackedScene *packed = nullptr;
     std::vector<ctgpu_ctx *> ctxs;        // one per GPU the frame is split over
     uint64_t rand_consumed = 0;           // LIBC jitter mode: rand() calls used by earlier frames
-    ct_raythread_options options{CTGPU_RNG_HASH, 0, 0, 1, 0, 0u};
+    ct_raythread_options options{CTGPU_RNG_HASH, 0, 0, 1, 0, 0u, 0};
     ctgpu_stats last_stats{};
     bool in_flight = false;               // async: a frame has been queued and not yet seen finished
     uint64_t frames_finished = 0;
@@ -225,9 +225,10 @@ bool RayThread(environment_t *env, scene_t *scene) {
                 desc = b.packed->desc();
                 if (api.upload_scene(ctx, &desc) != CTGPU_OK) die("ctgpu_upload_scene", api.last_error());
             }
-            // env->bitmap is the application's one framebuffer for its whole life (cobbletrace.cpp:60-75): its page-lock
-            // stays between frames; RayThreadReset / ctgpu_destroy ends it
-            if (api.keep_pinned(ctx, 1) != CTGPU_OK) die("ctgpu_keep_framebuffer_pinned", api.last_error());
+            // RayThread gets env on every call and cannot know how long a bitmap lives (a harness may pass a fresh array
+            // per frame): the page-lock lasts one frame.  An application whose bitmap is one allocation for its whole
+            // life (cobbletrace.cpp:57-75; cobbletrace_headless, cobbletrace_viewer) says so and keeps it between frames.
+            if (b.options.keep_bitmap_pinned && api.keep_pinned(ctx, 1) != CTGPU_OK) die("ctgpu_keep_framebuffer_pinned", api.last_error());
             b.ctxs.push_back(ctx);
             device_of.push_back(device);
         }
@@ -268,8 +269,8 @@ bool RayThread(environment_t *env, scene_t *scene) {
     frame.max_depth = 10;                 // TraceRay(..., 10, ...) raythread.cpp:474,508
 
     if (b.ctxs.size() == 1) {
-        // (begin / poll also when the caller wants the frame before RayThread returns: the bitmap is page-locked once
-        //  and the frame is copied straight into it; ctgpu_render would stage a pageable bitmap and copy it over)
+        // (begin / poll also when the caller wants the frame before RayThread returns: the bitmap is page-locked for
+        //  the frame and the pixels are copied straight into it; ctgpu_render would stage a pageable bitmap and copy it over)
         if (api.render_begin(b.ctxs[0], &frame, (uint32_t *)env->bitmap->memory) != CTGPU_OK)
             die("ctgpu_render_begin", api.last_error());
         b.in_flight = true;

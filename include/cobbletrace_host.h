@@ -172,6 +172,10 @@ struct ct_raythread_options {
                               where it is while a frame is in flight) */
     unsigned frame_flags;  /* extra CTGPU_F_* bits for every frame: CTGPU_F_SPHERES, CTGPU_F_REFLECT_FIX (what the
                               reference's source has but its pictures do not; default 0 = the reference's frame) */
+    int      keep_bitmap_pinned;  /* 1: env->bitmap->memory is ONE buffer that lives until RayThreadReset (the reference's
+                              application: cobbletrace.cpp:57) -- its page-lock then stays between frames
+                              (ctgpu_keep_framebuffer_pinned).  0 (default): RayThread is handed env anew on every call and
+                              assumes nothing about the bitmap's life: it is page-locked for one frame at a time. */
 };
 void RayThreadSetOptions(const ct_raythread_options *opt);
 bool RayThreadBusy(void);                 /* async: a queued frame has not been seen finished yet */

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""The leaf cull (triangle boxes, CTGPU_BIG_LEAF) against the walk without it: same pixels, kernel times, fetch counts.
+     python tools/cull_check.py [scene ...] [--mins 0,5,9]"""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import numpy as np
+import cobbletrace_amd as ca
+import __graft_entry__ as entry
+
+entry.prepare_assets(need_dragon=True)
+A = os.path.join(os.path.dirname(__file__), "..", "assets")
+files = {"cube": "scene_file_cube.json", "import": "scene_import.json", "bunny": "scene_import_bunny.json", "dragon": "scene_import_dragon.json"}
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+mins = [0, 5]
+for a in sys.argv[1:]:
+    if a.startswith("--mins"): mins = [int(x) for x in a.split("=")[1].split(",")]
+for name in (args or ["import", "bunny", "dragon"]):
+    scene = ca.HostScene(os.path.join(A, files[name]))
+    ref = {}
+    for big in mins:
+        os.environ["CTGPU_BIG_LEAF"] = str(big)
+        ctx = ca.GpuContext(0)
+        ctx.upload(scene.desc, build_on_device=True)
+        for ss in (True, False):
+            frame = scene.frame(1920, 1080, supersampling=ss)
+            best = None
+            for _ in range(5):
+                fb, st = ctx.render(frame)
+                if best is None or st.kernel_ms < best.kernel_ms: best = st
+            work = ctx.read_walk_work()
+            same = "" if (ss not in ref) else ("  differing pixels vs first: %d" % int((fb != ref[ss]).sum()))
+            if ss not in ref: ref[ss] = fb.copy()
+            print("%-7s big_leaf>=%-2d ss=%d: kernel %7.3f ms  rays %9d  quads p/s %9d %9d  records p/s %9d %9d%s" %
+                  (name, big, ss, best.kernel_ms, best.rays, work.quad_nodes[0] // 5, work.quad_nodes[1] // 5,
+                   work.triangle_records[0] // 5, work.triangle_records[1] // 5, same), flush=True)
+        ctx.close()

@@ -13,7 +13,7 @@ import __graft_entry__ as entry
 
 entry.prepare_assets(need_dragon=True)
 for name in (sys.argv[1:] or ["dragon", "bunny"]):
-    scene = ca.HostScene(os.path.join(HERE, "..", "assets", "scene_import_%s.json" % name))
+    scene = ca.HostScene(os.path.join(HERE, "..", "assets", "scene_import.json" if name == "import" else "scene_import_%s.json" % name))
     for ss in (True, False):
         for kind, label in ((0, "primary"), (1, "shadow")):
             os.environ["CTGPU_WALK_THRESH"] = "64,%d,24" % kind         # (the middle number picks the walk the build counts)
