@@ -59,29 +59,34 @@ static_assert(sizeof(TriRecord) == 80, "TriRecord is five 16-byte loads");
 
 static constexpr uint32_t kLeafBit = 0x80000000u;
 static constexpr uint32_t kNoNode = 0xffffffffu;
-// A leaf reference of the QuadNode trees may carry this bit: the leaf holds at least `big_leaf_min` triangles, and the
-// packet walk goes through it by way of the triangle boxes below instead of testing every record (slots stay < 2^30).
-static constexpr uint32_t kBigLeafBit = 0x40000000u;
+// The mark of an entry of a CULL NODE (below): on a leaf reference it names ONE triangle (the TriRecord at that slot,
+// whatever `remaining` says), on a node reference a lower cull node.  The reference to the ROOT of a leaf's cull nodes
+// sits in an ordinary QuadNode and does not carry it: that entry's box is the leaf's own, the reference's test.
+// Slots and node indices stay below 2^30.
+static constexpr uint32_t kOneBit = 0x40000000u;
+static constexpr uint32_t kBigLeafBit = kOneBit;      // (flag bits of a reference: indices stay below)
 static constexpr uint32_t kSlotMask = 0x3fffffffu;
 
-// ---------------------------------------------------------------- triangle boxes (the leaf cull, DESIGN appendix D)
+// ---------------------------------------------------------------- cull nodes (DESIGN appendix D)
 // The reference tests EVERY triangle of a leaf it enters (bvh.cpp:208-218), and its BuildBVH leaves up to dozens in
-// one (midpoint splits that put everything on one side stop: scene_import.json has 54-triangle leaves, the dragon
+// one (a midpoint split that puts everything on one side stops: scene_import.json has 54-triangle leaves, the dragon
 // stand-in 74).  A test the reference makes may be left out when its outcome is known: IntersectTriangle returns false,
 // or returns true without lowering ray.t -- neither changes anything a frame's ray carries (ray.t, the closest slot).
 // Both follow when the ray misses the triangle's bounding box grown by 2^-8 of its extent, by an argument about the
-// reference's own rounding errors (appendix D), for rays whose magnitudes pass a gate (cull_limits); the boxes are
-// binary32 and go through the node filter's arithmetic with its proven margin (box_filter_f32*: `least < -margin`
-// means the REAL slab test on the stored planes fails).
-//   tri_quads[g]   entry k: the grown box of TriRecord slot 4g + k          (QuadNode-shaped: two s_load_dwordx16)
-//   tri_groups[G]  entry j: the union of tri_quads[4G + j]'s four boxes; `count` = bit i set when slot 16G + i is the
-//                  LAST triangle of its leaf (so a walk that starts at a leaf's first slot knows where the leaf ends
-//                  without reading a record)
-// Slots beyond the last triangle have all-zero boxes and are never looked at (a leaf ends before them).
+// reference's own rounding errors (appendix D), for rays whose magnitudes pass a gate (CullLimits).
+// So a leaf of at least `big_leaf_min` triangles is replaced, in the folded tree the packet walk reads, by a small tree
+// of CULL NODES: QuadNodes (same 128 bytes, same binary32 planes, appended behind the tree's own: index >= cull_first)
+// whose entries are boxes of consecutive runs of the leaf's triangles -- 4^l triangles under an entry of level l, single
+// triangles (kLeafBit | kOneBit | slot) at the bottom -- listed in slot order, so the walk's "first entry first, the
+// others wait on the stack" reaches the triangles in the leaf's own order.  The walk treats a cull node like any node
+// except for what its filter verdict means: an entry is SKIPPED by a lane only when the binary32 filter proves that the
+// real slab test on the stored planes fails (`least < -margin`, the bound of appendix B) and the lane's ray is inside the
+// gate; undecided lanes and lanes outside the gate go in.  There are no binary64 boxes behind cull nodes and no exact
+// levels: nothing is ever decided against the reference's own arithmetic, only tests with a known outcome are left out.
 struct CullLimits {
     float d_lim;        // a ray takes part in the cull only if every |d_i| <= d_lim ...
     float o_lim;        // ... and every |o_i| <= o_lim
-    float tau;          // ray.t prunes a triangle box ("beyond the closest hit so far") only from this value up
+    float tau;          // ... and, once it has a closest hit, while its ray.t >= tau (closest-hit walks)
 };
 
 struct Material { uint32_t color; int32_t specular; float reflection; };

@@ -317,7 +317,7 @@ int build_quads(const ctgpu_node *d_nodes, bool root_is_inner, uint32_t n_inner,
     return CTGPU_OK;
 }
 
-// ---- triangle boxes for the leaf cull (ct_device.h "triangle boxes", DESIGN appendix D)
+// ---- cull nodes: the big leaves' own small trees of triangle boxes (ct_device.h "cull nodes", DESIGN appendix D)
 // next binary32 value below / above a finite x (zero steps to the smallest denormal of the other / same sign)
 __device__ __forceinline__ float float_down(float x) {
     const uint32_t b = __float_as_uint(x);
@@ -330,31 +330,28 @@ __device__ __forceinline__ float float_up(float x) { return -float_down(-x); }
 // One thread per TriRecord slot: the box of the triangle {p1, p1 + e1, p1 + e2} (the vertices the reference's test
 // works with, bvh.cpp:148-149), grown on every side by (1.01 / 256) of its extent on that axis -- the 2 * eta * extent of
 // appendix D with eta = 2^-9 -- plus 2^-45 of the largest coordinate (which swallows the binary64 roundings made here),
-// then rounded OUTWARD to binary32.  Also: the last-of-leaf flags of the slot's group, and the scene's magnitudes
-// (largest |e1|, |e2| component, largest |vertex coordinate|, largest |box plane| per axis) for the gate and the filter.
-__global__ void k_tri_boxes(const TriRecord *recs, uint32_t n, QuadNode *tri_quads, QuadNode *tri_groups, uint32_t *stats) {
+// then rounded OUTWARD to binary32: box[slot] = {lo xyz, hi xyz}.  Also the scene's magnitudes for the gate and the
+// filter: largest |e1|, |e2| component, largest |vertex coordinate|, largest |box plane| per axis; a flag for anything
+// that is not finite.
+__global__ void k_tri_boxes(const TriRecord *recs, uint32_t n, float *box, uint32_t *stats) {
     const uint32_t slot = blockIdx.x * kBlock + threadIdx.x;
     float edge = 0.0f, coord = 0.0f, plane[3] = {0.0f, 0.0f, 0.0f};
     bool bad = false;
     if (slot < n) {
         const TriRecord t = recs[slot];
-        float lo_f[3], hi_f[3];
         for (int a = 0; a < 3; a++) {
             const double v0 = t.p1[a], v1 = t.p1[a] + t.e1[a], v2 = t.p1[a] + t.e2[a];
             const double lo = fmin(v0, fmin(v1, v2)), hi = fmax(v0, fmax(v1, v2));
             const double big = fmax(fabs(lo), fabs(hi));
             const double pad = (hi - lo) * (1.01 / 256.0) + big * 0x1p-45;
             if (!(big <= 1e30) || !(fabs(t.e1[a]) <= 1e30) || !(fabs(t.e2[a]) <= 1e30)) bad = true;      // also NaN
-            lo_f[a] = float_down((float)(lo - pad));
-            hi_f[a] = float_up((float)(hi + pad));
+            const float lo_f = float_down((float)(lo - pad)), hi_f = float_up((float)(hi + pad));
+            box[(size_t)slot * 6 + a] = lo_f;
+            box[(size_t)slot * 6 + 3 + a] = hi_f;
             edge = fmaxf(edge, float_up((float)fmax(fabs(t.e1[a]), fabs(t.e2[a]))));
             coord = fmaxf(coord, float_up((float)big));
-            plane[a] = fmaxf(fabsf(lo_f[a]), fabsf(hi_f[a]));
+            plane[a] = fmaxf(fabsf(lo_f), fabsf(hi_f));
         }
-        QuadNode *q = tri_quads + (slot >> 2);
-        for (int a = 0; a < 3; a++) { q->plane[slot & 3u][a][0] = lo_f[a]; q->plane[slot & 3u][a][1] = hi_f[a]; }
-        q->ref[slot & 3u] = t.remaining;
-        if (t.remaining == 1u) atomicOr(&tri_groups[slot >> 4].count, 1u << (slot & 15u));
     }
     // (non-negative floats order like their bit patterns)
     uint32_t v[5] = {__float_as_uint(edge), __float_as_uint(coord), __float_as_uint(plane[0]), __float_as_uint(plane[1]), __float_as_uint(plane[2])};
@@ -364,70 +361,170 @@ __global__ void k_tri_boxes(const TriRecord *recs, uint32_t n, QuadNode *tri_qua
     }
     if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicMax(stats + 5, 1u);
 }
-// one thread per group of four slots: the union of their boxes (slots beyond the last triangle do not count)
-__global__ void k_tri_group_boxes(const QuadNode *tri_quads, uint32_t n, QuadNode *tri_groups) {
-    const uint32_t g = blockIdx.x * kBlock + threadIdx.x;
-    if ((uint64_t)g * 4u >= n) return;
-    const QuadNode q = tri_quads[g];
-    float lo[3], hi[3];
-    for (int a = 0; a < 3; a++) { lo[a] = q.plane[0][a][0]; hi[a] = q.plane[0][a][1]; }
-    for (uint32_t k = 1; k < 4 && (uint64_t)g * 4u + k < n; k++)
-        for (int a = 0; a < 3; a++) { lo[a] = fminf(lo[a], q.plane[k][a][0]); hi[a] = fmaxf(hi[a], q.plane[k][a][1]); }
-    QuadNode *G = tri_groups + (g >> 2);
-    for (int a = 0; a < 3; a++) { G->plane[g & 3u][a][0] = lo[a]; G->plane[g & 3u][a][1] = hi[a]; }
+
+// A leaf of c triangles becomes a tree of cull nodes: level 1 holds the triangles four to a node (entry = ONE triangle,
+// kLeafBit | kOneBit | slot), level l + 1 the level-l nodes four to a node, up to a single root; entries in slot order, so
+// the walk's "first entry first, the others wait on the stack" visits the triangles in the leaf's own order.  The nodes of a
+// leaf lie together, root first, then each lower level.
+constexpr uint32_t kCullMaxLevels = 6;               // leaves of up to 4^6 triangles
+constexpr uint32_t kCullMaxLeaf = 4096;
+__host__ __device__ inline uint32_t cull_levels(uint32_t c, uint32_t per_level[kCullMaxLevels]) {
+    uint32_t levels = 0, width = c;
+    do { width = (width + 3u) / 4u; per_level[levels++] = width; } while (width > 1u && levels < kCullMaxLevels);
+    return levels;
 }
-// leaf references of a QuadNode tree whose leaves hold at least big_min triangles get kBigLeafBit
-__global__ void k_mark_big_leaves(QuadNode *quads, uint32_t n_quads, const TriRecord *recs, uint32_t n, uint32_t big_min, uint32_t *marked) {
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n_quads * 4u) return;
-    QuadNode &q = quads[i >> 2];
-    const uint32_t k = i & 3u;
-    if (k >= q.count) return;
-    const uint32_t ref = q.ref[k];
-    if (!(ref & kLeafBit)) return;
-    const uint32_t first = ref & kSlotMask;
-    if (first < n && recs[first].remaining >= big_min) { q.ref[k] = ref | kBigLeafBit; atomicAdd(marked, 1u); }
+// the leaf an entry of the folded tree refers to, if it is to get cull nodes: entry e = 4 * quad + k; e = 4 * n_quads is
+// the tree's root when the whole tree is one leaf
+__device__ __forceinline__ bool cull_candidate(const QuadNode *quads, uint32_t n_quads, uint32_t root, const TriRecord *recs, uint32_t n,
+                                               uint32_t big_min, uint32_t e, uint32_t &first, uint32_t &count) {
+    uint32_t ref;
+    if (e == 4u * n_quads) ref = root;
+    else {
+        const QuadNode &q = quads[e >> 2];
+        if ((e & 3u) >= q.count) return false;
+        ref = q.ref[e & 3u];
+    }
+    if (!(ref & kLeafBit)) return false;
+    first = ref & kSlotMask;
+    if (first >= n) return false;
+    count = recs[first].remaining;
+    return count >= big_min && count <= kCullMaxLeaf && first + count <= n;
+}
+__global__ void k_cull_sizes(const QuadNode *quads, uint32_t n_quads, uint32_t root, const TriRecord *recs, uint32_t n, uint32_t big_min,
+                             uint32_t *size, uint32_t *stats) {
+    const uint32_t e = blockIdx.x * kBlock + threadIdx.x;
+    if (e > 4u * n_quads) return;
+    uint32_t first, count, nodes = 0;
+    if (cull_candidate(quads, n_quads, root, recs, n, big_min, e, first, count)) {
+        uint32_t per_level[kCullMaxLevels];
+        const uint32_t levels = cull_levels(count, per_level);
+        for (uint32_t l = 0; l < levels; l++) nodes += per_level[l];
+        atomicMax(stats + 6, levels);
+        atomicAdd(stats + 7, 1u);
+        atomicAdd(stats + 8, count);
+    }
+    size[e] = nodes;
+}
+__global__ void k_cull_emit(QuadNode *quads, uint32_t n_quads, uint32_t root, uint32_t *root_out, const TriRecord *recs, uint32_t n,
+                            uint32_t big_min, const uint32_t *offset, const float *box, const float *bound) {
+    const uint32_t e = blockIdx.x * kBlock + threadIdx.x;
+    if (e > 4u * n_quads) return;
+    uint32_t first, count;
+    if (!cull_candidate(quads, n_quads, root, recs, n, big_min, e, first, count)) return;
+    uint32_t per_level[kCullMaxLevels];
+    const uint32_t levels = cull_levels(count, per_level);
+    const uint32_t base = n_quads + offset[e];
+    // start[l]: where level l + 1's nodes begin (root level first)
+    uint32_t start[kCullMaxLevels];
+    uint32_t at = base;
+    for (int l = (int)levels - 1; l >= 0; l--) { start[l] = at; at += per_level[l]; }
+    uint32_t span = 1;                                       // triangles under one entry of the level
+    for (uint32_t l = 0; l < levels; l++) {
+        const uint32_t children = l == 0 ? count : per_level[l - 1];
+        for (uint32_t i = 0; i < per_level[l]; i++) {
+            QuadNode node;
+            uint32_t used = 0;
+            for (uint32_t k = 0; k < 4; k++) {
+                const uint32_t child = 4u * i + k;
+                if (child < children) {
+                    const uint32_t t0 = child * span, t1 = (t0 + span < count) ? t0 + span : count;
+                    float lo[3], hi[3];
+                    for (int a = 0; a < 3; a++) { lo[a] = box[(size_t)(first + t0) * 6 + a]; hi[a] = box[(size_t)(first + t0) * 6 + 3 + a]; }
+                    for (uint32_t t = t0 + 1; t < t1; t++)
+                        for (int a = 0; a < 3; a++) {
+                            lo[a] = fminf(lo[a], box[(size_t)(first + t) * 6 + a]);
+                            hi[a] = fmaxf(hi[a], box[(size_t)(first + t) * 6 + 3 + a]);
+                        }
+                    for (int a = 0; a < 3; a++) { node.plane[k][a][0] = lo[a]; node.plane[k][a][1] = hi[a]; }
+                    node.ref[k] = l == 0 ? (kLeafBit | kOneBit | (first + child)) : (kOneBit | (start[l - 1] + child));
+                    used += 1;
+                } else {
+                    // absent entry: a one-point box (never entered), as in every QuadNode
+                    for (int a = 0; a < 3; a++) node.plane[k][a][0] = node.plane[k][a][1] = bound[a];
+                    node.ref[k] = 0u;
+                }
+            }
+            node.count = used;
+            node.pad_[0] = node.pad_[1] = node.pad_[2] = 0u;
+            quads[start[l] + i] = node;
+        }
+        span *= 4u;
+    }
+    // the leaf's reference becomes the reference of its root cull node
+    if (e == 4u * n_quads) *root_out = base;
+    else quads[e >> 2].ref[e & 3u] = base;
 }
 
 }  // namespace
 
-// The leaf cull's arrays from the packed scene (whoever packed it: ct_pack's kernels or the host restatement), and the
-// big-leaf marks in both QuadNode trees.  big_min = 0: no leaf is marked (the arrays are made all the same, the marks decide).
-int ctgpu_pack_cull_on_device(int device, const void *d_tris, uint32_t n, void *d_quads, uint32_t n_quads, void *d_quads_flat,
-                              uint32_t n_quads_flat, uint32_t big_min, ctgpu_cull_scene *out) {
-    if (!d_tris || !d_quads || !d_quads_flat || !out || n == 0) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_pack_cull_on_device: null argument");
+// The cull nodes of the folded tree's big leaves (whoever packed the tree: ct_pack's kernels or the host restatement).
+// d_quads (n_quads QuadNodes, root reference quad_root) is left as it is; when any leaf gets cull nodes, out->quads is a
+// second, longer array -- the tree's own QuadNodes first, unchanged but for the references to those leaves, then the cull
+// nodes -- with out->quad_root its root reference.
+int ctgpu_pack_cull_on_device(int device, const void *d_tris, uint32_t n, const void *d_quads, uint32_t n_quads, uint32_t quad_root,
+                              uint32_t big_min, uint32_t share_percent, const float plane_bound[3], ctgpu_cull_scene *out) {
+    if (!d_tris || !d_quads || !out || n == 0) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_pack_cull_on_device: null argument");
     HIP_TRY(hipSetDevice(device));
     Owned owned;
-    const uint32_t n_tri_quads = (n + 3u) / 4u, n_groups = (n + 15u) / 16u;
-    QuadNode *tri_quads = nullptr, *tri_groups = nullptr;
-    uint32_t *d_stats = nullptr;
-    HIP_TRY(owned.alloc(tri_quads, n_tri_quads));
-    HIP_TRY(owned.alloc(tri_groups, n_groups));
-    HIP_TRY(owned.alloc(d_stats, 8));
-    HIP_TRY(hipMemsetAsync(tri_quads, 0, (size_t)n_tri_quads * sizeof(QuadNode), nullptr));
-    HIP_TRY(hipMemsetAsync(tri_groups, 0, (size_t)n_groups * sizeof(QuadNode), nullptr));
-    HIP_TRY(hipMemsetAsync(d_stats, 0, 8 * sizeof(uint32_t), nullptr));
+    float *box = nullptr, *d_bound = nullptr;
+    uint32_t *d_stats = nullptr, *d_size = nullptr, *d_offset = nullptr, *d_root = nullptr;
+    const uint32_t entries = 4u * n_quads + 1u;
+    HIP_TRY(owned.alloc(box, (size_t)n * 6));
+    HIP_TRY(owned.alloc(d_stats, 12));
+    HIP_TRY(owned.alloc(d_size, entries));
+    HIP_TRY(owned.alloc(d_offset, (size_t)entries + 1));
+    HIP_TRY(owned.alloc(d_root, 1));
+    HIP_TRY(owned.alloc(d_bound, 3));
+    HIP_TRY(hipMemsetAsync(d_stats, 0, 12 * sizeof(uint32_t), nullptr));
     const TriRecord *recs = (const TriRecord *)d_tris;
-    hipLaunchKernelGGL(k_tri_boxes, dim3(blocks_for(n)), dim3(kBlock), 0, nullptr, recs, n, tri_quads, tri_groups, d_stats);
-    hipLaunchKernelGGL(k_tri_group_boxes, dim3(blocks_for(n_tri_quads)), dim3(kBlock), 0, nullptr, (const QuadNode *)tri_quads, n, tri_groups);
-    if (big_min) {
-        hipLaunchKernelGGL(k_mark_big_leaves, dim3(blocks_for((uint64_t)n_quads * 4u)), dim3(kBlock), 0, nullptr, (QuadNode *)d_quads, n_quads, recs, n, big_min, d_stats + 6);
-        hipLaunchKernelGGL(k_mark_big_leaves, dim3(blocks_for((uint64_t)n_quads_flat * 4u)), dim3(kBlock), 0, nullptr, (QuadNode *)d_quads_flat, n_quads_flat, recs, n, big_min, d_stats + 7);
-    }
+    hipLaunchKernelGGL(k_tri_boxes, dim3(blocks_for(n)), dim3(kBlock), 0, nullptr, recs, n, box, d_stats);
     HIP_TRY(hipGetLastError());
-    uint32_t stats[8];
+    uint32_t stats[12];
     HIP_TRY(hipMemcpy(stats, d_stats, sizeof stats, hipMemcpyDeviceToHost));
     std::memcpy(&out->edge_bound, &stats[0], 4);
     std::memcpy(&out->vertex_bound, &stats[1], 4);
     std::memcpy(out->plane_bound, &stats[2], 12);
     out->usable = stats[5] == 0u;
-    out->n_big_leaves = stats[6];
-    out->n_tri_quads = n_tri_quads;
-    out->n_groups = n_groups;
-    owned.keep(tri_quads);
-    owned.keep(tri_groups);
-    out->tri_quads = tri_quads;
-    out->tri_groups = tri_groups;
+    out->cull_first = kNoNode; out->n_cull = 0; out->levels = 0; out->n_big_leaves = 0;
+    if (!out->usable || big_min == 0u) return CTGPU_OK;
+    // (the gate of appendix D can never open when K K S > 2^20 with S >= 3 V even for an eye inside the scene: a scene
+    //  of such magnitudes -- scene_file_cube.json's 200-unit floor triangles -- would only pay for cull nodes)
+    if (!((double)out->edge_bound * out->edge_bound * 3.0 * out->vertex_bound <= 0x1p20)) return CTGPU_OK;
+
+    // the bound the filter will use (and the absent entries sit at): the tree's planes and the triangle boxes'
+    float bound[3];
+    for (int c = 0; c < 3; c++) bound[c] = std::max(plane_bound[c], std::nextafterf(out->plane_bound[c], INFINITY));
+    HIP_TRY(hipMemcpy(d_bound, bound, sizeof bound, hipMemcpyHostToDevice));
+    Scanner scan;
+    int rc = scan.prepare(entries); if (rc) return rc;
+    const QuadNode *quads = (const QuadNode *)d_quads;
+    hipLaunchKernelGGL(k_cull_sizes, dim3(blocks_for(entries)), dim3(kBlock), 0, nullptr, quads, n_quads, quad_root, recs, n, big_min, d_size, d_stats);
+    scan.run(d_size, entries, d_offset, nullptr);
+    HIP_TRY(hipGetLastError());
+    uint32_t n_cull = 0;
+    HIP_TRY(hipMemcpy(&n_cull, d_offset + entries, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(stats, d_stats, sizeof stats, hipMemcpyDeviceToHost));
+    out->triangles_in_big_leaves = stats[8];
+    if (n_cull == 0u) return CTGPU_OK;
+    // cull nodes pay where the leaves they replace are where the walk's time goes; a scene with few triangles in big
+    // leaves keeps its plain tree and the walk kernels that do not carry the cull code (share_percent of all triangles)
+    if ((uint64_t)stats[8] * 100u < (uint64_t)share_percent * n) return CTGPU_OK;
+    if ((uint64_t)n_quads + n_cull >= (uint64_t)kBigLeafBit) return CTGPU_OK;                 // (references stay below the flag bits)
+    QuadNode *longer = nullptr;
+    HIP_TRY(owned.alloc(longer, (size_t)n_quads + n_cull));
+    HIP_TRY(hipMemcpy(longer, quads, (size_t)n_quads * sizeof(QuadNode), hipMemcpyDeviceToDevice));
+    HIP_TRY(hipMemcpy(d_root, &quad_root, 4, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_cull_emit, dim3(blocks_for(entries)), dim3(kBlock), 0, nullptr, longer, n_quads, quad_root, d_root, recs, n, big_min,
+                       (const uint32_t *)d_offset, (const float *)box, (const float *)d_bound);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(&out->quad_root, d_root, 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipDeviceSynchronize());
+    owned.keep(longer);
+    out->quads = longer;
+    out->cull_first = n_quads;
+    out->n_cull = n_cull;
+    out->levels = stats[6];
+    out->n_big_leaves = stats[7];
     return CTGPU_OK;
 }
 

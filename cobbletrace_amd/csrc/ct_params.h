@@ -50,9 +50,8 @@ struct FrameParams {
     uint32_t stack_depth;         // LDS stack entries per lane
     double   root_min[3], root_max[3];
     float    plane_bound[3];      // >= |plane| of every box in the tree AND of every triangle box, per axis (+inf: no filter)
-    const QuadNode *tri_quads;    // the leaf cull (ct_device.h "triangle boxes"): boxes of four TriRecord slots each ...
-    const QuadNode *tri_groups;   // ... and of sixteen, with the last-of-leaf flags
-    CullLimits cull;              // which rays may use them (d_lim = 0: none), from the scene's magnitudes and the eye
+    uint32_t cull_first;          // QuadNodes from this index on are cull nodes (ct_device.h; kNoNode: the scene has none)
+    CullLimits cull;              // which rays may skip their entries (d_lim = 0: none), from the scene's magnitudes and the eye
 
     // frame
     int32_t  width, height, half; // bitmap size; half = height/2
@@ -136,7 +135,6 @@ struct PipelineParams {
     uint32_t list_slots;         // 1: ray_hits[].triangle receives the TriRecord SLOT (kNoNode: none recorded), not the scene triangle
     uint32_t list_counter;       // frame counter word the walk adds its ray count to (0: none; 1 shadow rays, 2 reflected rays)
     const uint32_t *list_gate;   // when set and *list_gate == 0 the list holds no ray: the walk's waves leave at once
-    uint32_t big_leaves;         // 1: the scene has leaves marked kBigLeafBit and a usable gate: the BIGLEAF instantiations walk
     uint32_t ordered;            // 1: the frame's packet walks are the ORDERED instantiations, order[] is set
     OrderParams order[2];
 };

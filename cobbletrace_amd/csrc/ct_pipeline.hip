@@ -743,9 +743,8 @@ extern "C" __attribute__((visibility("default"))) int ctgpu_debug_packet_trace(u
 // cost the primary walk 12 % through register pressure: profiles/r03_handover_sweep.log).
 // ORDERED: chunks the frame before found heavy come first, in parts where that frame's packets were few (ct_params.h,
 // OrderParams), then every other chunk in the usual order; each packet adds its fetches to its chunk's cost word.
-// BIGLEAF: leaves marked kBigLeafBit go through their triangle boxes (scenes that have such leaves; a scene without
-// them runs the instantiation that does not carry the code).
-template <int KIND, bool SS, bool HANDOVER = false, bool ORDERED = false, bool BIGLEAF = false>
+// CULL: the tree holds cull nodes (ct_device.h; a scene without them runs the instantiation that does not carry the code).
+template <int KIND, bool SS, bool HANDOVER = false, bool ORDERED = false, bool CULL = false>
 __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const FrameParams P, const PipelineParams W) {
     const uint32_t q_chunk = (KIND == 1) ? W.chunk_shadow : W.chunk;      // ray ids per queue atomic
     constexpr bool LIST = KIND >= 2;                 // rays come from W.ray_list instead of the frame's samples
@@ -961,11 +960,12 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
             }
         }
 
-        // which of the packet's rays may use the leaf cull (ct_device.h "triangle boxes", DESIGN appendix D): magnitudes
+        // Which of the packet's rays may skip entries of cull nodes (ct_device.h "cull nodes", DESIGN appendix D): magnitudes
         // inside the frame's gate; a caller's closest-hit ray only when it starts at 1e30f like a frame's ray (with any
-        // other start a "hit" that does not lower ray.t still records its triangle, bvh.cpp:212)
+        // other start a "hit" that does not lower ray.t still records its triangle, bvh.cpp:212).  A closest-hit ray
+        // skips only while its ray.t is at least tau (looked at where a skip is decided).
         unsigned long long cull_lanes = 0ull;
-        if (BIGLEAF) {
+        if (CULL && P.cull.d_lim > 0.0f) {
             const double d_lim = (double)P.cull.d_lim, o_lim = (double)P.cull.o_lim;
             bool ok = has_ray && __builtin_fabs(d.x) <= d_lim && __builtin_fabs(d.y) <= d_lim && __builtin_fabs(d.z) <= d_lim;
             if (KIND != 0) ok = ok && __builtin_fabs(shadow_o.x) <= o_lim && __builtin_fabs(shadow_o.y) <= o_lim && __builtin_fabs(shadow_o.z) <= o_lim;
@@ -1001,6 +1001,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
             // (from the ray's own start value: a caller's / a bounce level's ray may start at 0, raythread.cpp:373)
             if (redo) { t = (LIST && !ANY_HIT) ? W.ray_list[ray_id].t : kNoHit; slot = kNoNode; }
         }
+        const uint32_t cull_first = (CULL && walk_pass == 0) ? P.cull_first : kNoNode;      // (the unfolded tree has no cull nodes)
         unsigned long long tracing = walk_pass == 0 ? __ballot(has_ray) : __ballot(redo);
         uint32_t cur = walk_pass == 0 ? P.quad_root : P.quad_root_flat;
         unsigned long long mask = walk_pass == 0 ? __ballot(root_pass) : tracing;
@@ -1058,83 +1059,19 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                     visits = 0u; lane_visits = 0u;             // still sharing well: look again after another `budget`
                 }
             }
-            if (BIGLEAF && (cur & (kLeafBit | kBigLeafBit)) == (kLeafBit | kBigLeafBit)) {
-                // A leaf of many triangles, by way of its triangle boxes: the reference tests every triangle of the leaf
-                // in index order (bvh.cpp:208-218); a lane skips the ones whose (grown) box its ray certainly misses --
-                // there IntersectTriangle returns false or leaves ray.t alone (appendix D) -- and makes the others' tests,
-                // in the same order.  Sixteen slots a step: the group's four boxes (four slots each), then the boxes of
-                // the groups some lane may hit, then the records.  Every lane computes every box (the masked-out ones on
-                // stale rays, as in the node visit); the masks are wave-uniform.
-                PK_T0();
-                uint32_t s = cur & kSlotMask;
-                for (;;) {
-                    unsigned long long act = mask;
-                    if (ANY_HIT) act &= __ballot(t == kNoHit);
-                    if (act == 0ull) break;                              // (any-hit: every ray of the leaf has met its blocker)
-                    const uint32_t group = s >> 4;
-                    const ScalarQuad gq = scalar_load_quad(P.tri_groups + group);
-                    n_quads += 1;
-                    // the leaf's slots in this group: from s up to the first last-of-leaf flag
-                    const uint32_t flags = gq.count() >> (s & 15u);
-                    const uint32_t stop = flags != 0u ? s + (uint32_t)__builtin_ctz(flags) + 1u : (group + 1u) << 4;
-                    // a closest hit prunes boxes beyond ray.t (1 + 2^-12) once ray.t has reached tau (appendix D.4)
-                    const float t_cull = ANY_HIT ? t : ((t >= P.cull.tau) ? t * (1.0f + 0x1p-12f) : __builtin_inff());
-                    unsigned long long live[4];
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        float tmin_j, least, margin;
-                        box_filter_f32_oct<OCT, ANY_HIT>(rf, gq.planes(j, 0), gq.planes(j, 1), gq.planes(j, 2), t_cull, tmin_j, least, margin);
-                        live[j] = act & ~(__ballot(least < -margin) & cull_lanes);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 4; j++) {
-                        const uint32_t base = (group << 4) + 4u * (uint32_t)j;
-                        const uint32_t lo = s > base ? s : base, hi = stop < base + 4u ? stop : base + 4u;
-                        if (lo >= hi || live[j] == 0ull) continue;
-                        const ScalarQuad tq = scalar_load_quad(P.tri_quads + (base >> 2));
-                        n_quads += 1;
-                        unsigned long long wants[4];
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            float tmin_k, least, margin;
-                            box_filter_f32_oct<OCT, ANY_HIT>(rf, tq.planes(k, 0), tq.planes(k, 1), tq.planes(k, 2), t_cull, tmin_k, least, margin);
-                            wants[k] = live[j] & ~(__ballot(least < -margin) & cull_lanes);
-                        }
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const uint32_t at = base + (uint32_t)k;
-                            if (at < lo || at >= hi || wants[k] == 0ull) continue;
-                            const ScalarTri tr = scalar_load_tri(P.tris + at);
-                            n_records += 1;
-                            if (__builtin_amdgcn_inverse_ballot_w64(wants[k]) && (!ANY_HIT || t == kNoHit)) {
-                                const d3 p1 = make_d3(tr.f64(0), tr.f64(1), tr.f64(2)), e1 = make_d3(tr.f64(3), tr.f64(4), tr.f64(5)),
-                                         e2 = make_d3(tr.f64(6), tr.f64(7), tr.f64(8));
-                                const float before = t;
-                                const bool hit = triangle_test(RAY_O, d, t, p1, e1, e2);
-                                const float tclosest = (slot != kNoNode) ? before : kFarAway;      // bvh.cpp:212-215
-                                if (hit && t != kNoHit && t < tclosest) slot = at;
-                            }
-                        }
-                    }
-                    if (flags != 0u) break;
-                    s = stop;
-                }
-                if (ANY_HIT) tracing &= __ballot(t == kNoHit);
-                mask = 0ull;               // on to the pop below
-                PK_T1(1);
-            } else if (cur & kLeafBit) {
+            if (cur & kLeafBit) {
                 // leaf: every triangle in index order, each lane keeps its own closest hit
                 const uint32_t first = cur & kSlotMask;
                 const bool mine = __builtin_amdgcn_inverse_ballot_w64(mask);
                 PK_T0();
-                uint32_t count = 1;        // the first record says how many the leaf holds
+                uint32_t count = 1;        // the first record says how many the leaf holds (a cull node's entry: this one only)
 #ifdef CT_SKIP_LEAF_KIND                   // diagnostic build: the walk alone, no triangle is loaded or tested
                 if (KIND == CT_SKIP_LEAF_KIND) count = 0;
 #endif
                 for (uint32_t k = 0; k < count; k++) {
                     const ScalarTri tr = scalar_load_tri(P.tris + first + k);
                     if (k == 0) {
-                        count = tr.remaining();
+                        count = (CULL && (cur & kOneBit)) ? 1u : tr.remaining();
                         n_records += count;
                         PK_COUNT(2, count);
                         PK_COUNT(3, (uint64_t)count * __popcll(mask));
@@ -1189,7 +1126,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                 PK_COUNT(0, 1);
                 n_quads += 1;
                 PK_COUNT(1, __popcll(mask));
-                const uint32_t node_id = cur;
+                const uint32_t node_id = CULL ? (cur & kSlotMask) : cur;       // (a cull node's entries carry kOneBit)
                 const ScalarQuad sq = scalar_load_quad(quads + node_id);
 #ifdef CT_DUMMY_VALU                       // diagnostic builds: what N more vector / scalar instructions per visit cost
                 {
@@ -1218,6 +1155,22 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                 // entry comes from one compare: the least of |least_k| - margin_k must be positive
                 // (a NaN, or the rare ray that grazes that corner point, sends the wave to the exact
                 // levels, which look at the entries one by one).
+                // A cull node (ct_device.h): its entries' boxes only ever EXCLUDE -- a lane stays out of an entry when the
+                // filter proves that the real slab test on the stored planes fails (`least < -margin`: the bound of appendix
+                // B read from the other side) and its ray is inside the gate (appendix D; a closest-hit ray only while its
+                // ray.t is at least tau); undecided lanes and lanes outside the gate go in.  No exact levels: nothing here
+                // is decided against the reference's arithmetic, only triangle tests with a known outcome are left out.
+                const bool cull_node = CULL && node_id >= cull_first;
+                if (cull_node) {
+                    const unsigned long long gated = ANY_HIT ? cull_lanes : (cull_lanes & __ballot(t >= P.cull.tau));
+                    const uint32_t n_entries = sq.count();
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        float least, margin;
+                        box_filter_f32_oct<OCT, ANY_HIT>(rf, sq.planes(k, 0), sq.planes(k, 1), sq.planes(k, 2), t, tmin[k], least, margin);
+                        enter[k] = ((uint32_t)k < n_entries) ? (mask & ~(__ballot(least < -margin) & gated)) : 0ull;
+                    }
+                } else {
                 float worst = 0.0f;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
@@ -1239,6 +1192,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                         box_filter_f32<ANY_HIT>(rf, sq.planes(k, 0), sq.planes(k, 1), sq.planes(k, 2), t, tmin_again, least, margin);
                         unsure_of[k] = ((uint32_t)k < n_entries) ? (__ballot(!(__builtin_fabsf(least) > margin)) & mask) : 0ull;
                     }
+                    {
                     // level 1 (some lane sits inside the bound): binary64 planes, one-step margins;
                     // level 2 (rarer still): the reference's divisions.  One box at a time, planes by
                     // vector load: this path is rare and must stay light on registers (it would
@@ -1273,7 +1227,9 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
 #pragma unroll
                     for (int k = 0; k < 4; k++)
                         enter[k] = ((enter[k] & ~unsure_of[k]) | __ballot(((passed >> k) & 1u) != 0u)) & ~gone;
+                    }
                 }
+                }   // (not a cull node)
                 PK_T1(0);
                 // the first entry some lane enters comes next; later ones wait on the stack (pushed last
                 // first), each lane's `tmin < ray.t` re-evaluated when the entry is popped.  Going down
@@ -1314,14 +1270,26 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                 const uint32_t pushed_hi = (uint32_t)__builtin_amdgcn_readlane(stack_mask_hi, (int)sp);
                 const unsigned long long pushed = ((unsigned long long)pushed_lo | ((unsigned long long)pushed_hi << 32)) & tracing;
                 if (pushed == 0ull) continue;
-                bool keep = false;
+                bool keep = false, unsettled = false;
                 if (__builtin_amdgcn_inverse_ballot_w64(pushed)) {
                     // the deferred  tmin < ray.t : from the filter's tmin, good to M(tmin) -- and settled beforehand for an
                     // any-hit ray the filter takes (ray.t = 1e30f while it is traced, |tmin| < 2^84: ray_filter's e_limit)
-                    bool settled;
-                    if (ANY_HIT) { keep = true; settled = rf.noi_z_e.y != __builtin_inff(); }
-                    else settled = deferred_verdict_f32(st.get_tmin(sp, lane), rf.noi_z_e.y, t, keep);
-                    if (!settled) {
+                    if (ANY_HIT) { keep = true; unsettled = rf.noi_z_e.y == __builtin_inff(); }
+                    else { bool settled = deferred_verdict_f32(st.get_tmin(sp, lane), rf.noi_z_e.y, t, keep); unsettled = !settled; }
+                }
+                cur = (uint32_t)__builtin_amdgcn_readlane(stack_ref, (int)sp);
+                // An entry a cull node pushed (a lower cull node, or one triangle: kOneBit): no binary64 box stands behind
+                // it; a lane stays out only when "beyond ray.t" is certain and its ray is inside the gate -- all at the level
+                // of wave masks.  (The root of a leaf's cull nodes was pushed by an ordinary node: the leaf's own box, the
+                // reference's test, settled exactly like any entry's.)
+                const bool cull_entry = CULL && (cur & kOneBit) != 0u;
+                if (cull_entry) {
+                    mask = (__ballot(keep) | __ballot(unsettled) | ~(ANY_HIT ? cull_lanes : (cull_lanes & __ballot(t >= P.cull.tau)))) & pushed;
+                    PK_T1(2);
+                    continue;
+                }
+                if (__ballot(unsettled) != 0ull) {
+                    if (unsettled) {
                         // too close to ray.t to trust (or a ray the filter does not take: e = inf): tmin from
                         // the binary64 box, one step off at most -- and if that is still too close, the whole
                         // test exactly
@@ -1339,7 +1307,6 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                     }
                 }
                 mask = __ballot(keep);
-                cur = (uint32_t)__builtin_amdgcn_readlane(stack_ref, (int)sp);
                 PK_T1(2);
             }
         }
@@ -1944,19 +1911,21 @@ __global__ __launch_bounds__(256) void ct_order_build(const OrderBuild primary, 
     if (there) A.listed[c] = listed;
 }
 
-// the frame's packet walk of one kind: the instantiation for its sampling, order and leaves (the hand-over experiment
-// has none with the leaf cull: its marked leaves are walked record by record)
+// the frame's packet walk of one kind: the instantiation for its sampling, its order, its tree (with or without cull nodes)
 template <int KIND>
-static void launch_frame_walk(bool ss, bool handover, bool ordered, bool big, dim3 grid, dim3 wave, size_t lds, hipStream_t stream,
+static void launch_frame_walk(bool ss, bool handover, bool ordered, bool cull, dim3 grid, dim3 wave, size_t lds, hipStream_t stream,
                               const FrameParams &P, const PipelineParams &W) {
-#define CT_WALK(SS_, HO_, ORD_, BIG_) hipLaunchKernelGGL((ct_walk_packet<KIND, SS_, HO_, ORD_, BIG_>), grid, wave, lds, stream, P, W)
-    if (handover) { if (ss) CT_WALK(true, true, false, false); else CT_WALK(false, true, false, false); return; }
+#define CT_WALK(SS_, HO_, ORD_, CULL_) hipLaunchKernelGGL((ct_walk_packet<KIND, SS_, HO_, ORD_, CULL_>), grid, wave, lds, stream, P, W)
+    if (handover) {           // (the hand-over experiment always carries the cull code: one instantiation per sampling)
+        if (ss) CT_WALK(true, true, false, true); else CT_WALK(false, true, false, true);
+        return;
+    }
     if (ss) {
-        if (ordered) { if (big) CT_WALK(true, false, true, true); else CT_WALK(true, false, true, false); }
-        else { if (big) CT_WALK(true, false, false, true); else CT_WALK(true, false, false, false); }
+        if (ordered) { if (cull) CT_WALK(true, false, true, true); else CT_WALK(true, false, true, false); }
+        else { if (cull) CT_WALK(true, false, false, true); else CT_WALK(true, false, false, false); }
     } else {
-        if (ordered) { if (big) CT_WALK(false, false, true, true); else CT_WALK(false, false, true, false); }
-        else { if (big) CT_WALK(false, false, false, true); else CT_WALK(false, false, false, false); }
+        if (ordered) { if (cull) CT_WALK(false, false, true, true); else CT_WALK(false, false, true, false); }
+        else { if (cull) CT_WALK(false, false, false, true); else CT_WALK(false, false, false, false); }
     }
 #undef CT_WALK
 }
@@ -2004,14 +1973,14 @@ void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hip
         const size_t lds_l = (size_t)W.lds_depth * kWave * 12u;
         const dim3 grid_l(W.listed_blocks);
         const bool handover = W.packet_budget != 0u;
-        launch_frame_walk<0>(ss, handover, ordered, W.big_leaves != 0u, grid, wave, lds_p, stream, P, W);
+        launch_frame_walk<0>(ss, handover, ordered, P.cull_first != kNoNode, grid, wave, lds_p, stream, P, W);
         if (handover && ss) hipLaunchKernelGGL((ct_walk<0, true, true>), grid_l, wave, lds_l, stream, P, W);
         if (handover && !ss) hipLaunchKernelGGL((ct_walk<0, false, true>), grid_l, wave, lds_l, stream, P, W);
         sphere_pass(0);
         mark(2);
         if (shadows) light_gate();
         mark(3);
-        if (shadows) launch_frame_walk<1>(ss, handover, ordered, W.big_leaves != 0u, grid, wave, lds_p, stream, P, W);
+        if (shadows) launch_frame_walk<1>(ss, handover, ordered, P.cull_first != kNoNode, grid, wave, lds_p, stream, P, W);
         if (shadows && handover && ss) hipLaunchKernelGGL((ct_walk<1, true, true>), grid_l, wave, lds_l, stream, P, W);
         if (shadows && handover && !ss) hipLaunchKernelGGL((ct_walk<1, false, true>), grid_l, wave, lds_l, stream, P, W);
     } else {
@@ -2058,15 +2027,13 @@ void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hip
         B.level = level;
         Wc.list_gate = Ws.list_gate = B.level_live + level;
         (void)hipMemsetAsync(W.queue, 0, queue_bytes, stream);
-        if (W.big_leaves) hipLaunchKernelGGL((ct_walk_packet<2, false, false, false, true>), list_grid(Wc.n_samples), wave, lds_p, stream, P, Wc);
-        else hipLaunchKernelGGL((ct_walk_packet<2, false>), list_grid(Wc.n_samples), wave, lds_p, stream, P, Wc);
+        hipLaunchKernelGGL((ct_walk_packet<2, false, false, false, true>), list_grid(Wc.n_samples), wave, lds_p, stream, P, Wc);
         if (sph) hipLaunchKernelGGL((ct_bounce_spheres<0>), strided, threads, 0, stream, P, W, B);
         if (shadows) {
             if (sph) hipLaunchKernelGGL((ct_bounce_gate<true>), strided, threads, 0, stream, P, W, B);
             else hipLaunchKernelGGL((ct_bounce_gate<false>), strided, threads, 0, stream, P, W, B);
             (void)hipMemsetAsync(W.queue, 0, queue_bytes, stream);
-            if (W.big_leaves) hipLaunchKernelGGL((ct_walk_packet<3, false, false, false, true>), list_grid(Ws.n_samples), wave, lds_p, stream, P, Ws);
-            else hipLaunchKernelGGL((ct_walk_packet<3, false>), list_grid(Ws.n_samples), wave, lds_p, stream, P, Ws);
+            hipLaunchKernelGGL((ct_walk_packet<3, false, false, false, true>), list_grid(Ws.n_samples), wave, lds_p, stream, P, Ws);
             if (sph) hipLaunchKernelGGL((ct_bounce_spheres<1>), strided, threads, 0, stream, P, W, B);
         }
         if (sph) hipLaunchKernelGGL((ct_bounce_shade<true>), strided, threads, 0, stream, P, W, B);
@@ -2082,14 +2049,8 @@ void launch_packet_ray_list(const FrameParams &P, const PipelineParams &W, bool 
     if (W.n_samples == 0) return;
     const uint32_t depth_p = W.packet_depth;
     const size_t lds_p = PacketStack::bytes(depth_p, W.packet_lds_levels < depth_p ? W.packet_lds_levels : depth_p);
-    const dim3 grid(W.walk_blocks), wave(kWave);
-    if (any_hit) {
-        if (W.big_leaves) hipLaunchKernelGGL((ct_walk_packet<3, false, false, false, true>), grid, wave, lds_p, stream, P, W);
-        else hipLaunchKernelGGL((ct_walk_packet<3, false>), grid, wave, lds_p, stream, P, W);
-    } else {
-        if (W.big_leaves) hipLaunchKernelGGL((ct_walk_packet<2, false, false, false, true>), grid, wave, lds_p, stream, P, W);
-        else hipLaunchKernelGGL((ct_walk_packet<2, false>), grid, wave, lds_p, stream, P, W);
-    }
+    if (any_hit) hipLaunchKernelGGL((ct_walk_packet<3, false, false, false, true>), dim3(W.walk_blocks), dim3(kWave), lds_p, stream, P, W);
+    else hipLaunchKernelGGL((ct_walk_packet<2, false, false, false, true>), dim3(W.walk_blocks), dim3(kWave), lds_p, stream, P, W);
 }
 
 }  // namespace ctd

@@ -42,18 +42,21 @@ struct ctgpu_packed_scene {
 CTGPU_HIDDEN int ctgpu_pack_on_device(int device, const ctgpu_node *d_nodes, uint32_t n_nodes, const uint32_t *d_indexes,
                                       const double *d_vertices, uint32_t n_triangles, ctgpu_packed_scene *out);
 
-// the leaf cull's arrays (ct_device.h "triangle boxes"), made from packed TriRecords / QuadNodes that are already on
-// the device; marks the leaves of at least big_min triangles in both QuadNode trees
+// the cull nodes of the folded tree's big leaves (ct_device.h "cull nodes"), made from packed TriRecords / QuadNodes that
+// are already on the device: a second QuadNode array (the tree with cull nodes behind it) beside the plain one
 struct ctgpu_cull_scene {
-    void *tri_quads = nullptr, *tri_groups = nullptr;      // QuadNode[n_tri_quads], QuadNode[n_groups]: hipMalloc'ed, caller owns
-    uint32_t n_tri_quads = 0, n_groups = 0;
-    uint32_t n_big_leaves = 0;                             // leaves marked in the folded tree
+    void *quads = nullptr;                                 // QuadNode[cull_first + n_cull], hipMalloc'ed, caller owns (NULL: no cull nodes)
+    uint32_t quad_root = 0;                                // root reference of that array's tree
+    uint32_t cull_first = 0xffffffffu;                     // first cull node in it (kNoNode: none)
+    uint32_t n_cull = 0, n_big_leaves = 0, levels = 0;     // cull nodes, leaves that got them, levels of the tallest such tree
+    uint32_t triangles_in_big_leaves = 0;
     float edge_bound = 0, vertex_bound = 0;                // >= every |e1|, |e2| component; >= every |vertex coordinate|
     float plane_bound[3] = {0, 0, 0};                      // >= |plane| of every triangle box, per axis
     bool usable = false;                                   // false: some coordinate is not finite -- no cull for this scene
 };
-CTGPU_HIDDEN int ctgpu_pack_cull_on_device(int device, const void *d_tris, uint32_t n_triangles, void *d_quads, uint32_t n_quads,
-                                           void *d_quads_flat, uint32_t n_quads_flat, uint32_t big_min, ctgpu_cull_scene *out);
+CTGPU_HIDDEN int ctgpu_pack_cull_on_device(int device, const void *d_tris, uint32_t n_triangles, const void *d_quads, uint32_t n_quads,
+                                           uint32_t quad_root, uint32_t big_min, uint32_t share_percent, const float plane_bound[3],
+                                           ctgpu_cull_scene *out);
 
 // one process, several devices (ctgpu_render_multi)
 CTGPU_HIDDEN int ctgpu_multi_comms(const int *devices, int n, std::vector<void *> &comms);

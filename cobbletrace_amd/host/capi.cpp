@@ -129,17 +129,17 @@ uint64_t cth_index_hash(void *p) {
 
 // ---- RayThread driven from the harness: the caller's buffer becomes env->bitmap->memory
 void cth_raythread_options(int rng_mode, uint64_t seed, int device, int n_devices) {
-    const ct_raythread_options o{rng_mode, seed, device, n_devices, 0, 0u};
+    const ct_raythread_options o{rng_mode, seed, device, n_devices, 0, 0u, 0};
     RayThreadSetOptions(&o);
 }
 
 void cth_raythread_options_async(int rng_mode, uint64_t seed, int device, int async) {
-    const ct_raythread_options o{rng_mode, seed, device, 1, async, 0u};
+    const ct_raythread_options o{rng_mode, seed, device, 1, async, 0u, 0};
     RayThreadSetOptions(&o);
 }
 
 void cth_raythread_options_ex(int rng_mode, uint64_t seed, int device, int n_devices, int async, unsigned frame_flags) {
-    const ct_raythread_options o{rng_mode, seed, device, n_devices, async, frame_flags};
+    const ct_raythread_options o{rng_mode, seed, device, n_devices, async, frame_flags, 0};
     RayThreadSetOptions(&o);
 }
 

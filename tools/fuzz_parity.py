@@ -21,10 +21,17 @@ while time.time() < t_end:
     scale = float(rng.choice([1e-3, 0.05, 1.0, 30.0, 2000.0]))
     size = float(rng.choice([0.02, 0.3, 2.0]))
     centres = rng.normal(size=(n, 3)) * scale
+    # a third of the scenes: triangles in a few clusters around a common centroid each -- BuildBVH cannot split those
+    # (bvh.cpp:95-96), so they end up in leaves of dozens or hundreds: the leaves that get cull nodes (DESIGN appendix D)
+    clustered = rng.random() < 0.35
+    if clustered:
+        centres = centres[rng.integers(0, min(n, int(rng.choice([1, 2, 5]))), n)]
     flat = rng.random() < 0.2                                  # axis-aligned flat geometry now and then
     tris = []
     for c in centres:
-        p = c[None, :] + rng.normal(size=(3, 3)) * scale * size
+        p = c[None, :] + rng.normal(size=(3, 3)) * scale * size * (10.0 ** rng.uniform(-2, 0) if clustered else 1.0)
+        if clustered:
+            p[2] = 3.0 * c - p[0] - p[1]                       # (p1 + p2 + p3) / 3 = c
         if flat:
             p[:, int(rng.integers(3))] = c[int(rng.integers(3))]
         tris.append({"type": "triangle", "p1": [float("%.6g" % v) for v in p[0]], "p2": [float("%.6g" % v) for v in p[1]],
@@ -97,13 +104,14 @@ while time.time() < t_end:
     fresh = rays.copy()
     fresh["t"] = np.float32(1e30)
     ray_ok &= bool((ctx.trace_rays_packet(fresh, any_hit=True)["found"] == oracle.trace_rays(scene.desc, fresh)["found"]).all())
+    ctx_cull = ctx.scene_array(6)
     ctx.close()
     scene.close()
     n_scenes += 1
     n_frames += 3
     n_rays += 3 * m
-    print("seed %d: %d triangles, scale %g, %dx%d ss=%d sub=%d flags %d rng %d lights %d: max diff %d, %d px differ, rays %s" %
-          (seed, n, scale, w, h, bool(frame.flags & 1), bool(frame.flags & 2), frame.flags >> 2, frame.rng_mode, len(lights), diff, int((got != want).sum()),
+    print("seed %d: %d triangles%s, scale %g, %dx%d ss=%d sub=%d flags %d rng %d lights %d: max diff %d, %d px differ, rays %s" %
+          (seed, n, " (clustered, %d cull nodes)" % (len(ctx_cull) // 128) if clustered else "", scale, w, h, bool(frame.flags & 1), bool(frame.flags & 2), frame.flags >> 2, frame.rng_mode, len(lights), diff, int((got != want).sum()),
            "equal" if ray_ok else "DIFFER"), flush=True)
     if not ok or not ray_ok:
         print("MISMATCH at seed %d (scene kept in %s)" % (seed, path))
