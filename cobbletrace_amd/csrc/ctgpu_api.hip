@@ -879,12 +879,14 @@ void traced_row_ordinals(const ctgpu_frame_desc *f, const Geometry &g, std::vect
     }
 }
 
-// Which rays may use the leaf cull, and from which ray.t on a closest hit prunes triangle boxes (DESIGN appendix D):
+// Which rays may skip entries of cull nodes, and from which ray.t on a closest hit prunes them (DESIGN appendix D.3):
 // with K >= every |e1|, |e2| component, V >= every |vertex coordinate|, the eye at `cam`,
 //   o_lim = max |cam_i| + 2 V     (the eye, every surface point and anything as near pass),   S = o_lim + V >= |o - p1|,
-//   d_lim = 2^20 / (K max(K, S))  (so that K K D and S D K stay below 2^20: the reference's rounding errors in a, u, v
-//                                  then stay below 2^-12, far inside the 2^-9 the grown boxes guarantee),
-//   tau   = 2^-20.5 K K S         (a closest hit at ray.t >= tau prunes boxes beyond ray.t (1 + 2^-12)),
+//   d_lim = min(2^20 / (K max(K, S)), 2^12 / K^2)
+//                                 (S D K <= 2^20: the reference's rounding errors in u, v stay below 2^-13, far inside the
+//                                  2^-9 the grown boxes guarantee; K K D <= 2^12: its error in a stays below 2^-22 of a,
+//                                  which "beyond ray.t" needs),
+//   tau   = 2^-12 K K S           (a closest hit prunes boxes beyond ray.t only while ray.t >= tau),
 // and no cull at all unless K K S <= 2^20 (then a plane hit behind the origin computes t <= 0.0001f).
 CullLimits cull_limits(const SceneStore &S, const double cam[3]) {
     CullLimits c;
@@ -896,10 +898,10 @@ CullLimits cull_limits(const SceneStore &S, const double cam[3]) {
     const double o_lim = eye + 2.0 * V, s_lim = (o_lim + V) * (1.0 + 0x1p-40);
     if (!(K * K * s_lim <= 0x1p20)) return c;
     const double denom = K * std::max(K, s_lim);
-    const double d_lim = denom > 0.0 ? std::min(0x1p20 / denom, 0x1p80) : 0x1p80;
+    const double d_lim = denom > 0.0 ? std::min(std::min(0x1p20 / denom, 0x1p12 / (K * K)), 0x1p80) : 0x1p80;
     c.d_lim = std::nextafterf((float)d_lim, 0.0f);          // (rounded towards zero: the comparison is made in binary32)
     c.o_lim = std::nextafterf((float)o_lim, INFINITY);      // (up: the eye itself must pass; S above has the slack)
-    c.tau = std::nextafterf((float)(0x1p-20 * 0.7072 * K * K * s_lim), INFINITY);
+    c.tau = std::nextafterf((float)(0x1p-12 * K * K * s_lim), INFINITY);
     return c;
 }
 
