@@ -275,6 +275,7 @@ def main():
         entry.prepare_assets(need_dragon=(args.scene == "dragon"))
     if use_dist:
         dist.barrier()
+    entry.check_build_ids()           # the libraries that are about to be measured were made from the sources on disk
 
     scene = ca.HostScene(os.path.join(ROOT, "assets", SCENE_FILES[args.scene]))
     ss = None if args.supersampling < 0 else bool(args.supersampling)
@@ -501,29 +502,55 @@ def main():
             "ct_shade": samples * (8 + (8 if is_ss else 0) + n_lights) + hits * 60 + pixels * 4,
         }
         alone_ms = [alone.total_ms[k] / max(alone.launches[k], 1) for k in range(5)]
-        kernels = {KERNELS[k]: {"avg_ms": round(avg_ms[k], 4), "avg_ms_alone": round(alone_ms[k], 4), "launches": int(launches[k]),
+        kernels = {KERNELS[k]: {"avg_ms": round(alone_ms[k], 4), "avg_ms_inflight": round(avg_ms[k], 4), "launches_inflight": int(launches[k]),
                                 "own_bytes": int(own[KERNELS[k]]),
-                                "own_GB/s": round(own[KERNELS[k]] / max(avg_ms[k], 1e-9) / 1e6, 1)} for k in range(5)}
-        dom = max(range(5), key=lambda k: avg_ms[k])
+                                "own_GB/s": round(own[KERNELS[k]] / max(alone_ms[k], 1e-9) / 1e6, 1)} for k in range(5)}
+        # the dominant kernel: by its UNDISTURBED duration (serial frames), the figure profiles/rNN_kernel_stats.csv
+        # (rocprofv3 of `bench.py --inflight 1`) reproduces; the duration inside the timed region, where kernels of the
+        # frames in flight share the GPU, is reported beside it
+        dom = max(range(5), key=lambda k: alone_ms[k])
         dom_name = KERNELS[dom]
-        achieved = own[dom_name] / (avg_ms[dom] * 1e-3) / 1e9
+        achieved = own[dom_name] / (alone_ms[dom] * 1e-3) / 1e9
+        achieved_inflight = own[dom_name] / (avg_ms[dom] * 1e-3) / 1e9
         traffic_rec, issue_rec = profile_record("traffic"), profile_record("issue")
         traffic = None
-        if traffic_rec and world == 1 and args.scene == "dragon" and (args.width, args.height) == (1920, 1080) and is_ss:
+        headline = world == 1 and args.scene == "dragon" and (args.width, args.height) == (1920, 1080) and is_ss
+        if traffic_rec and headline:
             traffic = traffic_rec.get("hbm_bytes_per_launch", {}).get(dom_name)
-        # the reference-layout figure of SURVEY.md 8(d), whole frame, instrumented kernel (not the bound: see DESIGN.md)
-        work = slots[0]["ctx"].count_work(frame) if world == 1 else None
-        roofline = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        # What actually limits the walk: the vector pipe's issue slots -- counters of a profiled
+        # run of the same kernels (tools/collect_profiles.sh -> profiles/rNN_issue.json, quoted only when the kernel
+        # sources are the ones on disk); "hbm" above is the bound the contract names for this path, not the limiter.
+        limiter = {"what": "valu-issue", "valu_pipe_busy_frac": None, "valu_lane_utilisation": None, "wave_cycles_in_waitcnt_frac": None,
+                   "source": None, "note": "the walks are bound by vector-instruction issue and each wave's dependent chain "
+                                           "(fetch -> four box tests -> decide), not by bytes: DESIGN.md section 4"}
+        if issue_rec and headline and dom_name in issue_rec.get("kernels", {}):
+            rec = issue_rec["kernels"][dom_name]
+            limiter.update({k: rec.get(k) for k in ("valu_pipe_busy_frac", "valu_lane_utilisation", "wave_cycles_in_waitcnt_frac")})
+            limiter["source"] = issue_rec["_source"]
+        # the reference-layout figure of SURVEY.md 8(d), whole frame, instrumented kernel (not the bound: see DESIGN.md);
+        # per walk: the same scene without its lights traces the primary rays alone
+        work = work_primary = None
+        if world == 1:
+            work = slots[0]["ctx"].count_work(frame)
+            import copy
+            bare = copy.copy(scene.desc)
+            bare.n_lights = 0
+            ctx_bare = ca.GpuContext(local_rank)
+            try:
+                ctx_bare.upload(bare, build_on_device=True)
+                work_primary = ctx_bare.count_work(frame)
+            finally:
+                ctx_bare.close()
+        roofline = {"bound": "hbm", "limiter": limiter, "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                     "traffic_source": (traffic_rec["_source"] if traffic is not None else None),
-                    "launch_ms": round(avg_ms[dom], 4), "launches_timed": int(launches[dom]),
-                    "timing": "HIP events around each kernel on the frame's stream, all frames of the timed region" +
-                              (" (%d frames in flight: kernels of different frames share the GPU, so a launch lasts longer "
-                               "than it does alone -- launch_ms_alone / frac_alone, from %d serial frames after the timed region)"
-                               % (inflight, serial) if inflight > 1 else ""),
-                    "launch_ms_alone": round(alone_ms[dom], 4),
-                    "achieved_alone": round(own[dom_name] / (alone_ms[dom] * 1e-3) / 1e9, 1),
-                    "frac_alone": round(own[dom_name] / (alone_ms[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "launch_ms": round(alone_ms[dom], 4), "launches_timed": int(alone.launches[dom]),
+                    "timing": "HIP events around each kernel on the frame's stream; launch_ms / achieved / frac: the kernel with the "
+                              "GPU to itself (%d serial frames right after the timed region) -- what rocprofv3 --kernel-trace of "
+                              "`bench.py --inflight 1` shows (profiles/); *_inflight: the same launches inside the timed region, "
+                              "%d frames in flight, where kernels of different frames share the GPU and each lasts longer" % (serial, inflight),
+                    "launch_ms_inflight": round(avg_ms[dom], 4), "launches_timed_inflight": int(launches[dom]),
+                    "achieved_inflight": round(achieved_inflight, 1), "frac_inflight": round(achieved_inflight / HBM_PEAK_GBS, 4),
                     "bytes_per_launch": int(own[dom_name]),
                     "bytes_model": "the kernel's own requests: QuadNodes fetched x 128 B + triangle records fetched x 80 B "
                                    "(counted by the kernel) + its per-sample / per-ray arrays",
@@ -534,16 +561,28 @@ def main():
                                    "shadow_packets_all_blocked": int(sum(w.shadow_packets_all_blocked for w in works) / n_launch)},
                     "kernels": kernels}
         if work is not None:
-            ref_bytes = (work.node_visits * B_NODE + work.triangle_tests * B_TRI + (work.rays_shadow // 2) * B_HIT
-                         + int(work.rays_primary // (16 if is_ss else 1)) * B_PIXEL)
-            frame_kernel_ms = sum(avg_ms)
+            def layout_bytes(visits, tests, hits_, pixels_):
+                return visits * B_NODE + tests * B_TRI + hits_ * B_HIT + pixels_ * B_PIXEL
+            n_pix = int(work.rays_primary // (16 if is_ss else 1))
+            ref_bytes = layout_bytes(work.node_visits, work.triangle_tests, work.rays_shadow // max(n_shadow_lights, 1), n_pix)
+            frame_kernel_ms = sum(alone_ms)
             roofline["reference_bytes"] = {
                 "per_frame": int(ref_bytes), "per_ray": round(ref_bytes / max(work.rays, 1), 1),
                 "node_visits_per_ray": round(work.node_visits / max(work.rays, 1), 2),
                 "triangle_tests_per_ray": round(work.triangle_tests / max(work.rays, 1), 2),
                 "rate_GB/s": round(ref_bytes / (frame_kernel_ms * 1e-3) / 1e9, 1),
-                "note": "SURVEY.md 8(d): per-ray node / triangle fetches of the reference layout over the frame's kernel time; "
-                        "above the HBM peak because a wave fetches a node once for its 64 rays -- bytes the design does not move"}
+                "note": "SURVEY.md 8(d): per-ray node / triangle fetches of the reference layout over the frame's kernel time "
+                        "(undisturbed launches); above the HBM peak because a wave fetches a node once for its 64 rays -- "
+                        "bytes the design does not move"}
+            if work_primary is not None:
+                vis_p, tst_p = work_primary.node_visits, work_primary.triangle_tests
+                vis_s, tst_s = work.node_visits - vis_p, work.triangle_tests - tst_p
+                for label, k, vis, tst, n_rays in (("primary_walk", 1, vis_p, tst_p, work.rays_primary), ("shadow_walk", 3, vis_s, tst_s, work.rays_shadow)):
+                    b = vis * B_NODE + tst * B_TRI
+                    roofline["reference_bytes"][label] = {
+                        "bytes": int(b), "node_visits": int(vis), "triangle_tests": int(tst), "rays": int(n_rays),
+                        "per_ray": round(b / max(n_rays, 1), 1), "launch_ms": round(alone_ms[k], 4),
+                        "rate_GB/s": round(b / max(alone_ms[k], 1e-9) / 1e6, 1)}
         if issue_rec:
             roofline["issue"] = {k: v for k, v in issue_rec.items() if not k.startswith("_") and k != "kernel_source_hash"}
             roofline["issue"]["source"] = issue_rec["_source"]
@@ -563,6 +602,8 @@ def main():
                                     "ct_light_gate proves irrelevant (reference_rays_per_frame)",
                        "row_tiles": "%d rows, round-robin over %d GPU(s)" % (tile_rows, world), "collective": collective},
             "timed": "dispatch -> pixels in the pinned host framebuffer, every frame",
+            "build_id": {"libctgpu": ca.gpu_library().ctgpu_build_id().decode(), "libcthost": ca.host_library().cth_build_id().decode(),
+                         "kernel_source_hash": kernel_source_hash()},
             "frames_in_flight": inflight, "ms_frame_latency": round(latency_ms, 4),
             "scene_setup": {"what": "vertices in host memory -> BuildBVH + walk layouts in HBM (ctgpu_upload_scene without a tree), "
                                     "once per rank; the frames in flight share that one copy",

@@ -119,6 +119,7 @@ def identity_rotation():
 _GPU_SYMBOLS = {
     # name: (restype, argtypes)
     "ctgpu_abi_version": (C.c_int, []),
+    "ctgpu_build_id": (C.c_char_p, []),
     "ctgpu_last_error": (C.c_char_p, []),
     "ctgpu_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "ctgpu_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
@@ -160,6 +161,7 @@ _GPU_SYMBOLS = {
 }
 
 _HOST_SYMBOLS = {
+    "cth_build_id": (C.c_char_p, []),
     "cth_load_scene": (C.c_void_p, [C.c_char_p]),
     "cth_scene_from_vertices": (C.c_void_p, [C.c_void_p, C.c_uint32]),
     "cth_free_scene": (None, [C.c_void_p]),
@@ -191,6 +193,43 @@ _HOST_SYMBOLS = {
 }
 
 _cache = {}
+
+
+def source_build_id(which):
+    """What ctgpu_build_id() / cth_build_id() of a library made from the sources ON DISK would return ("gpu" / "host"): the
+    Makefiles' recipe -- sha256 over the directory's sources and headers in name order, then the public headers."""
+    import glob
+    import hashlib
+    root = repo_root()
+    if which == "gpu":
+        here = os.path.join(root, "cobbletrace_amd", "csrc")
+        names = sorted(os.path.basename(f) for pat in ("*.hip", "*.h") for f in glob.glob(os.path.join(here, pat)))
+        public = ["ctgpu.h", "ct_tiles.h"]
+    else:
+        here = os.path.join(root, "cobbletrace_amd", "host")
+        names = sorted(os.path.basename(f) for pat in ("*.cpp", "*.h") for f in glob.glob(os.path.join(here, pat)))
+        public = ["cobbletrace_host.h", "ctgpu.h", "ct_tiles.h"]
+    h = hashlib.sha256()
+    for name in names:
+        if name == "build_id.h":
+            continue
+        with open(os.path.join(here, name), "rb") as f:
+            h.update(f.read())
+    for name in public:
+        with open(os.path.join(root, "include", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def stale_libraries():
+    """[(library, built from, sources on disk)] for every native library whose build id is not that of the sources."""
+    out = []
+    for which, lib, fn in (("gpu", gpu_library(), "ctgpu_build_id"), ("host", host_library(), "cth_build_id")):
+        built = getattr(lib, fn)().decode()
+        want = source_build_id(which)
+        if built != want:
+            out.append((which, built, want))
+    return out
 
 
 def _load(path, symbols, what):

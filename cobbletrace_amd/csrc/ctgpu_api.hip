@@ -6,6 +6,7 @@
 // entry point that needs one returns an error.
 #include "ctgpu_internal.h"
 #include "ct_tiles.h"
+#include "build_id.h"
 
 #include <algorithm>
 #include <chrono>
@@ -277,6 +278,7 @@ extern "C" int ctgpu_rand_stream(uint32_t seed, uint64_t offset, uint64_t n, int
 
 // ------------------------------------------------------------------ basic entry points
 extern "C" int ctgpu_abi_version(void) { return CTGPU_ABI_VERSION; }
+extern "C" const char *ctgpu_build_id(void) { return CTGPU_BUILD_ID; }
 extern "C" const char *ctgpu_last_error(void) { return g_last_error.c_str(); }
 
 extern "C" int ctgpu_device_count(int *count) {

@@ -32,7 +32,11 @@ void ensure_packed(Handle *h) {
 
 }  // namespace
 
+#include "build_id.h"
 extern "C" {
+
+// which sources libcthost.so was made from (see include/ctgpu.h: ctgpu_build_id)
+const char *cth_build_id(void) { return CTH_BUILD_ID; }
 
 void *cth_load_scene(const char *path) {
     Handle *h = new Handle();

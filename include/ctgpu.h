@@ -171,6 +171,11 @@ typedef struct ctgpu_hit {
 
 /* ---- entry points ---- */
 int  ctgpu_abi_version(void);
+/* Which sources this binary was made from: the first 16 hex digits of the sha256 over the .hip and .h files of cobbletrace_amd/csrc
+ * and the two public headers, in name order, taken by the Makefile when the library was linked.  Whoever runs a prebuilt
+ * library against a source tree (the tests, smoke(), bench.py) compares it with the same hash of the files on disk
+ * (cobbletrace_amd.bindings.source_build_id) and rebuilds or refuses when they differ. */
+const char *ctgpu_build_id(void);
 const char *ctgpu_last_error(void);
 int  ctgpu_device_count(int *count);
 

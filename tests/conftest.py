@@ -14,13 +14,26 @@ def pytest_configure(config):
 
 @pytest.fixture(scope="session", autouse=True)
 def native_build():
-    """Build whatever is missing (a no-op when the .so files travelled with the snapshot)."""
+    """The native libraries, made from the sources on disk: built when missing, rebuilt when their build id
+    (ctgpu_build_id / cth_build_id: a hash of the sources, baked in at link time) is not the hash of the files in the
+    tree -- prebuilt binaries travel with a snapshot, and nothing else ties them to the sources beside them."""
     import __graft_entry__ as entry
     needed = [os.path.join(ROOT, "cobbletrace_amd", "csrc", "libctgpu.so"),
               os.path.join(ROOT, "cobbletrace_amd", "host", "libcthost.so"),
               os.path.join(ROOT, "oracle", "libctoracle.so")]
     if not all(os.path.exists(p) for p in needed):
         entry.build()
+    else:
+        import subprocess
+        import sys
+        # (asked in a child process: a library that has been loaded cannot be replaced under this one)
+        probe = subprocess.run([sys.executable, "-c", "import cobbletrace_amd.bindings as b, sys; sys.exit(1 if b.stale_libraries() else 0)"],
+                               cwd=ROOT)
+        if probe.returncode != 0:
+            entry.build()
+    import cobbletrace_amd.bindings as bindings
+    stale = bindings.stale_libraries()
+    assert not stale, "native libraries do not match the sources on disk (library, built from, sources): %r" % (stale,)
     entry.prepare_assets()
     return entry
 
