@@ -58,8 +58,13 @@ def parse_args(argv=None):
     ap.add_argument("--inflight", type=int, default=0, help="frames in flight (1 = strictly serial frames; default 3, 4 from 8 ranks on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=60.0, help="budget of the CPU baseline leg (it drops variants to fit)")
-    ap.add_argument("--collective", default="native", choices=["native", "torch"],
-                    help="N > 1: the RCCL gather issued by libctgpu.so (default) or by torch.distributed")
+    ap.add_argument("--collective", default="native", choices=["native", "torch", "host"],
+                    help="N > 1: the RCCL gather issued by libctgpu.so (default), by torch.distributed, or -- a REHEARSAL for boxes "
+                         "with fewer GPUs than ranks, where RCCL cannot serve (it will not put two ranks on one device) -- tiles "
+                         "copied to pinned host memory and gathered over gloo")
+    ap.add_argument("--same-device", action="store_true",
+                    help="every rank uses device 0 (with --collective host: N real ranks, real kernels and partitions on a one-GPU box)")
+    ap.add_argument("--dump-frame", default=None, help="rank 0 writes the last timed frame's host framebuffer there (.npy)")
     ap.add_argument("--force-collective", action="store_true",
                     help="N = 1: still go through communicator set-up and the gather (a world of one)")
     ap.add_argument("--dry-run-launch", action="store_true",
@@ -257,13 +262,23 @@ def main():
         raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device is visible")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     # (CT_BENCH_FORCE_DIST=1 under torch.distributed.run with ONE rank rehearses every collective of the N-rank
     # path on a one-GPU box; RCCL will not put two ranks on one device)
     use_dist = world > 1 or (bool(os.environ.get("CT_BENCH_FORCE_DIST")) and "RANK" in os.environ)
+    host_collective = args.collective == "host"
+    if args.same_device and world > 1 and not host_collective:
+        raise SystemExit("--same-device with several ranks needs --collective host (RCCL does not put two ranks on one device)")
+    # tensors torch.distributed reduces: on the device under RCCL, on the host under gloo
+    red_device = torch.device("cpu") if host_collective else device
     if use_dist:
-        dist.init_process_group("nccl", device_id=device)
+        if host_collective:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=device)
 
     # every rank needs the assets and the native libraries; rank 0 prepares, the others wait
     if rank == 0:
@@ -289,7 +304,7 @@ def main():
     # their tail and its tiles are gathered, assembled and copied to the host, the way a renderer producing a
     # stream of frames runs.  Each slot owns a context (scene copy + scratch arrays), a stream, a communicator,
     # a device framebuffer and a pinned host framebuffer.
-    # (measured on one GPU with rank 0's share of the frame, tools/overlap.py: an eighth of the frame takes 0.49 ms with
+    # (measured on one GPU with rank 0's share of the frame, a round-1 measurement, repeated by tools/rank_share.py: an eighth of the frame takes 0.49 ms with
     # three frames in flight and 0.46 ms with four; the whole frame is best with three)
     inflight = args.inflight if args.inflight > 0 else (4 if world >= 8 else 3)      # (tools/rank_share.py, profiles/r03_rank_share.log: within run-to-run noise)
     # Throughput tuning through the library's documented knobs (read at context creation): with several
@@ -304,7 +319,7 @@ def main():
     native_ok = True
 
     def all_ranks_agree(flag):
-        t = torch.tensor([flag], device=device)
+        t = torch.tensor([flag], device=red_device)
         if use_dist:
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return t.item() >= 1.0
@@ -323,10 +338,14 @@ def main():
         n_tile = ctx.partition_pixels(frame, part)
         slot = {"ctx": ctx, "part": part, "stream": torch.cuda.Stream(device=device), "n_tile": n_tile,
                 "tiles": torch.zeros(n_tile, dtype=torch.int32, device=device),
+                # --collective host: this rank's tiles on the host (pinned), everybody's on rank 0's host and device
+                "host_tiles": torch.zeros(n_tile, dtype=torch.int32).pin_memory() if host_collective else None,
+                "host_all": torch.zeros(n_tile * world, dtype=torch.int32).pin_memory() if host_collective and rank == 0 else None,
+                "dev_all": torch.zeros(n_tile * world, dtype=torch.int32, device=device) if host_collective and rank == 0 else None,
                 "fb": torch.zeros(frame.height * frame.width, dtype=torch.int32, device=device) if rank == 0 else None,
                 "host_fb": torch.zeros(frame.height * frame.width, dtype=torch.int32).pin_memory() if rank == 0 else None,
                 "native": False}
-        if use_comm and args.collective == "native" and native_ok:
+        if use_comm and args.collective == "native" and native_ok and not host_collective:
             # rank 0 makes the RCCL unique id, torch.distributed carries its 128 bytes to the other ranks (one
             # communicator per rank, shared by the slots: RCCL then orders the in-flight frames' gathers itself).
             # Every step that can fail on one rank only is followed by a MIN over the ranks, so that all ranks take
@@ -360,6 +379,8 @@ def main():
             for s in slots:
                 s["native"] = False
         collective = ("RCCL ncclGather to rank 0, issued by libctgpu.so (ctgpu_render_sharded)" if slots[0]["native"]
+                      else "REHEARSAL: tiles through pinned host memory, gathered to rank 0 over gloo" +
+                           (" (all ranks on device 0)" if args.same_device else "") if host_collective
                       else "RCCL gather to rank 0 through torch.distributed")
 
     def sync_all():
@@ -387,7 +408,19 @@ def main():
                 e0 = mark(stream) if record else None
                 s["ctx"].render_partition(frame, s["part"], s["tiles"].data_ptr(), stream.cuda_stream)
                 e1 = mark(stream) if record else None
-                gathered = s["tiles"] if not use_dist else multi_gpu.gather_to_root(s["tiles"], world, rank)
+                if host_collective and use_dist:
+                    # the rehearsal's hand-over: device -> pinned host, gloo gather, rank 0: host -> device (the frame's
+                    # stream waits for its own copy; the other frames in flight keep tracing meanwhile)
+                    s["host_tiles"].copy_(s["tiles"], non_blocking=True)
+                    stream.synchronize()
+                    pieces = list(s["host_all"].split(s["n_tile"])) if rank == 0 else None
+                    dist.gather(s["host_tiles"], gather_list=pieces, dst=0)
+                    gathered = None
+                    if rank == 0:
+                        s["dev_all"].copy_(s["host_all"], non_blocking=True)
+                        gathered = s["dev_all"]
+                else:
+                    gathered = s["tiles"] if not use_dist else multi_gpu.gather_to_root(s["tiles"], world, rank)
                 e2 = mark(stream) if record else None
                 if rank == 0:
                     s["ctx"].assemble(frame, s["part"], gathered.data_ptr(), s["fb"].data_ptr(), stream.cuda_stream)
@@ -433,7 +466,7 @@ def main():
         s["ctx"].kernel_timing(False)
     my_rays = float(sum(c.rays for c in counted))
     my_elided = float(sum(c.rays_shadow_elided for c in counted))
-    totals = torch.tensor([my_rays, my_elided, elapsed], dtype=torch.float64, device=device)
+    totals = torch.tensor([my_rays, my_elided, elapsed], dtype=torch.float64, device=red_device)
     if use_dist:
         sums = totals[:2].clone()
         dist.all_reduce(sums, op=dist.ReduceOp.SUM)
@@ -445,11 +478,11 @@ def main():
     # per-rank breakdown (means per frame): what a first scaling curve is read with
     mine = torch.tensor([my_rays / args.steps, phases["trace"] / args.steps, phases["gather"] / args.steps,
                          phases["assemble"] / args.steps, phases["d2h"] / args.steps, float(slots[0]["n_tile"]),
-                         totals[2].item() / args.steps * 1e3], dtype=torch.float64, device=device)
+                         totals[2].item() / args.steps * 1e3], dtype=torch.float64, device=red_device)
     if use_dist:
-        everyone = torch.zeros(world * mine.numel(), dtype=torch.float64, device=device)
-        dist.all_gather_into_tensor(everyone, mine)
-        per_rank = everyone.view(world, -1).cpu().tolist()
+        rows = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(rows, mine)
+        per_rank = [r.cpu().tolist() for r in rows]
     else:
         per_rank = [mine.cpu().tolist()]
     rays_per_frame = total_rays / args.steps
@@ -459,7 +492,7 @@ def main():
     # ---- outside the timed region: the same K frames left on the device (no host copy), and one frame alone
     elapsed_device = timed(args.steps, to_host=False)
     if use_dist:
-        t = torch.tensor([elapsed_device], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed_device], dtype=torch.float64, device=red_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed_device = float(t.item())
     serial = 5
@@ -532,8 +565,9 @@ def main():
         work = work_primary = None
         if world == 1:
             work = slots[0]["ctx"].count_work(frame)
-            import copy
-            bare = copy.copy(scene.desc)
+            import ctypes
+            bare = ca.SceneDesc()
+            ctypes.memmove(ctypes.byref(bare), ctypes.byref(scene.desc), ctypes.sizeof(bare))      # (same arrays, no lights)
             bare.n_lights = 0
             ctx_bare = ca.GpuContext(local_rank)
             try:
@@ -626,6 +660,9 @@ def main():
             last = slots[(args.steps - 1) % inflight]["host_fb"].numpy().view(np.uint32).reshape(frame.height, frame.width)
             out["cpu_baseline"], out["parity"] = cpu_baseline(ca, scene, frame, last, args.cpu_seconds)
             out["speedup_vs_cpu_ms_per_frame"] = round(out["cpu_baseline"]["ms_per_frame"] / ms_per_step, 1)
+        if args.dump_frame:
+            last = slots[(args.steps - 1) % inflight]["host_fb"].numpy().view(np.uint32).reshape(frame.height, frame.width)
+            np.save(args.dump_frame, last)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     for s in slots:

@@ -94,6 +94,31 @@ class SceneInfo(C.Structure):
                 ("hbm_bytes", C.c_uint64)]
 
 
+class Config(C.Structure):
+    """ctgpu_config (include/ctgpu.h): every knob of a context; environment variable of each field in the header."""
+    _fields_ = [("packet_walk", C.c_int32), ("bounce", C.c_int32), ("force_megakernel", C.c_int32), ("keep_shadow_rays", C.c_int32),
+                ("blocks_per_cu", C.c_int32), ("chunk", C.c_int32), ("chunk_shadow", C.c_int32), ("lds_depth", C.c_int32),
+                ("packet_lds_levels", C.c_int32), ("probe_above", C.c_int32), ("packet_budget", C.c_int32), ("packet_lanes", C.c_int32),
+                ("order", C.c_int32), ("order_heavy", C.c_float * 4), ("order_floor", C.c_int32), ("order_split_below", C.c_int32),
+                ("order_parts", C.c_int32 * 4), ("big_leaf_min", C.c_int32), ("big_leaf_share", C.c_int32), ("pack_on_host", C.c_int32),
+                ("thresh", C.c_int32 * 3), ("walk_thresh", C.c_int32 * 3), ("debug", C.c_uint32)]
+
+    def as_dict(self):
+        return {name: (list(getattr(self, name)) if hasattr(getattr(self, name), "__len__") else getattr(self, name)) for name, _ in self._fields_}
+
+
+def default_config():
+    c = Config()
+    assert gpu_library().ctgpu_default_config(C.byref(c)) == 0
+    return c
+
+
+def config_from_environment():
+    c = Config()
+    assert gpu_library().ctgpu_config_from_environment(C.byref(c)) == 0
+    return c
+
+
 class Partition(C.Structure):
     _fields_ = [("tile_rows", C.c_int32), ("part_index", C.c_int32), ("part_count", C.c_int32)]
 
@@ -123,6 +148,10 @@ _GPU_SYMBOLS = {
     "ctgpu_last_error": (C.c_char_p, []),
     "ctgpu_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "ctgpu_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "ctgpu_create_with_config": (C.c_int, [C.c_int, C.POINTER(Config), C.POINTER(C.c_void_p)]),
+    "ctgpu_get_config": (C.c_int, [C.c_void_p, C.POINTER(Config)]),
+    "ctgpu_default_config": (C.c_int, [C.POINTER(Config)]),
+    "ctgpu_config_from_environment": (C.c_int, [C.POINTER(Config)]),
     "ctgpu_destroy": (None, [C.c_void_p]),
     "ctgpu_upload_scene": (C.c_int, [C.c_void_p, C.POINTER(SceneDesc)]),
     "ctgpu_share_scene": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -188,6 +217,7 @@ _HOST_SYMBOLS = {
     "cth_raythread_options": (None, [C.c_int, C.c_uint64, C.c_int, C.c_int]),
     "cth_raythread_reset": (None, []),
     "cth_intersect_bvh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]),
+    "cth_move_tree_in_place": (C.c_int, [C.c_void_p, C.c_double]),
     "cth_raythread_frames": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_char_p]),
     "cth_last_frame_stats": (None, [C.POINTER(Stats)]),
 }
@@ -362,11 +392,20 @@ def build_bvh_on_device(vertices, device=0):
 class GpuContext:
     """One ctgpu_ctx: a scene resident on one MI355X."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, config=None):
+        """config: a Config (ctgpu_create_with_config); None: the environment's (ctgpu_create)."""
         self.lib = gpu_library()
         h = C.c_void_p()
-        self._check(self.lib.ctgpu_create(device, C.byref(h)))
+        if config is None:
+            self._check(self.lib.ctgpu_create(device, C.byref(h)))
+        else:
+            self._check(self.lib.ctgpu_create_with_config(device, C.byref(config), C.byref(h)))
         self.handle = h
+
+    def get_config(self):
+        c = Config()
+        self._check(self.lib.ctgpu_get_config(self.handle, C.byref(c)))
+        return c
 
     def _check(self, rc):
         if rc != 0:

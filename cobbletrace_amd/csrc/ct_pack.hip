@@ -301,12 +301,15 @@ int build_quads(const ctgpu_node *d_nodes, bool root_is_inner, uint32_t n_inner,
         hipLaunchKernelGGL(k_quad_count, dim3(blocks_for(width)), dim3(kBlock), 0, nullptr, d_nodes, (const uint32_t *)out.head,
                            begin, end, fold ? 1 : 0, d_counts);
         scan.run(d_counts, width, d_offsets, nullptr);
-        hipLaunchKernelGGL(k_quad_emit, dim3(blocks_for(width)), dim3(kBlock), 0, nullptr, d_nodes, out, begin, end, fold ? 1 : 0,
-                           (const uint32_t *)d_offsets);
         HIP_TRY(hipGetLastError());
+        // (before anything is emitted: the level's QuadNodes write head / before / quads of the NEXT level's slots, and a
+        //  caller's node array that shares children between parents would reach more inner nodes than it has)
         uint32_t made = 0;
         HIP_TRY(hipMemcpy(&made, d_offsets + width, 4, hipMemcpyDeviceToHost));
         if ((uint64_t)end + made > room) return ctgpu_fail(CTGPU_ERR_ARG, "node links form a cycle");
+        hipLaunchKernelGGL(k_quad_emit, dim3(blocks_for(width)), dim3(kBlock), 0, nullptr, d_nodes, out, begin, end, fold ? 1 : 0,
+                           (const uint32_t *)d_offsets);
+        HIP_TRY(hipGetLastError());
         begin = end;
         end += made;
     }

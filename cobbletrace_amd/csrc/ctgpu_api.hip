@@ -113,6 +113,7 @@ struct SceneStore {
 
 struct ctgpu_ctx {
     int device = 0;
+    ctgpu_config cfg;                           // what the context was created with (ctgpu_get_config); the fields below are set from it
     std::shared_ptr<SceneStore> scene;          // null until ctgpu_upload_scene / ctgpu_share_scene
 
     DeviceArray<uint32_t> tiles;       // compact tile buffer of a whole-frame render
@@ -292,19 +293,108 @@ extern "C" int ctgpu_device_count(int *count) {
 
 static int create_resources(ctgpu_ctx *ctx);
 
-extern "C" int ctgpu_create(int device, ctgpu_ctx **out) {
-    if (!out) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_create: null argument");
+// ------------------------------------------------------------------ configuration
+static_assert(kOrderClasses == 4, "ctgpu_config lists four order classes");
+extern "C" int ctgpu_default_config(ctgpu_config *c) {
+    if (!c) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_default_config: null argument");
+    std::memset(c, 0, sizeof *c);
+    c->packet_walk = -1; c->bounce = -1;
+    c->lds_depth = 8;                            // 6 KB of LDS per wave; deeper entries spill to HBM
+    c->packet_lds_levels = 14;
+    c->probe_above = 100;
+    c->packet_lanes = 12;
+    c->order = 1;
+    const float heavy[4] = {8.0f, 4.0f, 2.0f, 1.0f};
+    const int parts[4] = {4, 2, 1, 1};
+    for (int k = 0; k < 4; k++) { c->order_heavy[k] = heavy[k]; c->order_parts[k] = parts[k]; }
+    c->order_floor = 64; c->order_split_below = 8;
+    c->big_leaf_min = 8; c->big_leaf_share = 20;
+    const int thresh[3] = {40, 20, 12}, walk_thresh[3] = {64, 32, 24};       // (measured best on MI355X)
+    for (int k = 0; k < 3; k++) { c->thresh[k] = thresh[k]; c->walk_thresh[k] = walk_thresh[k]; }
+    return CTGPU_OK;
+}
+
+extern "C" int ctgpu_config_from_environment(ctgpu_config *c) {
+    int rc = ctgpu_default_config(c); if (rc) return rc;
+    const auto number = [](const char *name, int32_t &field, int lo, int hi) {
+        if (const char *t = std::getenv(name)) field = std::min(hi, std::max(lo, std::atoi(t)));
+    };
+    const auto triple = [](const char *name, int32_t field[3]) {
+        int a, b, d;
+        if (const char *t = std::getenv(name))
+            if (std::sscanf(t, "%d,%d,%d", &a, &b, &d) == 3) { field[0] = a; field[1] = b; field[2] = d; }
+    };
+    const int big = 1 << 30;
+    triple("CTGPU_THRESH", c->thresh);
+    triple("CTGPU_WALK_THRESH", c->walk_thresh);
+    number("CTGPU_LDS_DEPTH", c->lds_depth, 1, big);
+    number("CTGPU_BLOCKS_PER_CU", c->blocks_per_cu, 0, big);
+    number("CTGPU_CHUNK", c->chunk, 0, big);
+    number("CTGPU_CHUNK_SHADOW", c->chunk_shadow, 0, big);
+    if (const char *t = std::getenv("CTGPU_PACKET")) c->packet_walk = std::atoi(t) != 0 ? 1 : 0;
+    if (const char *t = std::getenv("CTGPU_BOUNCE")) c->bounce = std::atoi(t) != 0 ? 1 : 0;
+    if (const char *t = std::getenv("CTGPU_KEEP_SHADOW_RAYS")) c->keep_shadow_rays = std::atoi(t) != 0 ? 1 : 0;
+    if (const char *t = std::getenv("CTGPU_FORCE_MEGAKERNEL")) c->force_megakernel = std::atoi(t) != 0 ? 1 : 0;
+    number("CTGPU_PROBE_ABOVE", c->probe_above, 0, big);
+    number("CTGPU_BIG_LEAF", c->big_leaf_min, 0, big);
+    number("CTGPU_BIG_LEAF_SHARE", c->big_leaf_share, 0, 100);
+    number("CTGPU_PACKET_BUDGET", c->packet_budget, 0, big);
+    number("CTGPU_PACKET_LANES", c->packet_lanes, 1, 64);
+    number("CTGPU_PACKET_LDS_LEVELS", c->packet_lds_levels, 1, big);
+    number("CTGPU_ORDER", c->order, 0, 3);
+    if (const char *t = std::getenv("CTGPU_ORDER_HEAVY")) {
+        float v[4];
+        if (std::sscanf(t, "%f,%f,%f,%f", &v[0], &v[1], &v[2], &v[3]) == 4 && v[0] >= v[1] && v[1] >= v[2] && v[2] >= v[3] && v[3] > 0.0f)
+            for (int k = 0; k < 4; k++) c->order_heavy[k] = v[k];
+    }
+    number("CTGPU_ORDER_FLOOR", c->order_floor, 0, big);
+    number("CTGPU_ORDER_SPLIT_BELOW", c->order_split_below, 0, big);
+    if (const char *t = std::getenv("CTGPU_ORDER_PARTS")) {
+        int v[4];
+        const auto ok = [](int x) { return x == 1 || x == 2 || x == 4 || x == 8 || x == 16; };
+        if (std::sscanf(t, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == 4 && ok(v[0]) && ok(v[1]) && ok(v[2]) && ok(v[3]))
+            for (int k = 0; k < 4; k++) c->order_parts[k] = v[k];
+    }
+    if (const char *t = std::getenv("CTGPU_PACK")) c->pack_on_host = std::strcmp(t, "host") == 0 ? 1 : 0;
+    c->debug = (std::getenv("CTGPU_DEBUG_PHASES") ? CTGPU_DEBUG_PHASES : 0u) | (std::getenv("CTGPU_DEBUG_TRI") ? CTGPU_DEBUG_TRI : 0u) |
+               (std::getenv("CTGPU_DEBUG_REDO") ? CTGPU_DEBUG_REDO : 0u) | (std::getenv("CTGPU_DEBUG_PACKET") ? CTGPU_DEBUG_PACKET : 0u);
+    return CTGPU_OK;
+}
+
+extern "C" int ctgpu_get_config(const ctgpu_ctx *ctx, ctgpu_config *out) {
+    if (!ctx || !out) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_get_config: null argument");
+    *out = ctx->cfg;
+    return CTGPU_OK;
+}
+
+extern "C" int ctgpu_create_with_config(int device, const ctgpu_config *config, ctgpu_ctx **out) {
+    if (!out || !config) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_create: null argument");
     *out = nullptr;
+    const ctgpu_config &c = *config;
+    const auto part_ok = [](int x) { return x == 1 || x == 2 || x == 4 || x == 8 || x == 16; };
+    if (c.lds_depth < 1 || c.packet_lds_levels < 1 || c.packet_lanes < 1 || c.packet_lanes > 64 || c.blocks_per_cu < 0 || c.chunk < 0 ||
+        c.chunk_shadow < 0 || c.order < 0 || c.order > 3 || c.big_leaf_min < 0 || c.big_leaf_share < 0 || c.big_leaf_share > 100 ||
+        c.packet_budget < 0 || c.order_floor < 0 || c.order_split_below < 0 || c.probe_above < 0 ||
+        !(c.order_heavy[0] >= c.order_heavy[1] && c.order_heavy[1] >= c.order_heavy[2] && c.order_heavy[2] >= c.order_heavy[3] && c.order_heavy[3] > 0.0f) ||
+        !part_ok(c.order_parts[0]) || !part_ok(c.order_parts[1]) || !part_ok(c.order_parts[2]) || !part_ok(c.order_parts[3]))
+        return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_create_with_config: a field is out of range (ctgpu_default_config gives valid values)");
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return ctgpu_fail(CTGPU_ERR_NO_DEVICE, "no HIP device is visible");
     if (device < 0 || device >= n) return ctgpu_fail(CTGPU_ERR_ARG, "device %d out of range (0..%d)", device, n - 1);
     HIP_TRY(hipSetDevice(device));
     ctgpu_ctx *ctx = new ctgpu_ctx();
     ctx->device = device;
+    ctx->cfg = c;
     const int rc = create_resources(ctx);
     if (rc != CTGPU_OK) { ctgpu_destroy(ctx); return rc; }      // (the message of the failing call stands)
     *out = ctx;
     return CTGPU_OK;
+}
+
+extern "C" int ctgpu_create(int device, ctgpu_ctx **out) {
+    ctgpu_config c;
+    int rc = ctgpu_config_from_environment(&c); if (rc) return rc;
+    return ctgpu_create_with_config(device, &c, out);
 }
 
 static int create_resources(ctgpu_ctx *ctx) {
@@ -317,42 +407,19 @@ static int create_resources(ctgpu_ctx *ctx) {
     HIP_TRY(ctx->overflow.resize(1));
     HIP_TRY(hipMemset(ctx->counters.ptr, 0, kCounterWords * sizeof(unsigned long long)));
     HIP_TRY(hipMemset(ctx->overflow.ptr, 0, sizeof(uint32_t)));
-    if (const char *t = std::getenv("CTGPU_THRESH")) {   // tuning knob: "a,b,c"
-        int a, b, c;
-        if (std::sscanf(t, "%d,%d,%d", &a, &b, &c) == 3) { ctx->thresh[0] = a; ctx->thresh[1] = b; ctx->thresh[2] = c; }
-    }
-    // tuning / A-B knobs of the wavefront pipeline
-    if (const char *t = std::getenv("CTGPU_WALK_THRESH")) {
-        int a, b, c;
-        if (std::sscanf(t, "%d,%d,%d", &a, &b, &c) == 3) { ctx->walk_thresh[0] = a; ctx->walk_thresh[1] = b; ctx->walk_thresh[2] = c; }
-    }
-    if (const char *t = std::getenv("CTGPU_LDS_DEPTH")) ctx->lds_depth = std::max(1, std::atoi(t));
-    if (const char *t = std::getenv("CTGPU_BLOCKS_PER_CU")) ctx->blocks_per_cu = std::max(0, std::atoi(t));
-    if (const char *t = std::getenv("CTGPU_CHUNK")) ctx->chunk = std::max(0, std::atoi(t));
-    if (const char *t = std::getenv("CTGPU_CHUNK_SHADOW")) ctx->chunk_shadow = std::max(0, std::atoi(t));
-    if (const char *t = std::getenv("CTGPU_PACKET")) { ctx->packet_walk = std::atoi(t) != 0; ctx->walk_auto = false; }
-    if (const char *t = std::getenv("CTGPU_KEEP_SHADOW_RAYS")) ctx->keep_shadow_rays = std::atoi(t) != 0;
-    if (const char *t = std::getenv("CTGPU_PROBE_ABOVE")) ctx->probe_above = std::max(0, std::atoi(t));
-    if (const char *t = std::getenv("CTGPU_BIG_LEAF")) ctx->big_leaf_min = std::max(0, std::atoi(t));
-    if (const char *t = std::getenv("CTGPU_BIG_LEAF_SHARE")) ctx->big_leaf_share = std::min(100, std::max(0, std::atoi(t)));
-    if (const char *t = std::getenv("CTGPU_PACKET_BUDGET")) ctx->packet_budget = std::max(0, std::atoi(t));
-    if (const char *t = std::getenv("CTGPU_PACKET_LANES")) ctx->packet_lanes = std::min(64, std::max(1, std::atoi(t)));
-    if (const char *t = std::getenv("CTGPU_PACKET_LDS_LEVELS")) ctx->packet_lds_levels = std::max(1, std::atoi(t));
-    if (const char *t = std::getenv("CTGPU_FORCE_MEGAKERNEL")) ctx->force_megakernel = std::atoi(t) != 0;
-    if (const char *t = std::getenv("CTGPU_BOUNCE")) { ctx->bounce_on_pipeline = std::atoi(t) != 0; ctx->bounce_auto = false; }
-    if (const char *t = std::getenv("CTGPU_ORDER")) { ctx->order_on = std::atoi(t) != 0; ctx->order_always = std::atoi(t) == 2; ctx->order_pipelined = std::atoi(t) == 3; }
-    if (const char *t = std::getenv("CTGPU_ORDER_HEAVY")) {
-        float v[kOrderClasses];
-        if (std::sscanf(t, "%f,%f,%f,%f", &v[0], &v[1], &v[2], &v[3]) == kOrderClasses && v[0] >= v[1] && v[1] >= v[2] && v[2] >= v[3] && v[3] > 0.0f)
-            for (int k = 0; k < kOrderClasses; k++) ctx->order_heavy[k] = v[k];
-    }
-    if (const char *t = std::getenv("CTGPU_ORDER_FLOOR")) ctx->order_floor = std::max(0, std::atoi(t));
-    if (const char *t = std::getenv("CTGPU_ORDER_SPLIT_BELOW")) ctx->order_split_below = std::max(0, std::atoi(t));
-    if (const char *t = std::getenv("CTGPU_ORDER_PARTS")) {
-        int v[kOrderClasses];
-        const auto ok = [](int x) { return x == 1 || x == 2 || x == 4 || x == 8 || x == 16; };
-        if (std::sscanf(t, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]) == kOrderClasses && ok(v[0]) && ok(v[1]) && ok(v[2]) && ok(v[3]))
-            for (int k = 0; k < kOrderClasses; k++) ctx->order_parts[k] = v[k];
+    {   // the context's working fields, from its configuration
+        const ctgpu_config &c = ctx->cfg;
+        for (int k = 0; k < 3; k++) { ctx->thresh[k] = c.thresh[k]; ctx->walk_thresh[k] = c.walk_thresh[k]; }
+        ctx->lds_depth = c.lds_depth; ctx->blocks_per_cu = c.blocks_per_cu; ctx->chunk = c.chunk; ctx->chunk_shadow = c.chunk_shadow;
+        ctx->walk_auto = c.packet_walk < 0; ctx->packet_walk = c.packet_walk != 0;
+        ctx->keep_shadow_rays = c.keep_shadow_rays != 0; ctx->probe_above = c.probe_above;
+        ctx->big_leaf_min = c.big_leaf_min; ctx->big_leaf_share = c.big_leaf_share;
+        ctx->packet_budget = c.packet_budget; ctx->packet_lanes = c.packet_lanes; ctx->packet_lds_levels = c.packet_lds_levels;
+        ctx->force_megakernel = c.force_megakernel != 0;
+        ctx->bounce_auto = c.bounce < 0; ctx->bounce_on_pipeline = c.bounce != 0;
+        ctx->order_on = c.order != 0; ctx->order_always = c.order == 2; ctx->order_pipelined = c.order == 3;
+        for (int k = 0; k < kOrderClasses; k++) { ctx->order_heavy[k] = c.order_heavy[k]; ctx->order_parts[k] = c.order_parts[k]; }
+        ctx->order_floor = c.order_floor; ctx->order_split_below = c.order_split_below;
     }
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ctx->cu_count = prop.multiProcessorCount;
@@ -622,8 +689,7 @@ extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
     auto store = std::make_shared<SceneStore>();
     SceneStore &S = *store;
     S.device = ctx->device;
-    const char *where = std::getenv("CTGPU_PACK");
-    const bool host_pack = where && std::strcmp(where, "host") == 0;
+    const bool host_pack = ctx->cfg.pack_on_host != 0;
 
     uint32_t depth = 0, M = s->n_nodes;
     if (!build_here) { int rc = validate_tree(s, depth); if (rc) return rc; }
@@ -997,24 +1063,25 @@ int check_overflow(ctgpu_ctx *ctx) {
 }
 
 int read_counters(ctgpu_ctx *ctx, ctgpu_stats *st) {
+    const uint32_t debug = ctx->cfg.debug;
     unsigned long long c[kCounterWords];
     HIP_TRY(hipMemcpy(c, ctx->counters.ptr, sizeof c, hipMemcpyDeviceToHost));
-    if (std::getenv("CTGPU_DEBUG_PHASES") && c[5])
+    if ((debug & CTGPU_DEBUG_PHASES) && c[5])
         std::fprintf(stderr, "phases: A %llu x %.1f lanes (%.0f cyc each), B %llu x %.1f lanes (%.0f cyc), C %llu x %.1f lanes (%.0f cyc)\n", c[5],
                      (double)c[6] / c[5], (double)c[11] / c[5], c[7], c[7] ? (double)c[8] / c[7] : 0.0, c[7] ? (double)c[12] / c[7] : 0.0,
                      c[9], c[9] ? (double)c[10] / c[9] : 0.0, c[9] ? (double)c[13] / c[9] : 0.0);
-    if (std::getenv("CTGPU_DEBUG_TRI") && c[19])         // diagnostic build -DCT_TRI_STATS (tools/tri_stats.py)
+    if ((debug & CTGPU_DEBUG_TRI) && c[19])         // diagnostic build -DCT_TRI_STATS (tools/tri_stats.py)
         std::fprintf(stderr, "triangle records tested by a wave: %llu; the wave's furthest lane stops at |a| %.2f%%, at u %.2f%%, at v / u+v %.2f%%, "
                      "passes (a hit candidate) %.2f%%\n", c[19], 100.0 * c[20] / c[19], 100.0 * c[21] / c[19], 100.0 * c[22] / c[19], 100.0 * c[23] / c[19]);
-    if (std::getenv("CTGPU_DEBUG_REDO"))
+    if (debug & CTGPU_DEBUG_REDO)
         std::fprintf(stderr, "packet walk: %llu rays walked again unfolded (NaN box parameter)\n", c[15]);
-    if (std::getenv("CTGPU_DEBUG_PACKET") && c[14])
+    if ((debug & CTGPU_DEBUG_PACKET) && c[14])
         std::fprintf(stderr, "packet walk: inner %llu (%.1f lanes, %.0f cyc each; level 1 on %.3f%%), leaf triangles %llu (%.1f lanes; %.0f cyc each), "
                      "pops %llu (%.0f cyc each); wave cycles %llu: inner %.1f%% leaf %.1f%% pop %.1f%% other %.1f%%\n",
                      c[5], (double)c[6] / c[5], (double)c[11] / c[5], 100.0 * c[9] / c[5], c[7], c[7] ? (double)c[8] / c[7] : 0.0,
                      c[7] ? (double)c[12] / c[7] : 0.0, c[10], c[10] ? (double)c[13] / c[10] : 0.0, c[14], 100.0 * c[11] / c[14],
                      100.0 * c[12] / c[14], 100.0 * c[13] / c[14], 100.0 * (c[14] - c[11] - c[12] - c[13]) / c[14]);
-    else if (std::getenv("CTGPU_DEBUG_PHASES") && c[14])
+    else if ((debug & CTGPU_DEBUG_PHASES) && c[14])
         std::fprintf(stderr, "wave lifetime cycles total %llu: A %.1f%% B %.1f%% R %.1f%% other %.1f%%\n", c[14],
                      100.0 * c[11] / c[14], 100.0 * c[12] / c[14], 100.0 * c[13] / c[14],
                      100.0 * (c[14] - c[11] - c[12] - c[13]) / c[14]);

@@ -209,6 +209,22 @@ int cth_intersect_bvh(void *p, const void *rays_in, uint32_t n, int closest, voi
     return 0;
 }
 
+// The scene's own tree REBUILT IN PLACE after moving every triangle by (dx, 0, 0): same arrays, same counts, other
+// content -- what a caller of the operator-level boundary may do between two queries (bvh.h:28-32 keeps no copy)
+int cth_move_tree_in_place(void *p, double dx) {
+    Handle *h = H(p);
+    ensure_packed(h);
+    bvh_state_t &b = h->packed.bvh;
+    for (uint32_t i = 0; i < b.triangles.size; i++) {
+        triangle_t &t = b.triangles.data[i];
+        t.p1.x += dx; t.p2.x += dx; t.p3.x += dx;
+        b.triangles.indexes[i] = i;
+    }
+    b.nodesUsed = 1;
+    BuildBVH(&b);
+    return (int)b.nodesUsed;
+}
+
 // First call renders; each byte of `keys` is then delivered as one key-down event followed
 // by one more RayThread call (one frame per key).  Returns the number of RayThread calls.
 int cth_raythread_frames(void *p, int width, int height, uint32_t *fb, const char *keys) {

@@ -309,7 +309,37 @@ struct QueryTree {
     const bvh_node_t *nodes = nullptr;
     const triangle_t *triangles = nullptr;
     uint32_t nodes_used = 0, size = 0;
+    uint64_t fingerprint = 0;             // of a sample of the arrays' CONTENT (tree_fingerprint)
 };
+
+// FNV-1a over a SAMPLE of what the walk reads -- the root, up to 256 nodes, index entries and triangles at even strides and
+// the last of each -- so that a tree rebuilt in place, or another tree at a freed one's addresses, is uploaded again (the
+// reference walks whatever is in memory at call time, bvh.cpp:181-222).  An edit that leaves every sampled element as it was
+// is not seen: RayThreadReset() drops the resident copy.  (Hashing everything would cost more than the query's launch.)
+uint64_t tree_fingerprint(const bvh_state_t *state) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    auto mix = [&h](const void *p, size_t n) {
+        const unsigned char *b = static_cast<const unsigned char *>(p);
+        for (size_t i = 0; i < n; i++) h = (h ^ b[i]) * 0x100000001b3ull;
+    };
+    auto sampled = [](uint32_t count, auto &&visit) {
+        if (count == 0) return;
+        const uint32_t step = count / 256u + 1u;
+        for (uint32_t i = 0; i < count; i += step) visit(i);
+        visit(count - 1u);
+    };
+    sampled(state->nodesUsed, [&](uint32_t i) {                    // (the fields, not the struct's padding)
+        const bvh_node_t &n = state->bvhNodes[i];
+        mix(&n.aabbMin, sizeof n.aabbMin); mix(&n.aabbMax, sizeof n.aabbMax);
+        mix(&n.leftNode, 4); mix(&n.firstTriangleIndex, 4); mix(&n.triangleCount, 4);
+    });
+    sampled(state->triangles.size, [&](uint32_t i) {
+        mix(&state->triangles.indexes[i], 4);
+        const triangle_t &t = state->triangles.data[i];
+        mix(&t.p1, sizeof t.p1); mix(&t.p2, sizeof t.p2); mix(&t.p3, sizeof t.p3);
+    });
+    return h;
+}
 
 QueryTree &query_tree() {
     static QueryTree q;
@@ -325,8 +355,9 @@ void release_query_tree() {
 ctgpu_ctx *resident(bvh_state_t *state) {
     QueryTree &q = query_tree();
     GpuApi &api = gpu();
+    const uint64_t print = tree_fingerprint(state);
     if (q.ctx && q.nodes == state->bvhNodes && q.triangles == state->triangles.data && q.nodes_used == state->nodesUsed &&
-        q.size == state->triangles.size)
+        q.size == state->triangles.size && q.fingerprint == print)
         return q.ctx;
     if (!q.ctx && api.create(boss().options.device, &q.ctx) != CTGPU_OK) die("ctgpu_create", api.last_error());
     const uint32_t n = state->triangles.size;
@@ -347,6 +378,7 @@ ctgpu_ctx *resident(bvh_state_t *state) {
     d.indexes = state->triangles.indexes;
     if (api.upload_scene(q.ctx, &d) != CTGPU_OK) die("ctgpu_upload_scene", api.last_error());
     q.nodes = state->bvhNodes; q.triangles = state->triangles.data; q.nodes_used = state->nodesUsed; q.size = n;
+    q.fingerprint = print;
     return q.ctx;
 }
 

@@ -15,7 +15,7 @@ import ctypes as C
 import torch
 import torch.distributed as dist
 
-from .bindings import GpuContext, Partition
+from .bindings import Partition
 
 DEFAULT_TILE_ROWS = 8   # one wave tile (8x8 pixels) high
 
@@ -35,46 +35,3 @@ def gather_to_root(local, world, rank, root=0):
         return everything
     dist.gather(local, gather_list=None, dst=root)
     return None
-
-
-class ShardedRenderer:
-    """Per-rank: trace my tiles -> gather -> (rank 0) assemble into a device framebuffer."""
-
-    def __init__(self, scene_desc, rank, world, device_index, tile_rows=DEFAULT_TILE_ROWS):
-        self.rank, self.world = rank, world
-        self.device = torch.device("cuda", device_index)
-        torch.cuda.set_device(self.device)
-        self.ctx = GpuContext(device_index)
-        self.ctx.upload(scene_desc)
-        self.part = partition_of(rank, world, tile_rows)
-        self._buffers = {}
-
-    def _buffers_for(self, frame):
-        key = (frame.width, frame.height, frame.num_threads)
-        if key not in self._buffers:
-            n = self.ctx.partition_pixels(frame, self.part)
-            tiles = torch.zeros(n, dtype=torch.int32, device=self.device)
-            fb = torch.zeros(frame.height * frame.width, dtype=torch.int32, device=self.device) if self.rank == 0 else None
-            self._buffers[key] = (tiles, fb)
-        return self._buffers[key]
-
-    def trace(self, frame):
-        """Launch this rank's trace kernel on torch's current stream; returns the tile buffer."""
-        tiles, _ = self._buffers_for(frame)
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        self.ctx.render_partition(frame, self.part, tiles.data_ptr(), stream)
-        return tiles
-
-    def frame(self, frame):
-        """One whole frame; rank 0 gets the device framebuffer (int32 view of 0x00BBGGRR), others None."""
-        tiles = self.trace(frame)
-        gathered = gather_to_root(tiles, self.world, self.rank)
-        if self.rank != 0:
-            return None
-        _, fb = self._buffers_for(frame)
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        self.ctx.assemble(frame, self.part, gathered.data_ptr(), fb.data_ptr(), stream)
-        return fb
-
-    def close(self):
-        self.ctx.close()

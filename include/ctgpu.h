@@ -179,25 +179,49 @@ const char *ctgpu_build_id(void);
 const char *ctgpu_last_error(void);
 int  ctgpu_device_count(int *count);
 
-/* A context is bound to one GPU.  Tuning knobs are read from the environment here, once (none
- * changes a pixel -- tests/test_gpu_parity.py::test_pipeline_knobs_do_not_change_pixels):
- *   CTGPU_BLOCKS_PER_CU  persistent waves per CU of the traversal launches (0 = what fits; fewer
- *                        is better when several contexts keep frames in flight on one GPU)
- *   CTGPU_CHUNK          ray ids a wave reserves per queue atomic (multiple of 64; 0 = by frame size)
- *   CTGPU_CHUNK_SHADOW   the same for the shadow walk alone (default: CTGPU_CHUNK's value)
- *   CTGPU_KEEP_SHADOW_RAYS   1: trace also the shadow rays whose answer cannot change a pixel (ct_light_gate)
- *   CTGPU_RCCL_LIBRARY   path of the librccl to bind (default: one the process already holds, else ROCm's)
- *   CTGPU_PACKET         0: per-lane walk over the binary tree, 1: the shared (packet) walk, always (unset: the
- *                        shared walk unless the per-lane one was measured faster on this scene, ctgpu_walk_choice)
- *   CTGPU_PACKET_BUDGET, CTGPU_PACKET_LANES   experiment, off by default: packets that made BUDGET visits with fewer
- *                        than LANES rays per visit hand their rays to the per-lane kernel
- *   CTGPU_PACKET_LDS_LEVELS, CTGPU_LDS_DEPTH   stack levels kept in LDS (deeper ones go to HBM)
- *   CTGPU_FORCE_MEGAKERNEL   1: the general path (one kernel, reflection capable) for every frame
- *   CTGPU_PACK           host: re-lay-out an uploaded tree on the host (default: on the device)
- *   CTGPU_ORDER, CTGPU_ORDER_HEAVY, CTGPU_ORDER_SPLIT_BELOW   heavy chunks first (ctgpu_order_info)
- *   CTGPU_BOUNCE         frames whose materials reflect: 1 the bounce levels on the wavefront pipeline, 0 the general
- *                        path's one kernel (unset: whichever was measured faster, ctgpu_bounce_choice) */
+/* ---- configuration ----
+ * Every knob of a context in one place.  None changes a pixel (tests/test_gpu_parity.py::
+ * test_pipeline_knobs_do_not_change_pixels; the GPU suite is run under the main ones); they trade speed between
+ * workloads and switch measurement / experiment code.  ctgpu_default_config gives the built-in values,
+ * ctgpu_config_from_environment those overridden by the environment variable named beside each field (malformed values
+ * are ignored), ctgpu_create uses the latter, ctgpu_create_with_config what the caller hands it, ctgpu_get_config reports
+ * what a context runs with.  -1 in a "measured" field: the context tries both and keeps the faster (same pixels). */
+typedef struct ctgpu_config {
+    int32_t packet_walk;          /* CTGPU_PACKET         -1 measured per scene (ctgpu_walk_choice), 1 the shared (packet) walk, 0 the per-lane walk */
+    int32_t bounce;               /* CTGPU_BOUNCE         reflective frames: -1 measured (ctgpu_bounce_choice), 1 bounce levels, 0 the general path's one kernel */
+    int32_t force_megakernel;     /* CTGPU_FORCE_MEGAKERNEL  1: the general path for every frame */
+    int32_t keep_shadow_rays;     /* CTGPU_KEEP_SHADOW_RAYS  1: trace also the shadow rays whose answer cannot change a pixel (ct_light_gate) */
+    int32_t blocks_per_cu;        /* CTGPU_BLOCKS_PER_CU  persistent waves per CU of the walk launches (0: what fits; fewer suits several frames in flight) */
+    int32_t chunk, chunk_shadow;  /* CTGPU_CHUNK, CTGPU_CHUNK_SHADOW  ray ids a wave takes per queue atomic (multiple of 64; 0: by frame size / = chunk) */
+    int32_t lds_depth;            /* CTGPU_LDS_DEPTH      per-lane walk: stack levels kept in LDS */
+    int32_t packet_lds_levels;    /* CTGPU_PACKET_LDS_LEVELS  shared walk: per-lane tmin levels kept in LDS */
+    int32_t probe_above;          /* CTGPU_PROBE_ABOVE    fetches per packet beyond which the per-lane walk gets a trial frame */
+    int32_t packet_budget, packet_lanes;  /* CTGPU_PACKET_BUDGET, CTGPU_PACKET_LANES  hand-over experiment (0: off, the default) */
+    int32_t order;                /* CTGPU_ORDER          heavy chunks first: 0 off, 1 frames with few packets per wave (default), 2 every frame, 3 pipelined frames too */
+    float   order_heavy[4];       /* CTGPU_ORDER_HEAVY    "a,b,c,d": a chunk is of class k from this many times the mean packet's fetches */
+    int32_t order_floor;          /* CTGPU_ORDER_FLOOR    ... and never below this many fetches */
+    int32_t order_split_below;    /* CTGPU_ORDER_SPLIT_BELOW  chunks per wave of the grid below which heavy chunks are cut into parts */
+    int32_t order_parts[4];       /* CTGPU_ORDER_PARTS    "a,b,c,d": parts a chunk of class k is cut into (1, 2, 4, 8, 16) */
+    int32_t big_leaf_min;         /* CTGPU_BIG_LEAF       leaves of at least this many triangles get cull nodes (0: none) */
+    int32_t big_leaf_share;       /* CTGPU_BIG_LEAF_SHARE ... in scenes where at least this percentage of the triangles sits in such leaves */
+    int32_t pack_on_host;         /* CTGPU_PACK=host      1: re-lay-out an uploaded tree on the host (the restatement the device packing is tested against) */
+    int32_t thresh[3];            /* CTGPU_THRESH         "a,b,c": general path, lanes that make a phase worth running */
+    int32_t walk_thresh[3];       /* CTGPU_WALK_THRESH    "r,a,b": per-lane walk, the same (diagnostic builds: the middle number picks the walk they count) */
+    uint32_t debug;               /* CTGPU_DEBUG_PHASES (1), CTGPU_DEBUG_TRI (2), CTGPU_DEBUG_REDO (4), CTGPU_DEBUG_PACKET (8): diagnostics on stderr */
+} ctgpu_config;
+#define CTGPU_DEBUG_PHASES 1u
+#define CTGPU_DEBUG_TRI    2u
+#define CTGPU_DEBUG_REDO   4u
+#define CTGPU_DEBUG_PACKET 8u
+int  ctgpu_default_config(ctgpu_config *out);
+int  ctgpu_config_from_environment(ctgpu_config *out);
+/* (not in the struct because it is not per context: CTGPU_RCCL_LIBRARY, the librccl to bind -- default: one the process
+ *  already holds, else ROCm's) */
+
+/* A context is bound to one GPU.  ctgpu_create: configuration from the environment, read here, once. */
 int  ctgpu_create(int device, ctgpu_ctx **out);
+int  ctgpu_create_with_config(int device, const ctgpu_config *config, ctgpu_ctx **out);
+int  ctgpu_get_config(const ctgpu_ctx *ctx, ctgpu_config *out);
 void ctgpu_destroy(ctgpu_ctx *ctx);
 
 /* Scene -> HBM (raythread.cpp:641-654: GetSceneTriangles + InitializeBVHState + BuildBVH at RayThread's first call).

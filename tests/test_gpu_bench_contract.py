@@ -38,6 +38,14 @@ def test_bench_line_has_the_contract_fields():
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
     assert 0 < roof["frac"] <= 1 and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
     assert roof["kernel"].startswith("ct_walk_packet") and roof["launches_timed"] >= 4
+    # frac is the undisturbed launch (what profiles/ reproduces); the in-flight figure beside it, never better
+    assert roof["launch_ms_inflight"] >= 0.9 * roof["launch_ms"] and 0 < roof["frac_inflight"] <= roof["frac"] * 1.1
+    assert abs(roof["achieved"] - roof["bytes_per_launch"] / roof["launch_ms"] / 1e6) < 0.01 * roof["achieved"]
+    assert roof["limiter"]["what"] == "valu-issue"
+    ref = roof["reference_bytes"]
+    assert ref["primary_walk"]["bytes"] + ref["shadow_walk"]["bytes"] <= ref["per_frame"]
+    assert ref["primary_walk"]["rays"] + ref["shadow_walk"]["rays"] == rec["config"]["reference_rays_per_frame"]
+    assert len(rec["build_id"]["libctgpu"]) == 16 and len(rec["build_id"]["libcthost"]) == 16
     cpu = rec["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["unit"] == "Mrays/s" and cpu["sample"]
     assert rec["parity"]["differing_pixels"] == 0 and rec["parity"]["parity_max_lsb"] <= 1

@@ -234,3 +234,35 @@ def test_operator_level_boundary(scenes):
     assert scene.lib.cth_intersect_bvh(scene.handle, rays.ctypes.data, 300, 0, any_hit.ctypes.data) == 0
     assert (any_hit["t"].view(np.uint32) == want["t"].view(np.uint32)).all()
     ca.host_library().cth_raythread_reset()
+
+
+def test_operator_level_boundary_sees_a_tree_rebuilt_in_place():
+    """The reference's IntersectBVHClosest walks whatever the bvh_state_t holds at call time (bvh.cpp:198-222); the GPU-backed
+    export keeps the tree it was asked about last resident, keyed by the arrays' addresses, counts AND a fingerprint of their
+    content: the same arrays moved and rebuilt in place must be uploaded again, not answered from the old copy."""
+    from oracle import oracle
+    rng = np.random.default_rng(8)
+    verts = np.round((rng.random((400, 9)) * 2.0 - 1.0) * 2 ** 20) / 2 ** 20        # (multiples of 2^-20: moving by 64 and back is exact)
+    scene = ca.HostScene(vertices=verts)
+    rays = np.zeros(64, dtype=ca.bindings.RAY_DTYPE)
+    rays["origin"] = np.array([0.0, 0.0, -5.0]) + rng.normal(size=(64, 3)) * 0.2
+    rays["direction"] = np.array([0.0, 0.0, 1.0]) + rng.normal(size=(64, 3)) * 0.15
+    rays["t"] = np.float32(1e30)
+    try:
+        def ask():
+            got = np.zeros(len(rays), dtype=ca.bindings.HIT_DTYPE)
+            assert scene.lib.cth_intersect_bvh(scene.handle, rays.ctypes.data, len(rays), 1, got.ctypes.data) == 0
+            return got
+        first = ask()
+        want = oracle.trace_rays(scene.desc, rays)
+        assert first["found"].sum() > 20 and (first["t"].view(np.uint32) == want["t"].view(np.uint32)).all()
+        nodes = scene.lib.cth_move_tree_in_place(scene.handle, 64.0)         # 64 units to the side: these rays now miss
+        assert nodes > 1
+        moved = ask()
+        assert moved["found"].sum() == 0, "answered from the tree that is no longer there"
+        scene.lib.cth_move_tree_in_place(scene.handle, -64.0)                # and back: the first answers again
+        back = ask()
+        assert (back["t"].view(np.uint32) == first["t"].view(np.uint32)).all() and (back["triangle"] == first["triangle"]).all()
+    finally:
+        ca.host_library().cth_raythread_reset()
+        scene.close()

@@ -143,6 +143,29 @@ def test_pageable_framebuffers_in_the_c_heap():
             if k %% 3 == 0:
                 del ballast                                                        # the top of the heap goes back ...
             del fb, got                                                            # ... and comes again next round
+        # A registration that outlives its memory (advisor, round 3): a context that keeps its page-lock between frames
+        # draws into a C-heap array, the array is freed, and a LARGER array comes to lie on the same addresses.  The
+        # runtime would still call its first byte "host memory"; the library knows the range as one of its own
+        # registrations and stages -- in the context that made it, in another context, through begin / poll and render.
+        keeper = ca.GpuContext(0)
+        keeper.share_scene(ctx)
+        keeper.keep_framebuffer_pinned(True)
+        small = np.zeros((frames[2].height, frames[2].width), dtype=np.uint32)
+        at = small.ctypes.data
+        keeper.render_begin(frames[2], small)
+        assert keeper.render_poll(wait=True)[0] and (small == want[2]).all()
+        del small                                                                  # freed; the page-lock stays (keep_pin)
+        big = np.zeros((frames[1].height, frames[1].width), dtype=np.uint32)      # a larger array from the same heap
+        reused = big.ctypes.data <= at < big.ctypes.data + big.nbytes
+        for renderer in (ctx, keeper):
+            got, _ = renderer.render(frames[1], big)
+            assert (big == want[1]).all()
+            big[:] = 0
+        keeper.render_begin(frames[1], big)                                        # another range: the stale pin is dropped, big registered
+        assert keeper.render_poll(wait=True)[0] and (big == want[1]).all()
+        keeper.keep_framebuffer_pinned(False)
+        keeper.close()
+        print("stale registration: the larger array %s the freed one's addresses" % ("covers" if reused else "does not cover"))
         try:
             ctx.download_frame(frames[0], 1, np.zeros((480, 640), dtype=np.uint32).ctypes.data)
         except RuntimeError as e:
@@ -154,3 +177,42 @@ def test_pageable_framebuffers_in_the_c_heap():
     """) % (ROOT, ROOT)
     proc = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert proc.returncode == 0 and proc.stdout.strip().endswith("ok"), proc.stdout[-2000:] + proc.stderr[-4000:]
+
+
+def test_contexts_report_and_take_their_configuration(scenes, monkeypatch):
+    """ctgpu_get_config: a context made by ctgpu_create runs with what the environment said at that moment;
+    ctgpu_create_with_config takes the caller's struct instead (and refuses values out of range); the knobs do what the
+    header says -- here: no cull nodes with big_leaf_min = 0, the host's packing with pack_on_host -- and no pixel moves."""
+    monkeypatch.setenv("CTGPU_CHUNK", "256")
+    monkeypatch.setenv("CTGPU_ORDER", "0")
+    ctx = ca.GpuContext(0)
+    monkeypatch.delenv("CTGPU_CHUNK")
+    monkeypatch.delenv("CTGPU_ORDER")
+    scene = scenes("import")
+    try:
+        got = ctx.get_config()
+        assert (got.chunk, got.order) == (256, 0)
+        want = ca.default_config()
+        want.chunk, want.order = 256, 0
+        assert got.as_dict() == want.as_dict()
+        ctx.upload(scene.desc)
+        frame = scene.frame(320, 240, rng_seed=2)
+        reference, _ = ctx.render(frame)
+        assert len(ctx.scene_array(6)) > 0
+        custom = ca.default_config()
+        custom.big_leaf_min, custom.pack_on_host, custom.packet_walk, custom.keep_shadow_rays = 0, 1, 1, 1
+        other = ca.GpuContext(0, config=custom)
+        try:
+            assert other.get_config().as_dict() == custom.as_dict()
+            other.upload(scene.desc)
+            assert len(other.scene_array(6)) == 0
+            fb, _ = other.render(frame)
+            assert (fb == reference).all()
+        finally:
+            other.close()
+        bad = ca.default_config()
+        bad.order_parts[1] = 3
+        with pytest.raises(RuntimeError, match="out of range"):
+            ca.GpuContext(0, config=bad)
+    finally:
+        ctx.close()
