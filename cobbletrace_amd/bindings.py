@@ -100,7 +100,7 @@ class Config(C.Structure):
                 ("blocks_per_cu", C.c_int32), ("chunk", C.c_int32), ("chunk_shadow", C.c_int32), ("lds_depth", C.c_int32),
                 ("packet_lds_levels", C.c_int32), ("probe_above", C.c_int32), ("packet_budget", C.c_int32), ("packet_lanes", C.c_int32),
                 ("order", C.c_int32), ("order_heavy", C.c_float * 4), ("order_floor", C.c_int32), ("order_split_below", C.c_int32),
-                ("order_parts", C.c_int32 * 4), ("big_leaf_min", C.c_int32), ("big_leaf_share", C.c_int32), ("pack_on_host", C.c_int32),
+                ("order_parts", C.c_int32 * 4), ("shadow_split_gap", C.c_float), ("big_leaf_min", C.c_int32), ("big_leaf_share", C.c_int32), ("pack_on_host", C.c_int32),
                 ("thresh", C.c_int32 * 3), ("walk_thresh", C.c_int32 * 3), ("debug", C.c_uint32)]
 
     def as_dict(self):

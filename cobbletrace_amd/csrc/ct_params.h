@@ -12,8 +12,10 @@ namespace ctd {
 
 // words of FrameParams::counters: 0 primary rays, 1 shadow rays, 2 reflected rays, 3 node visits, 4 triangle
 // tests, 5..14 diagnostic builds, 15 rays the packet walk walked again unfolded, 16 shadow rays not needed,
-// 17 / 18 primary / shadow rays the packet walk handed over to the per-lane walk
-constexpr int kCounterWords = 24;
+// 17 / 18 primary / shadow rays the packet walk handed over to the per-lane walk; 19..23 triangle-test stages (CT_TRI_STATS);
+// 24..47 histograms of the CT_WALK_STATS build, eight bins of eight lanes each: node visits, triangle tests and packets by
+// the number of rays taking part (tools/lane_stats.py)
+constexpr int kCounterWords = 48;
 // ray-queue head words: walk 0 primary rays, walks 1..L the shadow rays of the scene's L shadow-casting lights, walks
 // L+1 / L+2 the handed-over primary / shadow rays; 8 shards each, one 128-byte line per head word; then 32 words
 // for the two hand-over counters (everything cleared together, per frame)
@@ -135,6 +137,8 @@ struct PipelineParams {
     uint32_t list_slots;         // 1: ray_hits[].triangle receives the TriRecord SLOT (kNoNode: none recorded), not the scene triangle
     uint32_t list_counter;       // frame counter word the walk adds its ray count to (0: none; 1 shadow rays, 2 reflected rays)
     const uint32_t *list_gate;   // when set and *list_gate == 0 the list holds no ray: the walk's waves leave at once
+    float    shadow_split_gap;   // shadow packets: a window's hit samples go out as two groups when their primary hits' depths fall into
+                                 // two ranges at least this far apart (relative to the middle depth); < 0: never
     uint32_t ordered;            // 1: the frame's packet walks are the ORDERED instantiations, order[] is set
     OrderParams order[2];
 };

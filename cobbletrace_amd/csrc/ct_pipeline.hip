@@ -705,7 +705,8 @@ struct PacketStack {
     float __attribute__((address_space(1))) *tmin_spill;  // [depth - lds_levels][64] deeper levels, in HBM
     uint32_t lds_levels;
     static __host__ __device__ size_t bytes(uint32_t depth, uint32_t lds_levels) {
-        return (size_t)((depth + 3u) & ~3u) * 4u + (size_t)lds_levels * 256u;
+        // (at least 512 bytes behind the parent words: the shadow walk lists a window's 128 ray offsets there)
+        return (size_t)((depth + 3u) & ~3u) * 4u + (size_t)(lds_levels < 2u ? 2u : lds_levels) * 256u;
     }
     __device__ __forceinline__ void put_tmin(uint32_t level, uint32_t lane, float v) const {
         if (level < lds_levels) tmin[level * kWave + lane] = v;
@@ -784,6 +785,10 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
     uint64_t chunk_next = 0, chunk_end = 0;
     bool wave_drained = false;
     uint32_t n_traced = 0;
+    // shadow walk: the window of up to 128 ray ids the next packets come from -- the live ones' offsets, listed in LDS (the
+    // per-lane tmin levels' room, which an any-hit walk does not use), near cluster first (see the fetch below)
+    uint32_t win_pos = 0, win_count = 0, win_split = 0;
+    uint64_t win_base = 0;
     // what this wave asked the memory system for: packets walked, QuadNodes (128 B each) and triangle
     // records (80 B each) fetched -- the kernel's own bytes of the roofline (ctgpu_read_walk_work)
     uint32_t n_packets = 0, n_quads = 0, n_records = 0;
@@ -797,10 +802,15 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
 #ifdef CT_WALK_STATS
     unsigned long long pk_n[6] = {0, 0, 0, 0, 0, 0}, pk_cyc[3] = {0, 0, 0};
     const unsigned long long pk_begin = __builtin_amdgcn_s_memtime();
+    // (one wave per workgroup: the histograms are this wave's own until the end)
+    __shared__ unsigned int pk_hist[24];
+    if (lane < 24) pk_hist[lane] = 0u;
+#define PK_HIST(which, lanes, n) do { if (lane == 0 && (lanes) > 0) pk_hist[(which) * 8 + ((lanes) - 1) / 8] += (unsigned int)(n); } while (0)
 #define PK_COUNT(i, v) do { pk_n[i] += (unsigned long long)(v); } while (0)
 #define PK_T0() const unsigned long long pk_t0 = __builtin_amdgcn_s_memtime()
 #define PK_T1(i) do { pk_cyc[i] += __builtin_amdgcn_s_memtime() - pk_t0; } while (0)
 #else
+#define PK_HIST(which, lanes, n) do {} while (0)
 #define PK_COUNT(i, v) do {} while (0)
 #define PK_T0() do {} while (0)
 #define PK_T1(i) do {} while (0)
@@ -817,6 +827,25 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
         redo = false;
         float px = 0.0f, py = 0.0f;
         for (;;) {
+            if (KIND == 1) {
+                // Shadow packets come from a WINDOW of up to 128 consecutive ids (two 2x2-pixel blocks' samples under one
+                // light) whose live ids -- the hit samples whose light can contribute -- were listed in LDS when the window
+                // was opened: 64 list entries a packet.  Where the window's primary hits fall into two depth ranges that
+                // are clearly apart (a silhouette: the samples of the near surface and those of what lies behind it), the
+                // list holds the near ones first and a packet does not cross from one to the other: rays that start on
+                // different surfaces share little of their way to the light, and walking them together only makes every
+                // visit of either wider.  Who walks with whom never changes a ray's result.
+                if (win_pos < win_count) {
+                    uint32_t upto = win_count;
+                    if (win_split > win_pos && win_split < upto) upto = win_split;
+                    const uint32_t n = upto - win_pos < 64u ? upto - win_pos : 64u;
+                    LdsWord *win_list = (LdsWord *)st.tmin;
+                    if (lane < n) { ray_id = win_base + win_list[win_pos + lane]; has_ray = true; }
+                    win_pos += n;
+                    break;
+                }
+                if (wave_drained) break;
+            }
             const unsigned long long m_i = __ballot(!has_ray);
             if (m_i == 0ull || wave_drained) break;
             if (chunk_next >= chunk_end) {
@@ -873,10 +902,46 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                 chunk_end = chunk_light_base + hi;
                 if (KIND == 1) chunk_light_index = (uint32_t)__builtin_amdgcn_readfirstlane((int)W.shadow_lights[light]);
                 }
-                // a packet never mixes lights (its rays should point the same way) nor chunks (the next chunk
-                // this wave gets lies elsewhere in the image: topping up from it was measured, 5 % slower --
-                // it splits that chunk's rays over two packets, i.e. two walks through that region)
-                if (KIND == 1 && m_i != ~0ull) break;
+                // (a shadow packet never mixes lights -- its rays should point the same way -- nor chunks: the next chunk
+                //  this wave gets lies elsewhere in the image; topping up from it was measured, 5 % slower)
+            }
+            if (KIND == 1) {
+                // open the next window of the chunk: which of its ids are rays, and how deep their primary hits lie
+                const uint32_t n_ids = chunk_end - chunk_next < 128u ? (uint32_t)(chunk_end - chunk_next) : 128u;
+                const uint64_t id0 = chunk_next + lane, id1 = chunk_next + 64u + lane;
+                const bool live0 = lane < n_ids && W.shadow[id0] == 0, live1 = 64u + lane < n_ids && W.shadow[id1] == 0;
+                float t0 = 0.0f, t1 = 0.0f;
+                if (live0) { const uint2 h = W.hits[id0 - chunk_light_base]; t0 = (h.y != kNoNode) ? __uint_as_float(h.x) : kFarAway; }
+                if (live1) { const uint2 h = W.hits[id1 - chunk_light_base]; t1 = (h.y != kNoNode) ? __uint_as_float(h.x) : kFarAway; }
+                bool far0 = false, far1 = false;
+                unsigned long long m_live0 = __ballot(live0), m_live1 = __ballot(live1);
+                if (W.shadow_split_gap >= 0.0f && (m_live0 | m_live1) != 0ull) {
+                    const float inf = __builtin_inff();
+                    float lo = __builtin_fminf(live0 ? t0 : inf, live1 ? t1 : inf), hi = __builtin_fmaxf(live0 ? t0 : -inf, live1 ? t1 : -inf);
+                    for (int off = 32; off > 0; off >>= 1) { lo = __builtin_fminf(lo, __shfl_xor(lo, off)); hi = __builtin_fmaxf(hi, __shfl_xor(hi, off)); }
+                    const float mid = 0.5f * (lo + hi);
+                    float near_hi = __builtin_fmaxf(live0 && t0 <= mid ? t0 : -inf, live1 && t1 <= mid ? t1 : -inf);
+                    float far_lo = __builtin_fminf(live0 && t0 > mid ? t0 : inf, live1 && t1 > mid ? t1 : inf);
+                    for (int off = 32; off > 0; off >>= 1) { near_hi = __builtin_fmaxf(near_hi, __shfl_xor(near_hi, off)); far_lo = __builtin_fminf(far_lo, __shfl_xor(far_lo, off)); }
+                    if (far_lo - near_hi > W.shadow_split_gap * mid) { far0 = live0 && t0 > mid; far1 = live1 && t1 > mid; }
+                }
+                const unsigned long long m_far0 = __ballot(far0), m_far1 = __ballot(far1);
+                const unsigned long long m_near0 = m_live0 & ~m_far0, m_near1 = m_live1 & ~m_far1;
+                const uint32_t n_near0 = (uint32_t)__popcll(m_near0), n_near = n_near0 + (uint32_t)__popcll(m_near1);
+                const uint32_t n_far0 = (uint32_t)__popcll(m_far0), n_far = n_far0 + (uint32_t)__popcll(m_far1);
+                const auto rank_in = [&](unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
+                LdsWord *win_list = (LdsWord *)st.tmin;
+                if (live0) win_list[far0 ? n_near + rank_in(m_far0) : rank_in(m_near0)] = lane;
+                if (live1) win_list[far1 ? n_near + n_far0 + rank_in(m_far1) : n_near0 + rank_in(m_near1)] = 64u + lane;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                win_base = chunk_next;
+                win_pos = 0; win_count = n_near + n_far; win_split = n_far != 0u ? n_near : 0u;
+                chunk_next += n_ids;
+                light_base = chunk_light_base;                // (the packets' light)
+                light_index = chunk_light_index;
+                if (ORDERED) cost_at = chunk_cost_at;
+                continue;
             }
             const uint64_t avail = chunk_end - chunk_next;
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m_i >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m_i, 0u));
@@ -914,6 +979,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
             continue;
         }
         n_packets += 1;
+        { const int rays_in_packet = __popcll(__ballot(has_ray)); PK_HIST(2, rays_in_packet, 1); (void)rays_in_packet; }
         if (ORDERED) cost_mark = n_quads + n_records;
 #ifdef CT_PACKET_TRACE
         const unsigned long long trace_begin = wall_clock64();
@@ -1075,6 +1141,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                         n_records += count;
                         PK_COUNT(2, count);
                         PK_COUNT(3, (uint64_t)count * __popcll(mask));
+                        PK_HIST(1, __popcll(mask), count);
                     }
 #ifdef CT_TRI_STATS
                     // diagnostic build (tools/tri_stats.py): how far does the WAVE get into IntersectTriangle for this
@@ -1126,6 +1193,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                 PK_COUNT(0, 1);
                 n_quads += 1;
                 PK_COUNT(1, __popcll(mask));
+                PK_HIST(0, __popcll(mask), 1);
                 const uint32_t node_id = CULL ? (cur & kSlotMask) : cur;       // (a cull node's entries carry kOneBit)
                 const ScalarQuad sq = scalar_load_quad(quads + node_id);
 #ifdef CT_DUMMY_VALU                       // diagnostic builds: what N more vector / scalar instructions per visit cost
@@ -1367,6 +1435,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
 #ifdef CT_WALK_STATS
     if (lane == 0 && KIND == W.thresh_a) {     // diagnostic build: CTGPU_WALK_THRESH=r,<kind>,b picks the kernel
         for (int k = 0; k < 6; k++) atomicAdd(&P.counters[5 + k], pk_n[k]);
+        for (int k = 0; k < 24; k++) atomicAdd(&P.counters[24 + k], (unsigned long long)pk_hist[k]);
         for (int k = 0; k < 3; k++) atomicAdd(&P.counters[11 + k], pk_cyc[k]);
         atomicAdd(&P.counters[14], __builtin_amdgcn_s_memtime() - pk_begin);
     }

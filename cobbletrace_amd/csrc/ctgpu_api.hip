@@ -309,6 +309,7 @@ extern "C" int ctgpu_default_config(ctgpu_config *c) {
     for (int k = 0; k < 4; k++) { c->order_heavy[k] = heavy[k]; c->order_parts[k] = parts[k]; }
     c->order_floor = 64; c->order_split_below = 8;
     c->big_leaf_min = 8; c->big_leaf_share = 20;
+    c->shadow_split_gap = -1.0f;
     const int thresh[3] = {40, 20, 12}, walk_thresh[3] = {64, 32, 24};       // (measured best on MI355X)
     for (int k = 0; k < 3; k++) { c->thresh[k] = thresh[k]; c->walk_thresh[k] = walk_thresh[k]; }
     return CTGPU_OK;
@@ -336,6 +337,7 @@ extern "C" int ctgpu_config_from_environment(ctgpu_config *c) {
     if (const char *t = std::getenv("CTGPU_KEEP_SHADOW_RAYS")) c->keep_shadow_rays = std::atoi(t) != 0 ? 1 : 0;
     if (const char *t = std::getenv("CTGPU_FORCE_MEGAKERNEL")) c->force_megakernel = std::atoi(t) != 0 ? 1 : 0;
     number("CTGPU_PROBE_ABOVE", c->probe_above, 0, big);
+    if (const char *t = std::getenv("CTGPU_SHADOW_SPLIT")) { float v; if (std::sscanf(t, "%f", &v) == 1 && v == v) c->shadow_split_gap = v; }
     number("CTGPU_BIG_LEAF", c->big_leaf_min, 0, big);
     number("CTGPU_BIG_LEAF_SHARE", c->big_leaf_share, 0, 100);
     number("CTGPU_PACKET_BUDGET", c->packet_budget, 0, big);
@@ -1073,6 +1075,14 @@ int read_counters(ctgpu_ctx *ctx, ctgpu_stats *st) {
     if ((debug & CTGPU_DEBUG_TRI) && c[19])         // diagnostic build -DCT_TRI_STATS (tools/tri_stats.py)
         std::fprintf(stderr, "triangle records tested by a wave: %llu; the wave's furthest lane stops at |a| %.2f%%, at u %.2f%%, at v / u+v %.2f%%, "
                      "passes (a hit candidate) %.2f%%\n", c[19], 100.0 * c[20] / c[19], 100.0 * c[21] / c[19], 100.0 * c[22] / c[19], 100.0 * c[23] / c[19]);
+    if ((debug & CTGPU_DEBUG_PACKET) && c[14]) {          // diagnostic build -DCT_WALK_STATS (tools/lane_stats.py): "hist <what> b0 .. b7"
+        const char *what[3] = {"node visits", "triangle tests", "packets"};
+        for (int h = 0; h < 3; h++) {
+            std::fprintf(stderr, "hist %s by rays taking part (1-8 .. 57-64):", what[h]);
+            for (int b = 0; b < 8; b++) std::fprintf(stderr, " %llu", c[24 + h * 8 + b]);
+            std::fprintf(stderr, "\n");
+        }
+    }
     if (debug & CTGPU_DEBUG_REDO)
         std::fprintf(stderr, "packet walk: %llu rays walked again unfolded (NaN box parameter)\n", c[15]);
     if ((debug & CTGPU_DEBUG_PACKET) && c[14])
@@ -1271,6 +1281,7 @@ int fill_pipeline(ctgpu_ctx *ctx, uint64_t n_samples, PipelineParams &W, int kin
     W.n_samples = n_samples;
     W.n_shadow_lights = ctx->scene->n_shadow_lights;
     W.keep_every_shadow_ray = ctx->keep_shadow_rays ? 1u : 0u;
+    W.shadow_split_gap = ctx->cfg.shadow_split_gap;
     W.lds_depth = std::min<uint32_t>((uint32_t)ctx->lds_depth, std::max<uint32_t>(ctx->scene->tree_depth, 1));
     W.spill_depth = std::max<uint32_t>(ctx->scene->tree_depth, 1) - W.lds_depth;
     const size_t lds_bytes = (size_t)W.lds_depth * 64 * 12;

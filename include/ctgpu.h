@@ -202,6 +202,8 @@ typedef struct ctgpu_config {
     int32_t order_floor;          /* CTGPU_ORDER_FLOOR    ... and never below this many fetches */
     int32_t order_split_below;    /* CTGPU_ORDER_SPLIT_BELOW  chunks per wave of the grid below which heavy chunks are cut into parts */
     int32_t order_parts[4];       /* CTGPU_ORDER_PARTS    "a,b,c,d": parts a chunk of class k is cut into (1, 2, 4, 8, 16) */
+    float   shadow_split_gap;     /* CTGPU_SHADOW_SPLIT   shadow packets: the hit samples of a window (two 2x2-pixel blocks) walk as two packets when their
+                                     primary hits' depths fall into two ranges this far apart, relative to the middle depth (< 0: never) */
     int32_t big_leaf_min;         /* CTGPU_BIG_LEAF       leaves of at least this many triangles get cull nodes (0: none) */
     int32_t big_leaf_share;       /* CTGPU_BIG_LEAF_SHARE ... in scenes where at least this percentage of the triangles sits in such leaves */
     int32_t pack_on_host;         /* CTGPU_PACK=host      1: re-lay-out an uploaded tree on the host (the restatement the device packing is tested against) */

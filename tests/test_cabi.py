@@ -116,6 +116,9 @@ def test_host_library_exports_the_reference_boundary():
         assert signature in out, signature
 
 
+DEFAULT_SHADOW_SPLIT = -1.0
+
+
 def test_configuration_struct_and_environment(monkeypatch):
     """ctgpu_config (include/ctgpu.h): one struct for every knob of a context.  Needs no GPU: the defaults, and what the
     environment makes of them -- each variable lands in its field, malformed values are ignored."""
@@ -125,12 +128,13 @@ def test_configuration_struct_and_environment(monkeypatch):
     d = ca.default_config()
     assert ca.config_from_environment().as_dict() == d.as_dict()
     assert (d.packet_walk, d.bounce, d.order, d.big_leaf_min, d.big_leaf_share, d.pack_on_host, d.debug) == (-1, -1, 1, 8, 20, 0, 0)
+    assert d.shadow_split_gap == DEFAULT_SHADOW_SPLIT
     assert list(d.order_heavy) == [8.0, 4.0, 2.0, 1.0] and list(d.order_parts) == [4, 2, 1, 1] and list(d.walk_thresh) == [64, 32, 24]
     env = {"CTGPU_PACKET": "0", "CTGPU_BOUNCE": "1", "CTGPU_FORCE_MEGAKERNEL": "1", "CTGPU_KEEP_SHADOW_RAYS": "1", "CTGPU_BLOCKS_PER_CU": "12",
            "CTGPU_CHUNK": "128", "CTGPU_CHUNK_SHADOW": "256", "CTGPU_LDS_DEPTH": "5", "CTGPU_PACKET_LDS_LEVELS": "9", "CTGPU_PROBE_ABOVE": "77",
            "CTGPU_PACKET_BUDGET": "96", "CTGPU_PACKET_LANES": "200", "CTGPU_ORDER": "2", "CTGPU_ORDER_HEAVY": "9,5,3,1.5", "CTGPU_ORDER_FLOOR": "3",
            "CTGPU_ORDER_SPLIT_BELOW": "4", "CTGPU_ORDER_PARTS": "8,4,2,1", "CTGPU_BIG_LEAF": "16", "CTGPU_BIG_LEAF_SHARE": "250", "CTGPU_PACK": "host",
-           "CTGPU_THRESH": "1,2,3", "CTGPU_WALK_THRESH": "4,5,6", "CTGPU_DEBUG_REDO": "1", "CTGPU_DEBUG_PACKET": "1"}
+           "CTGPU_SHADOW_SPLIT": "0.25", "CTGPU_THRESH": "1,2,3", "CTGPU_WALK_THRESH": "4,5,6", "CTGPU_DEBUG_REDO": "1", "CTGPU_DEBUG_PACKET": "1"}
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     c = ca.config_from_environment()
@@ -138,7 +142,7 @@ def test_configuration_struct_and_environment(monkeypatch):
     assert (c.lds_depth, c.packet_lds_levels, c.probe_above, c.packet_budget, c.packet_lanes) == (5, 9, 77, 96, 64)       # (lanes clamped to a wave)
     assert (c.order, c.order_floor, c.order_split_below, c.big_leaf_min, c.big_leaf_share, c.pack_on_host, c.debug) == (2, 3, 4, 16, 100, 1, 4 | 8)
     assert list(c.order_heavy) == [9.0, 5.0, 3.0, 1.5] and list(c.order_parts) == [8, 4, 2, 1]
-    assert list(c.thresh) == [1, 2, 3] and list(c.walk_thresh) == [4, 5, 6]
+    assert list(c.thresh) == [1, 2, 3] and list(c.walk_thresh) == [4, 5, 6] and c.shadow_split_gap == 0.25
     for k, v in {"CTGPU_ORDER_HEAVY": "1,2,3,4", "CTGPU_ORDER_PARTS": "3,3,3,3", "CTGPU_THRESH": "7", "CTGPU_PACK": "device"}.items():
         monkeypatch.setenv(k, v)                                                # rising thresholds, parts that are no power of two, ...
     c = ca.config_from_environment()
