@@ -191,7 +191,9 @@ __global__ void k_quad_count(const ctgpu_node *nodes, const uint32_t *head, uint
 }
 struct QuadOut {
     QuadNode *quads;
-    double *boxes;            // [quad][4][6]
+    double *boxes;            // [quad][4][6] (the folded tree: read on the walk's undecided visits, one dependent fetch)
+    uint32_t *node_of;        // [quad][4] the entries' reference nodes (the unfolded tree: its boxes are read from the reference's
+                              //           own node array, by the one ray in a million that walks it; NULL for the folded tree)
     uint32_t *head, *before;  // per QuadNode: its reference node; entries pending on the stack when it is reached
     uint32_t *pending_max;
     float bound[3];
@@ -228,8 +230,12 @@ __global__ void k_quad_emit(const ctgpu_node *nodes, QuadOut out, uint32_t begin
     node.count = n;
     node.pad_[0] = node.pad_[1] = node.pad_[2] = 0u;
     out.quads[q] = node;
-    double *dst = out.boxes + (size_t)q * 24;
-    for (int i = 0; i < 24; i++) dst[i] = (&box[0][0])[i];
+    if (out.boxes) {
+        double *dst = out.boxes + (size_t)q * 24;
+        for (int i = 0; i < 24; i++) dst[i] = (&box[0][0])[i];
+    }
+    if (out.node_of)
+        for (uint32_t k = 0; k < 4; k++) out.node_of[(size_t)q * 4 + k] = k < n ? entry[k] : 0u;
     atomicMax(out.pending_max, before + n - 1u);
 }
 
@@ -272,20 +278,23 @@ struct Owned {
 // one of the two QuadNode trees; arrays sized for the worst case (every inner node heads a QuadNode) and left so
 int build_quads(const ctgpu_node *d_nodes, bool root_is_inner, uint32_t n_inner, bool fold, const float bound[3], Owned &owned,
                 const Scanner &scan, uint32_t *d_counts, uint32_t *d_offsets, uint32_t *d_pending, QuadNode *&quads,
-                double *&boxes, uint32_t &n_quads, uint32_t &root, uint32_t &pending) {
+                double *&boxes, uint32_t *&node_of, uint32_t &n_quads, uint32_t &root, uint32_t &pending) {
     const uint32_t room = std::max<uint32_t>(n_inner, 1);
     HIP_TRY(owned.alloc(quads, room));
-    HIP_TRY(owned.alloc(boxes, (size_t)room * 24));
+    boxes = nullptr; node_of = nullptr;
+    if (fold) HIP_TRY(owned.alloc(boxes, (size_t)room * 24));
+    else HIP_TRY(owned.alloc(node_of, (size_t)room * 4));
     root = kLeafBit | 0u;
     pending = 1;
     if (!root_is_inner) {                             // a single leaf: one all-zero QuadNode nobody visits
         HIP_TRY(hipMemsetAsync(quads, 0, sizeof(QuadNode), nullptr));
-        HIP_TRY(hipMemsetAsync(boxes, 0, 24 * sizeof(double), nullptr));
+        if (boxes) HIP_TRY(hipMemsetAsync(boxes, 0, 24 * sizeof(double), nullptr));
+        if (node_of) HIP_TRY(hipMemsetAsync(node_of, 0, 4 * sizeof(uint32_t), nullptr));
         n_quads = 1;
         return CTGPU_OK;
     }
     QuadOut out;
-    out.quads = quads; out.boxes = boxes; out.pending_max = d_pending;
+    out.quads = quads; out.boxes = boxes; out.node_of = node_of; out.pending_max = d_pending;
     std::memcpy(out.bound, bound, sizeof out.bound);
     HIP_TRY(owned.alloc(out.head, room));
     HIP_TRY(owned.alloc(out.before, room));
@@ -316,7 +325,8 @@ int build_quads(const ctgpu_node *d_nodes, bool root_is_inner, uint32_t n_inner,
     n_quads = end;
     HIP_TRY(hipMemcpy(&pending, d_pending, 4, hipMemcpyDeviceToHost));
     owned.keep(quads);
-    owned.keep(boxes);
+    if (boxes) owned.keep(boxes);
+    if (node_of) owned.keep(node_of);
     return CTGPU_OK;
 }
 
@@ -587,13 +597,15 @@ int ctgpu_pack_on_device(int device, const ctgpu_node *d_nodes, uint32_t m, cons
     HIP_TRY(owned.alloc(d_pending, 1));
     QuadNode *quads = nullptr, *quads_flat = nullptr;
     uint32_t pending = 1, pending_flat = 1;
+    uint32_t *no_ids = nullptr;
+    double *no_boxes = nullptr;
     rc = build_quads(d_nodes, root_is_inner, n_inner, true, out->plane_bound, owned, scan, d_counts, d_offsets, d_pending, quads,
-                     out->quad_boxes, out->n_quads, out->quad_root, pending);
+                     out->quad_boxes, no_ids, out->n_quads, out->quad_root, pending);
     if (rc) return rc;
     rc = build_quads(d_nodes, root_is_inner, n_inner, false, out->plane_bound, owned, scan, d_counts, d_offsets, d_pending, quads_flat,
-                     out->quad_boxes_flat, out->n_quads_flat, out->quad_root_flat, pending_flat);
+                     no_boxes, out->quad_node_of_flat, out->n_quads_flat, out->quad_root_flat, pending_flat);
     if (rc) return rc;
-    if (!root_is_inner) { owned.keep(quads); owned.keep(out->quad_boxes); owned.keep(quads_flat); owned.keep(out->quad_boxes_flat); }
+    if (!root_is_inner) { owned.keep(quads); owned.keep(out->quad_boxes); owned.keep(quads_flat); owned.keep(out->quad_node_of_flat); }
     out->quads = quads;
     out->quads_flat = quads_flat;
     out->quad_pending = std::max(pending, pending_flat);

@@ -34,7 +34,8 @@ struct FrameParams {
     const double    *quad_boxes;  // [quad][entry][6] the entries' binary64 boxes (min xyz, max xyz): levels 1 and 2
     uint32_t quad_root;           // root reference of the folded tree (a leaf reference for a one-leaf tree)
     const QuadNode  *quads_flat;  // the same tree with nothing folded (two entries per node): second pass of
-    const double    *quad_boxes_flat;    // the packet walk, for rays folding is not proven for
+    const uint32_t  *quad_node_of_flat;  // the packet walk, for rays folding is not proven for; [quad][entry] -> reference node,
+    const ctgpu_node *ref_nodes;         // whose box (bmin, bmax: the node's first six doubles) is that entry's
     uint32_t quad_root_flat;
     const TriRecord *tris;
     const Material  *materials;

@@ -1059,7 +1059,12 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
         bool hand_over = false;
         for (int walk_pass = 0; walk_pass < 2; walk_pass++) {
         const QuadNode *quads = walk_pass == 0 ? P.quads : P.quads_flat;
-        const double *quad_boxes = walk_pass == 0 ? P.quad_boxes : P.quad_boxes_flat;
+        // an entry's binary64 box: beside the folded tree's QuadNodes (one dependent fetch on the undecided visits); the
+        // unfolded tree's, walked by one ray in a million, through the entry's reference node
+        const auto entry_box = [&](uint32_t index) -> const double * {
+            if (walk_pass == 0) return P.quad_boxes + (size_t)index * 6u;
+            return P.ref_nodes[P.quad_node_of_flat[index]].bmin;
+        };
         if (walk_pass == 1) {
             const unsigned long long again = __ballot(redo);
             if (again == 0ull) break;
@@ -1275,7 +1280,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
 #pragma nounroll
                         for (uint32_t k = 0; k < n_entries; k++) {
                             if (((todo >> k) & 1u) == 0u) continue;
-                            const double *bmin = quad_boxes + (size_t)(node_id * 4u + k) * 6u, *bmax = bmin + 3;
+                            const double *bmin = entry_box(node_id * 4u + k), *bmax = bmin + 3;
                             const d3 inv = make_d3(quick_reciprocal(d.x), quick_reciprocal(d.y), quick_reciprocal(d.z));
                             float tmin64, tmax64;
                             bool verdict;
@@ -1362,7 +1367,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                         // the binary64 box, one step off at most -- and if that is still too close, the whole
                         // test exactly
                         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                        const double *bmin = quad_boxes + (size_t)st.parent[sp] * 6u;
+                        const double *bmin = entry_box(st.parent[sp]);
                         const d3 inv = make_d3(quick_reciprocal(d.x), quick_reciprocal(d.y), quick_reciprocal(d.z));
                         float etmin, etmax;
                         const bool some_nan = slab_approx_checked(RAY_O, inv, bmin, bmin + 3, etmin, etmax);

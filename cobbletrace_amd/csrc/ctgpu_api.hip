@@ -78,7 +78,8 @@ struct SceneStore {
 
     DeviceArray<WideNode> nodes;
     DeviceArray<QuadNode> quads, quads_flat;
-    DeviceArray<double> quad_boxes, quad_boxes_flat;      // [quad][entry][6]: the entries' binary64 boxes
+    DeviceArray<double> quad_boxes;             // [quad][entry][6]: the folded tree's entries' binary64 boxes
+    DeviceArray<uint32_t> quad_node_of_flat;    // [quad][entry]: the unfolded tree's entries' reference nodes (boxes: ref_nodes)
     uint32_t quad_root = 0, quad_root_flat = 0, quad_pending = 1;
     uint32_t n_quads = 0, n_quads_flat = 0;
     float plane_bound[3] = {0, 0, 0};
@@ -105,7 +106,7 @@ struct SceneStore {
 
     ~SceneStore() {
         (void)hipSetDevice(device);
-        nodes.release(); quads.release(); quads_flat.release(); quad_boxes.release(); quad_boxes_flat.release();
+        nodes.release(); quads.release(); quads_flat.release(); quad_boxes.release(); quad_node_of_flat.release();
         tris.release(); quads_cull.release(); materials.release(); lights.release(); spheres.release(); sphere_nodes.release();
         sphere_indexes.release(); shadow_lights.release(); ref_nodes.release(); ref_indexes.release();
     }
@@ -568,7 +569,7 @@ int pack_on_host(SceneStore &S, const ctgpu_scene_desc *s) {
         }
         return true;
     };
-    struct Folded { std::vector<QuadNode> quads; std::vector<double> boxes; uint32_t root = kLeafBit | 0u, pending = 1; };
+    struct Folded { std::vector<QuadNode> quads; std::vector<double> boxes; std::vector<uint32_t> node_of; uint32_t root = kLeafBit | 0u, pending = 1; };
     // fold = true: the tree the packet walk uses; fold = false: the same structure with nothing folded
     // (two entries per node), walked a second time by rays folding is not proven for (DESIGN B2)
     auto build_quads = [&](bool fold, Folded &out) -> bool {
@@ -586,9 +587,11 @@ int pack_on_host(SceneStore &S, const ctgpu_scene_desc *s) {
             QuadNode node;
             std::memset(&node, 0, sizeof node);
             double boxes[4][6] = {};
+            uint32_t ids[4] = {0, 0, 0, 0};
             auto add = [&](uint32_t id) {
                 const ctgpu_node &e = s->nodes[id];
                 const uint32_t k = node.count++;
+                ids[k] = id;
                 for (int a = 0; a < 3; a++) { node.plane[k][a][0] = (float)e.bmin[a]; node.plane[k][a][1] = (float)e.bmax[a]; }
                 node.ref[k] = e.count ? (kLeafBit | e.first) : quad_for(id);
                 for (int a = 0; a < 3; a++) { boxes[k][a] = e.bmin[a]; boxes[k][3 + a] = e.bmax[a]; }
@@ -603,6 +606,7 @@ int pack_on_host(SceneStore &S, const ctgpu_scene_desc *s) {
                 for (int a = 0; a < 3; a++) node.plane[k][a][0] = node.plane[k][a][1] = S.plane_bound[a];
             out.quads.push_back(node);
             out.boxes.insert(out.boxes.end(), &boxes[0][0], &boxes[0][0] + 24);
+            out.node_of.insert(out.node_of.end(), ids, ids + 4);
         }
         // most entries ever waiting on the packet walk's stack: along a path, every QuadNode leaves count-1 behind
         if (!out.quads.empty()) {
@@ -619,7 +623,7 @@ int pack_on_host(SceneStore &S, const ctgpu_scene_desc *s) {
                     if (!(node.ref[k] & kLeafBit)) todo.push_back({node.ref[k], before + node.count - 1u - k});
             }
         }
-        if (out.quads.empty()) { out.quads.emplace_back(); std::memset(&out.quads[0], 0, sizeof(QuadNode)); out.boxes.assign(24, 0.0); }
+        if (out.quads.empty()) { out.quads.emplace_back(); std::memset(&out.quads[0], 0, sizeof(QuadNode)); out.boxes.assign(24, 0.0); out.node_of.assign(4, 0u); }
         return true;
     };
     Folded folded, flat;
@@ -656,8 +660,11 @@ int pack_on_host(SceneStore &S, const ctgpu_scene_desc *s) {
     HIP_TRY(hipMemcpy(S.quad_boxes.ptr, folded.boxes.data(), folded.boxes.size() * sizeof(double), hipMemcpyHostToDevice));
     HIP_TRY(S.quads_flat.resize(flat.quads.size()));
     HIP_TRY(hipMemcpy(S.quads_flat.ptr, flat.quads.data(), flat.quads.size() * sizeof(QuadNode), hipMemcpyHostToDevice));
-    HIP_TRY(S.quad_boxes_flat.resize(flat.boxes.size()));
-    HIP_TRY(hipMemcpy(S.quad_boxes_flat.ptr, flat.boxes.data(), flat.boxes.size() * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(S.quad_node_of_flat.resize(flat.node_of.size()));
+    HIP_TRY(hipMemcpy(S.quad_node_of_flat.ptr, flat.node_of.data(), flat.node_of.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    // (the unfolded tree's boxes are read from the reference's own node array)
+    HIP_TRY(S.ref_nodes.resize(M));
+    HIP_TRY(hipMemcpy(S.ref_nodes.ptr, s->nodes, (size_t)M * sizeof(ctgpu_node), hipMemcpyHostToDevice));
     S.quad_root = folded.root;
     S.quad_root_flat = flat.root;
     S.n_quads = (uint32_t)folded.quads.size();
@@ -722,7 +729,7 @@ extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
         S.quads.adopt((QuadNode *)packed.quads, packed.n_quads);
         S.quad_boxes.adopt(packed.quad_boxes, (size_t)packed.n_quads * 24);
         S.quads_flat.adopt((QuadNode *)packed.quads_flat, packed.n_quads_flat);
-        S.quad_boxes_flat.adopt(packed.quad_boxes_flat, (size_t)packed.n_quads_flat * 24);
+        S.quad_node_of_flat.adopt(packed.quad_node_of_flat, (size_t)packed.n_quads_flat * 4);
         S.tris.adopt((TriRecord *)packed.tris, N);
         S.quad_root = packed.quad_root; S.quad_root_flat = packed.quad_root_flat;
         S.n_quads = packed.n_quads; S.n_quads_flat = packed.n_quads_flat;
@@ -733,7 +740,7 @@ extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
         std::memcpy(S.root_min, packed.root_min, 24);
         std::memcpy(S.root_max, packed.root_max, 24);
         S.pack_ms = packed.device_ms;
-        if (!build_here) { S.ref_nodes.release(); S.ref_indexes.release(); }       // the caller holds these already
+        if (!build_here) S.ref_indexes.release();       // (the caller holds these; the node array stays: the unfolded tree's boxes are read from it)
     }
     if (depth > CTGPU_MAX_TREE_DEPTH) return ctgpu_fail(CTGPU_ERR_STACK, "tree depth %u exceeds %d", depth, CTGPU_MAX_TREE_DEPTH);
 
@@ -846,7 +853,7 @@ extern "C" int ctgpu_download_tree(ctgpu_ctx *ctx, ctgpu_node *nodes_out, uint32
     if (!ctx || !n_nodes) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_download_tree: null argument");
     if (!ctx->scene) return ctgpu_fail(CTGPU_ERR_NO_SCENE, "no scene uploaded");
     const SceneStore &S = *ctx->scene;
-    if (!S.ref_nodes.ptr) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_download_tree: this scene's tree came from the caller");
+    if (!S.ref_indexes.ptr) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_download_tree: this scene's tree came from the caller");
     HIP_TRY(hipSetDevice(ctx->device));
     *n_nodes = S.n_nodes;
     if (nodes_out) HIP_TRY(hipMemcpy(nodes_out, S.ref_nodes.ptr, (size_t)S.n_nodes * sizeof(ctgpu_node), hipMemcpyDeviceToHost));
@@ -868,13 +875,13 @@ extern "C" int ctgpu_scene_info(ctgpu_ctx *ctx, ctgpu_scene_info_t *out) {
     out->build_ms = S.build_ms; out->pack_ms = S.pack_ms;
     out->shared_by = (uint32_t)ctx->scene.use_count();
     out->hbm_bytes = S.nodes.count * sizeof(WideNode) + (S.quads.count + S.quads_flat.count + S.quads_cull.count) * sizeof(QuadNode) +
-                     (S.quad_boxes.count + S.quad_boxes_flat.count) * sizeof(double) + S.tris.count * sizeof(TriRecord) +
+                     S.quad_boxes.count * sizeof(double) + S.quad_node_of_flat.count * sizeof(uint32_t) + S.tris.count * sizeof(TriRecord) +
                      S.materials.count * sizeof(Material) + S.ref_nodes.count * sizeof(ctgpu_node) + S.ref_indexes.count * 4;
     return CTGPU_OK;
 }
 
 // The packed arrays themselves, for comparing the device packing with the host's (which: 0 WideNodes, 1 QuadNodes,
-// 2 their boxes, 3 unfolded QuadNodes, 4 their boxes, 5 TriRecords, 6 the QuadNodes with the cull nodes behind them).  bytes = room in out; *needed = size of the array.
+// 2 their boxes, 3 unfolded QuadNodes, 4 their entries' reference nodes, 5 TriRecords, 6 the QuadNodes with the cull nodes behind them).  bytes = room in out; *needed = size of the array.
 extern "C" int ctgpu_debug_scene_array(ctgpu_ctx *ctx, int which, void *out, uint64_t bytes, uint64_t *needed) {
     if (!ctx || !needed) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_debug_scene_array: null argument");
     if (!ctx->scene) return ctgpu_fail(CTGPU_ERR_NO_SCENE, "no scene uploaded");
@@ -886,7 +893,7 @@ extern "C" int ctgpu_debug_scene_array(ctgpu_ctx *ctx, int which, void *out, uin
         case 1: src = S.quads.ptr; size = (uint64_t)S.n_quads * sizeof(QuadNode); break;
         case 2: src = S.quad_boxes.ptr; size = (uint64_t)S.n_quads * 24 * sizeof(double); break;
         case 3: src = S.quads_flat.ptr; size = (uint64_t)S.n_quads_flat * sizeof(QuadNode); break;
-        case 4: src = S.quad_boxes_flat.ptr; size = (uint64_t)S.n_quads_flat * 24 * sizeof(double); break;
+        case 4: src = S.quad_node_of_flat.ptr; size = (uint64_t)S.n_quads_flat * 4 * sizeof(uint32_t); break;
         case 5: src = S.tris.ptr; size = (uint64_t)S.n_triangles * sizeof(TriRecord); break;
         case 6: src = S.quads_cull.ptr; size = (uint64_t)S.quads_cull.count * sizeof(QuadNode); break;
         default: return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_debug_scene_array: unknown array %d", which);
@@ -984,7 +991,7 @@ int fill_params(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, const ctgpu_partition
     const Geometry g = geometry(f);
     std::memset(&P, 0, sizeof P);
     P.nodes = ctx->scene->nodes.ptr; P.quads = ctx->scene->quads.ptr; P.quad_boxes = ctx->scene->quad_boxes.ptr; P.quad_root = ctx->scene->quad_root;
-    P.quads_flat = ctx->scene->quads_flat.ptr; P.quad_boxes_flat = ctx->scene->quad_boxes_flat.ptr; P.quad_root_flat = ctx->scene->quad_root_flat; P.tris = ctx->scene->tris.ptr; P.materials = ctx->scene->materials.ptr; P.lights = ctx->scene->lights.ptr;
+    P.quads_flat = ctx->scene->quads_flat.ptr; P.quad_node_of_flat = ctx->scene->quad_node_of_flat.ptr; P.ref_nodes = ctx->scene->ref_nodes.ptr; P.quad_root_flat = ctx->scene->quad_root_flat; P.tris = ctx->scene->tris.ptr; P.materials = ctx->scene->materials.ptr; P.lights = ctx->scene->lights.ptr;
     P.n_lights = ctx->scene->n_lights;
     if ((f->flags & CTGPU_F_SPHERES) && ctx->scene->n_spheres) {
         P.spheres = ctx->scene->spheres.ptr; P.sphere_nodes = ctx->scene->sphere_nodes.ptr; P.sphere_indexes = ctx->scene->sphere_indexes.ptr;

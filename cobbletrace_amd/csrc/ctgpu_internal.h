@@ -30,7 +30,8 @@ CTGPU_HIDDEN int ctgpu_build_bvh_resident(int device, const double *d_vertices, 
 struct ctgpu_packed_scene {
     void *wide = nullptr;              // WideNode[n_wide]
     void *quads = nullptr, *quads_flat = nullptr;          // QuadNode[n_quads], QuadNode[n_quads_flat]
-    double *quad_boxes = nullptr, *quad_boxes_flat = nullptr;   // [n][4][6]
+    double *quad_boxes = nullptr;      // [n_quads][4][6] the folded tree's entries' binary64 boxes
+    uint32_t *quad_node_of_flat = nullptr;                  // [n_quads_flat][4] the unfolded tree's entries' reference nodes (their boxes: the reference's node array)
     void *tris = nullptr;              // TriRecord[n_triangles]
     uint32_t n_wide = 0, n_quads = 0, n_quads_flat = 0;
     uint32_t quad_root = 0, quad_root_flat = 0, quad_pending = 1;

@@ -165,7 +165,7 @@ def test_pageable_framebuffers_in_the_c_heap():
         assert keeper.render_poll(wait=True)[0] and (big == want[1]).all()
         keeper.keep_framebuffer_pinned(False)
         keeper.close()
-        print("stale registration: the larger array %s the freed one's addresses" % ("covers" if reused else "does not cover"))
+        print("stale registration: the larger array", "covers" if reused else "does not cover", "the freed one's addresses")
         try:
             ctx.download_frame(frames[0], 1, np.zeros((480, 640), dtype=np.uint32).ctypes.data)
         except RuntimeError as e:

@@ -10,7 +10,7 @@ import pytest
 import cobbletrace_amd as ca
 
 pytestmark = pytest.mark.gpu
-ARRAYS = {0: "WideNodes", 1: "QuadNodes", 2: "QuadNode boxes", 3: "unfolded QuadNodes", 4: "unfolded boxes", 5: "TriRecords"}
+ARRAYS = {0: "WideNodes", 1: "QuadNodes", 2: "QuadNode boxes", 3: "unfolded QuadNodes", 4: "unfolded entries' reference nodes", 5: "TriRecords"}
 SCALARS = ("n_triangles", "n_nodes", "tree_depth", "n_wide", "n_quads", "n_quads_flat", "quad_root", "quad_root_flat",
            "quad_pending", "root_ref", "slot_of_triangle0")
 
