@@ -270,6 +270,8 @@ def _load(path, symbols, what):
             "%s not found at %s -- build it first (python -c 'import __graft_entry__ as g; g.build()')" % (what, path))
     lib = C.CDLL(path)
     for name, (restype, argtypes) in symbols.items():
+        if os.environ.get("CTGPU_OLDER_LIBRARY") and not hasattr(lib, name):
+            continue                   # (tools/ab_library.py: an earlier round's library measured beside this one)
         fn = getattr(lib, name)        # AttributeError here = the library does not export what the header declares
         fn.restype = restype
         fn.argtypes = argtypes

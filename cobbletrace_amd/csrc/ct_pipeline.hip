@@ -910,12 +910,12 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                 const uint32_t n_ids = chunk_end - chunk_next < 128u ? (uint32_t)(chunk_end - chunk_next) : 128u;
                 const uint64_t id0 = chunk_next + lane, id1 = chunk_next + 64u + lane;
                 const bool live0 = lane < n_ids && W.shadow[id0] == 0, live1 = 64u + lane < n_ids && W.shadow[id1] == 0;
-                float t0 = 0.0f, t1 = 0.0f;
-                if (live0) { const uint2 h = W.hits[id0 - chunk_light_base]; t0 = (h.y != kNoNode) ? __uint_as_float(h.x) : kFarAway; }
-                if (live1) { const uint2 h = W.hits[id1 - chunk_light_base]; t1 = (h.y != kNoNode) ? __uint_as_float(h.x) : kFarAway; }
                 bool far0 = false, far1 = false;
                 unsigned long long m_live0 = __ballot(live0), m_live1 = __ballot(live1);
-                if (W.shadow_split_gap >= 0.0f && (m_live0 | m_live1) != 0ull) {
+                if (W.shadow_split_gap >= 0.0f && (m_live0 | m_live1) != 0ull) {       // (an experiment that lost: off by default)
+                    float t0 = 0.0f, t1 = 0.0f;
+                    if (live0) { const uint2 h = W.hits[id0 - chunk_light_base]; t0 = (h.y != kNoNode) ? __uint_as_float(h.x) : kFarAway; }
+                    if (live1) { const uint2 h = W.hits[id1 - chunk_light_base]; t1 = (h.y != kNoNode) ? __uint_as_float(h.x) : kFarAway; }
                     const float inf = __builtin_inff();
                     float lo = __builtin_fminf(live0 ? t0 : inf, live1 ? t1 : inf), hi = __builtin_fmaxf(live0 ? t0 : -inf, live1 ? t1 : -inf);
                     for (int off = 32; off > 0; off >>= 1) { lo = __builtin_fminf(lo, __shfl_xor(lo, off)); hi = __builtin_fmaxf(hi, __shfl_xor(hi, off)); }
@@ -1343,10 +1343,39 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                 const uint32_t pushed_hi = (uint32_t)__builtin_amdgcn_readlane(stack_mask_hi, (int)sp);
                 const unsigned long long pushed = ((unsigned long long)pushed_lo | ((unsigned long long)pushed_hi << 32)) & tracing;
                 if (pushed == 0ull) continue;
-                bool keep = false, unsettled = false;
+                bool keep = false;
+                if (!CULL) {
+                    // (a tree without cull nodes: the pop as it has always been -- every wave-level operation here is paid per pop)
+                    if (__builtin_amdgcn_inverse_ballot_w64(pushed)) {
+                        // the deferred  tmin < ray.t : from the filter's tmin, good to M(tmin) -- and settled beforehand for an
+                        // any-hit ray the filter takes (ray.t = 1e30f while it is traced, |tmin| < 2^84: ray_filter's e_limit)
+                        bool settled;
+                        if (ANY_HIT) { keep = true; settled = rf.noi_z_e.y != __builtin_inff(); }
+                        else settled = deferred_verdict_f32(st.get_tmin(sp, lane), rf.noi_z_e.y, t, keep);
+                        if (!settled) {
+                        // too close to ray.t to trust (or a ray the filter does not take: e = inf): tmin from
+                        // the binary64 box, one step off at most -- and if that is still too close, the whole
+                        // test exactly
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                        const double *bmin = entry_box(st.parent[sp]);
+                        const d3 inv = make_d3(quick_reciprocal(d.x), quick_reciprocal(d.y), quick_reciprocal(d.z));
+                        float etmin, etmax;
+                        const bool some_nan = slab_approx_checked(RAY_O, inv, bmin, bmin + 3, etmin, etmax);
+                        const bool near_t = ordinals_near(__float_as_int(etmin), __float_as_int(t), 2u);
+                        keep = etmin < t;        // (tmax >= tmin and tmax > 0 held when the entry was pushed)
+                        if (some_nan | near_t | !direction_allows_checked_slab(d) | (LIST && !(t > 0.0f))) {
+                            (void)slab_in_sequence(RAY_O, d, bmin, bmin + 3, etmin, etmax);  // (a NaN here was seen at push time)
+                            keep = etmax >= etmin && etmin < t && etmax > 0;
+                        }
+                        }
+                    }
+                    mask = __ballot(keep);
+                    cur = (uint32_t)__builtin_amdgcn_readlane(stack_ref, (int)sp);
+                    PK_T1(2);
+                    continue;
+                }
+                bool unsettled = false;
                 if (__builtin_amdgcn_inverse_ballot_w64(pushed)) {
-                    // the deferred  tmin < ray.t : from the filter's tmin, good to M(tmin) -- and settled beforehand for an
-                    // any-hit ray the filter takes (ray.t = 1e30f while it is traced, |tmin| < 2^84: ray_filter's e_limit)
                     if (ANY_HIT) { keep = true; unsettled = rf.noi_z_e.y == __builtin_inff(); }
                     else { bool settled = deferred_verdict_f32(st.get_tmin(sp, lane), rf.noi_z_e.y, t, keep); unsettled = !settled; }
                 }
@@ -1355,8 +1384,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                 // it; a lane stays out only when "beyond ray.t" is certain and its ray is inside the gate -- all at the level
                 // of wave masks.  (The root of a leaf's cull nodes was pushed by an ordinary node: the leaf's own box, the
                 // reference's test, settled exactly like any entry's.)
-                const bool cull_entry = CULL && (cur & kOneBit) != 0u;
-                if (cull_entry) {
+                if ((cur & kOneBit) != 0u) {
                     mask = (__ballot(keep) | __ballot(unsettled) | ~(ANY_HIT ? cull_lanes : (cull_lanes & __ballot(t >= P.cull.tau)))) & pushed;
                     PK_T1(2);
                     continue;

@@ -23,13 +23,18 @@ def _oracle():
 
 
 def _context(monkeypatch, scene, **env):
+    """a context for the scene under exactly these knobs (the suite is also run with knobs in the environment: a test
+    that is ABOUT a knob owns it -- the shared walk, the default leaf thresholds unless given)"""
+    for name in ("CTGPU_PACKET", "CTGPU_BIG_LEAF", "CTGPU_BIG_LEAF_SHARE", "CTGPU_PACK"):
+        monkeypatch.delenv(name, raising=False)
+    env.setdefault("CTGPU_PACKET", 1)
     for k, v in env.items():
         monkeypatch.setenv(k, str(v))
     ctx = ca.GpuContext(0)
     ctx.upload(scene.desc)
     for k in env:
         monkeypatch.delenv(k)
-    return ctx
+    return ctx          # (the caller's environment is back when the test ends: monkeypatch)
 
 
 def _cull_arrays(ctx):

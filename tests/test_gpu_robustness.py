@@ -183,6 +183,9 @@ def test_contexts_report_and_take_their_configuration(scenes, monkeypatch):
     """ctgpu_get_config: a context made by ctgpu_create runs with what the environment said at that moment;
     ctgpu_create_with_config takes the caller's struct instead (and refuses values out of range); the knobs do what the
     header says -- here: no cull nodes with big_leaf_min = 0, the host's packing with pack_on_host -- and no pixel moves."""
+    for name in list(os.environ):                # (the suite is also run with knobs in the environment: this test owns them all)
+        if name.startswith("CTGPU_") and name not in ("CTGPU_LIBRARY", "CTGPU_RCCL_LIBRARY"):
+            monkeypatch.delenv(name)
     monkeypatch.setenv("CTGPU_CHUNK", "256")
     monkeypatch.setenv("CTGPU_ORDER", "0")
     ctx = ca.GpuContext(0)

@@ -24,6 +24,10 @@ for name in (args or ["import", "bunny", "dragon"]):
         os.environ["CTGPU_BIG_LEAF"] = str(big)
         ctx = ca.GpuContext(0)
         ctx.upload(scene.desc, build_on_device=True)
+        info = ctx.scene_info()
+        n_with_cull = len(ctx.scene_array(6)) // 128
+        print("%-7s big_leaf>=%-2d: %d triangles, %d reference nodes, %d QuadNodes, %d cull nodes, stack bound %d, %.1f MB resident" %
+              (name, big, info.n_triangles, info.n_nodes, info.n_quads, max(0, n_with_cull - info.n_quads), info.quad_pending, info.hbm_bytes / 1e6), flush=True)
         for ss in (True, False):
             frame = scene.frame(SIZE[0], SIZE[1], supersampling=ss)
             best = None
