@@ -64,7 +64,6 @@ static constexpr uint32_t kNoNode = 0xffffffffu;
 // sits in an ordinary QuadNode and does not carry it: that entry's box is the leaf's own, the reference's test.
 // Slots and node indices stay below 2^30.
 static constexpr uint32_t kOneBit = 0x40000000u;
-static constexpr uint32_t kBigLeafBit = kOneBit;      // (flag bits of a reference: indices stay below)
 static constexpr uint32_t kSlotMask = 0x3fffffffu;
 
 // ---------------------------------------------------------------- cull nodes (DESIGN appendix D)

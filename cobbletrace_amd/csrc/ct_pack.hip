@@ -522,7 +522,7 @@ int ctgpu_pack_cull_on_device(int device, const void *d_tris, uint32_t n, const 
     // cull nodes pay where the leaves they replace are where the walk's time goes; a scene with few triangles in big
     // leaves keeps its plain tree and the walk kernels that do not carry the cull code (share_percent of all triangles)
     if ((uint64_t)stats[8] * 100u < (uint64_t)share_percent * n) return CTGPU_OK;
-    if ((uint64_t)n_quads + n_cull >= (uint64_t)kBigLeafBit) return CTGPU_OK;                 // (references stay below the flag bits)
+    if ((uint64_t)n_quads + n_cull >= (uint64_t)kOneBit) return CTGPU_OK;                     // (references stay below the flag bits)
     QuadNode *longer = nullptr;
     HIP_TRY(owned.alloc(longer, (size_t)n_quads + n_cull));
     HIP_TRY(hipMemcpy(longer, quads, (size_t)n_quads * sizeof(QuadNode), hipMemcpyDeviceToDevice));

@@ -24,9 +24,12 @@
 // whose folded form could leave more than 64 entries pending, and as an independent
 // implementation the tests compare against.
 //
-// Scope: scenes without reflective materials and with at most 32 non-ambient lights.
-// Everything else takes the megakernel.  Semantics and citations: ct_device.h,
-// ct_kernels.hip header.
+// Since round 3 every frame can take this path: any number of lights, spheres as passes of their own, reflective
+// materials as bounce levels over the ray-list kinds of the packet walk (a context measures those against the
+// megakernel and keeps the faster).  Round 4: in scenes whose triangles sit in many-triangle leaves the tree
+// supersampled frames walk carries CULL NODES in place of those leaves (ct_device.h, DESIGN appendix D;
+// ct_walk_packet<.., CULL>), and shadow packets are formed from windows of 128 ray ids listed in LDS.
+// Semantics and citations: ct_device.h, ct_kernels.hip header.
 #include <type_traits>
 #include "ct_params.h"
 #include "ct_raygen.h"
