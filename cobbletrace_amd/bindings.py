@@ -284,7 +284,7 @@ def gpu_library_path():
 
 
 def host_library_path():
-    return os.path.join(repo_root(), "cobbletrace_amd", "host", "libcthost.so")
+    return os.environ.get("CTHOST_LIBRARY", os.path.join(repo_root(), "cobbletrace_amd", "host", "libcthost.so"))
 
 
 def gpu_library():

@@ -153,7 +153,7 @@ bool import_ply_body_parallel(const TextCursor &tc, const scene_object_t &record
         }
     });
     std::vector<size_t> starts;
-    starts.reserve(n_records + 1);
+    starts.reserve(std::min(n_records, size - body) + 1);     // (a record is at least one byte: the header's counts do not size memory)
     for (const std::vector<size_t> &part : found) starts.insert(starts.end(), part.begin(), part.end());
     if (starts.size() < n_records) return false;          // the file ends early: the serial code's business
     auto line_end = [&](size_t from) {
@@ -184,10 +184,10 @@ bool import_ply_body_parallel(const TextCursor &tc, const scene_object_t &record
         TextCursor line(tc, 0);
         for (size_t i = lo; i < hi && clean.load(std::memory_order_relaxed); i++) {
             line.seek(starts[n_vertices + i]);
-            const int corners = (int)line.number();
+            const int corners = TextCursor::to_int(line.number());
             double f[3];
             line.vec3_bare(f);
-            const int ia = (int)f[0], ib = (int)f[1], ic = (int)f[2];
+            const int ia = TextCursor::to_int(f[0]), ib = TextCursor::to_int(f[1]), ic = TextCursor::to_int(f[2]);
             if (line.position() > line_end(starts[n_vertices + i]) || corners != 3 || ia < 0 || ib < 0 || ic < 0 ||
                 (uint32_t)ia >= n_vertices || (uint32_t)ib >= n_vertices || (uint32_t)ic >= n_vertices) {
                 clean = false;
@@ -222,8 +222,8 @@ void import_ply(const scene_object_t &record, scene_t *scene) {
         std::string word = tc.bare_word();
         if (word == "element") {
             word = tc.bare_word();
-            if (word == "vertex") n_vertices = (uint32_t)tc.number();
-            else if (word == "face") n_faces = (uint32_t)tc.number();
+            if (word == "vertex") n_vertices = TextCursor::to_u32(tc.number());
+            else if (word == "face") n_faces = TextCursor::to_u32(tc.number());
         } else if (word == "end_header") {
             tc.skip_line();
             break;
@@ -233,25 +233,30 @@ void import_ply(const scene_object_t &record, scene_t *scene) {
     const Placement place(record.import.position, record.import.rotation, record.import.scale);
     if (import_ply_body_parallel(tc, record, place, scene, n_vertices, n_faces)) return;
 
-    std::vector<v3_t> vertices(n_vertices);
+    // (the reference mallocs totalVertices entries and fills what the file holds; here the array is sized by what the file
+    //  CAN hold -- a record is at least one byte -- so that a header's count does not size memory, and a face that names a
+    //  vertex the file never gave reads zeros, where the reference reads its uninitialised block)
+    const size_t bytes_left = tc.size() > tc.position() ? tc.size() - tc.position() : 0;
+    std::vector<v3_t> vertices(std::min<size_t>(n_vertices, bytes_left + 1));
+    const auto vertex_at = [&](int i) { return (size_t)i < vertices.size() ? vertices[i] : v3_t{0.0, 0.0, 0.0}; };
     for (uint32_t i = 0; i < n_vertices && !tc.at_end(); i++) {
         double v[3];
         tc.vec3_bare(v);
-        vertices[i] = v3_t{v[0], v[1], v[2]};
+        if (i < vertices.size()) vertices[i] = v3_t{v[0], v[1], v[2]};
         tc.skip_line();
     }
 
     for (uint32_t i = 0; i < n_faces && !tc.at_end(); i++) {
-        const int corners = (int)tc.number();
+        const int corners = TextCursor::to_int(tc.number());
         if (corners != 3) tc.fatal("only triangular faces are supported");
         double f[3];
         tc.vec3_bare(f);
         tc.skip_line();
-        const int ia = (int)f[0], ib = (int)f[1], ic = (int)f[2];
+        const int ia = TextCursor::to_int(f[0]), ib = TextCursor::to_int(f[1]), ic = TextCursor::to_int(f[2]);
         if (ia < 0 || ib < 0 || ic < 0 || (uint32_t)ia >= n_vertices || (uint32_t)ib >= n_vertices ||
             (uint32_t)ic >= n_vertices)
             tc.fatal("face index out of range");
-        emit_triangle(scene, record, place, vertices[ia], vertices[ib], vertices[ic], tc);
+        emit_triangle(scene, record, place, vertex_at(ia), vertex_at(ib), vertex_at(ic), tc);
     }
 }
 
@@ -279,11 +284,13 @@ void import_obj(const scene_object_t &record, scene_t *scene) {
     if (faces.empty()) return;
 
     const Placement place(record.import.position, record.import.rotation, record.import.scale);
+    // (the range is checked on the number as read: converting a value outside int's range is undefined, and a NaN fails too)
+    const auto index_of = [&](double one_based) -> size_t {
+        if (!(one_based >= 1.0 && one_based < (double)vertices.size() + 1.0)) tc.fatal("face index out of range");
+        return (size_t)one_based - 1;
+    };
     for (const v3_t &f : faces) {
-        const int ia = (int)f.x - 1, ib = (int)f.y - 1, ic = (int)f.z - 1;
-        if (ia < 0 || ib < 0 || ic < 0 || (size_t)ia >= vertices.size() || (size_t)ib >= vertices.size() ||
-            (size_t)ic >= vertices.size())
-            tc.fatal("face index out of range");
+        const size_t ia = index_of(f.x), ib = index_of(f.y), ic = index_of(f.z);
         emit_triangle(scene, record, place, vertices[ia], vertices[ib], vertices[ic], tc);
     }
 }

@@ -72,9 +72,13 @@ void read_objects(TextCursor &tc, scene_t *scene) {
                 obj.sphere.radius = tc.number();
             } else if (key == "color") {
                 const v3_t c = read_v3(tc);
-                obj.material.color = ct::pack_rgb((uint8_t)c.x, (uint8_t)c.y, (uint8_t)c.z);
+                // double -> uint8_t at RgbToColor's parameters (scenefile.cpp:74, color.h:78): the low byte of the int
+                // conversion, which is what the reference's binary makes of scene_file_1.json's [0, 100, 2000] (208) and
+                // is defined for every value here
+                const auto channel = [](double v) { return (uint8_t)(TextCursor::to_int(v) & 0xff); };
+                obj.material.color = ct::pack_rgb(channel(c.x), channel(c.y), channel(c.z));
             } else if (key == "specular") {
-                obj.material.specular = (int)tc.number();
+                obj.material.specular = TextCursor::to_int(tc.number());
             } else if (key == "reflection") {
                 obj.material.reflection = tc.number();
             } else if (key == "p1") {
@@ -157,7 +161,7 @@ void read_settings(TextCursor &tc, scene_t *scene) {
     tc.expect('{');
     while (!tc.at_end()) {
         const std::string key = read_key(tc);
-        if (key == "numberOfThreads") scene->settings.numberOfThreads = (int)tc.number();
+        if (key == "numberOfThreads") scene->settings.numberOfThreads = TextCursor::to_int(tc.number());
         else if (key == "subsampling") scene->settings.subsampling = tc.boolean();
         else if (key == "wireframe") scene->settings.wireframe = tc.boolean();
         else if (key == "supersampling") scene->settings.supersampling = tc.boolean();

@@ -121,7 +121,7 @@ float TextCursor::number() {
         if (c >= '0' && c <= '9') {
             const int digit = c - '0';
             if (in_exponent) {
-                exponent = exponent * 10 + digit;
+                if (exponent < 100000000) exponent = exponent * 10 + digit;   // (beyond: 10^e is inf or 0 whatever follows; no int overflow)
             } else if (in_fraction) {
                 float term = (float)digit;
                 term = term / place;

@@ -50,6 +50,13 @@ public:
     void vec3_bracketed(double out[3]);  // [a, b, c]
     void vec3_bare(double out[3]);       // a b c
 
+    // number -> integer as the reference's assignments convert (`int n = GetNumber(&fb)`, objectLoader.cpp:177;
+    // `uint32_t totalVertices = GetNumber(&fb)`, :159), defined for every value: in range it is the truncation; outside
+    // -- undefined in the language -- what the reference's x86-64 binary does (cvttss2si: INT_MIN; the low half of
+    // the 64-bit conversion).  Hostile files reach these with 1e30 and NaN.
+    static int to_int(double v) { return (v > -2147483649.0 && v < 2147483648.0) ? (int)v : (-2147483647 - 1); }
+    static unsigned to_u32(double v) { return (v > -9223372036854775808.0 && v < 9223372036854775808.0) ? (unsigned)(long long)v : 0u; }
+
     [[noreturn]] void fatal(const std::string &what) const;
 
 private:

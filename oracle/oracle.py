@@ -25,7 +25,7 @@ _lib = None
 def library():
     global _lib
     if _lib is None:
-        path = os.path.join(_HERE, "libctoracle.so")
+        path = os.environ.get("CTORACLE_LIBRARY", os.path.join(_HERE, "libctoracle.so"))     # (tools/sanitize_host.sh: the sanitizer build)
         if not os.path.exists(path):
             raise RuntimeError("oracle not built: run `make -C oracle`")
         lib = C.CDLL(path)

@@ -194,6 +194,41 @@ def test_malformed_input_aborts_like_the_reference_asserts(tmp_path):
         ca.HostScene(str(tmp_path / "missing.json"))
 
 
+def test_hostile_numbers_have_defined_outcomes(tmp_path):
+    """Values the conversions of the reference leave undefined (a colour channel of 2000 -- scene_file_1.json has one --,
+    a face index of 1e30, a header that promises four billion vertices) take the outcome of the reference's x86-64 binary
+    or a refusal, and never size memory; tools/sanitize_host.sh runs this file and tools/fuzz_loader.py under ASan + UBSan."""
+    (tmp_path / "models").mkdir()
+    imp = lambda name, fmt: {"type": "import", "filename": name, "format": fmt, "position": [0, 0, 0], "rotation": [0, 0, 0],
+                             "scale": [1, 1, 1], "color": [0, 100, 2000], "specular": "1e30", "reflection": "1e99999999999999999999"}
+    def write_raw(tmp_path, objects):                                      # (literals json.dumps would not write)
+        path = write_scene(tmp_path, objects)
+        raw = open(path).read().replace('"1e30"', "1e30").replace('"1e99999999999999999999"', "1e99999999999999999999")
+        open(path, "w").write(raw)
+        return path
+    (tmp_path / "models" / "a.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n")
+    scene = ca.HostScene(write_raw(tmp_path, [imp("models/a.obj", "blender")]))
+    assert scene.desc.n_triangles == 1
+    assert scene.desc.materials[0].color == ((2000 & 0xff) << 16) | (100 << 8) and scene.desc.materials[0].specular == -2**31
+    assert scene.desc.materials[0].reflection == float("inf")             # the exponent's digits do not overflow an int
+    for face in ("f 1 2 1e30", "f 0 1 2", "f 1 2 4", "f -1e30 1 2", "f 1 2 1e400"):
+        (tmp_path / "models" / "b.obj").write_text("v 0 0 0\nv 1 0 0\nv 0 1 0\n%s\n" % face)
+        path = write_raw(tmp_path, [imp("models/b.obj", "blender")])
+        proc = _run_child("import cobbletrace_amd as ca; ca.HostScene(%r)" % path)
+        assert proc.returncode < 0 and "face index out of range" in proc.stderr, face
+    header = "ply\nformat ascii 1.0\nelement vertex %s\nproperty float x\nelement face %s\nend_header\n"
+    body = "0 0 0\n1 0 0\n0 1 0\n3 0 1 2\n"
+    (tmp_path / "models" / "c.ply").write_text(header % ("4000000000", "1") + body)      # the face line is read as a vertex: no face left
+    scene = ca.HostScene(write_raw(tmp_path, [imp("models/c.ply", "ply")]))
+    assert scene.desc.n_triangles == 0
+    (tmp_path / "models" / "d.ply").write_text(header % ("3", "4000000000") + body)      # faces until the file ends, then the
+    proc = _run_child("import cobbletrace_amd as ca; ca.HostScene(%r)" % write_raw(tmp_path, [imp("models/d.ply", "ply")]))
+    assert proc.returncode < 0 and "only triangular faces" in proc.stderr               # reference's assert(n == 3) on what follows
+    (tmp_path / "models" / "e.ply").write_text(header % ("3", "1") + "0 0 0\n1 0 0\n0 1 0\n3 0 1 1e30\n")
+    proc = _run_child("import cobbletrace_amd as ca; ca.HostScene(%r)" % write_raw(tmp_path, [imp("models/e.ply", "ply")]))
+    assert proc.returncode < 0 and "face index out of range" in proc.stderr
+
+
 def test_shipped_scenes_load(scenes):
     for name, tris in (("cube", 37), ("import", 1712), ("bunny", 69451)):
         s = scenes(name)
