@@ -20,7 +20,9 @@ def native_build():
     import __graft_entry__ as entry
     needed = [os.path.join(ROOT, "cobbletrace_amd", "csrc", "libctgpu.so"),
               os.path.join(ROOT, "cobbletrace_amd", "host", "libcthost.so"),
-              os.path.join(ROOT, "oracle", "libctoracle.so")]
+              os.path.join(ROOT, "oracle", "libctoracle.so"),
+              os.path.join(ROOT, "cobbletrace_amd", "host", "cobbletrace_headless"),
+              os.path.join(ROOT, "cobbletrace_amd", "host", "cobbletrace_viewer_double")]
     if not all(os.path.exists(p) for p in needed):
         entry.build()
     else:

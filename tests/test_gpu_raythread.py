@@ -97,6 +97,47 @@ def test_headless_application(assets, tmp_path):
     assert subprocess.run([exe], capture_output=True).returncode == 0
 
 
+def test_windowed_viewer_against_the_sdl_double(assets, tmp_path):
+    """host/main_viewer.cpp (the reference's application shell, cobbletrace.cpp:26-125) and the SDL branch of host/blit.cpp
+    (draw2d.h:22-64), built against tests/sdl_double -- a scripted stand-in for the SDL2 calls they make; the image has no
+    SDL2 -- and run: key-downs from the script reach RayThread through the event queue, frames finish asynchronously,
+    Blit wraps the bitmap in a surface with the hand-off's masks and presents it.  The last frame the double was
+    SHOWN is the frame RayThread renders synchronously for the same keys."""
+    import subprocess
+    root = os.path.dirname(assets)
+    exe = os.path.join(root, "cobbletrace_amd", "host", "cobbletrace_viewer_double")
+    scene_path = tmp_path / "import_single_sample.json"        # (supersampled frames draw new jitter every frame: the number of
+    text = open(os.path.join(assets, "scene_import.json")).read()  # frames an asynchronous loop renders would show in the pixels)
+    assert '"supersampling": true' in text
+    scene_path.write_text(text.replace('"supersampling": true', '"supersampling": false'))
+    out = tmp_path / "shown.ppm"
+    env = dict(os.environ, CT_SDL_DOUBLE_SCRIPT="30 w w d 5 a 60 quit", CT_SDL_DOUBLE_OUT=str(out))
+    proc = subprocess.run([exe, str(scene_path)], cwd=assets, env=env, capture_output=True, text=True, timeout=180)
+    assert proc.returncode == 0, proc.stderr
+    counts = [int(t) for t in proc.stderr.split("sdl double:")[-1].replace(",", " ").split() if t.isdigit()]
+    polls, keys, presents, distinct = counts
+    assert keys == 4 and presents >= 95 and 3 <= distinct <= 6, proc.stderr          # black, first frame, >= 1 after the keys
+    data = out.read_bytes()
+    header = b"P6\n640 640\n255\n"
+    assert data.startswith(header)
+    rgb = np.frombuffer(data[len(header):], dtype=np.uint8).reshape(640, 640, 3).astype(np.uint32)
+    shown = rgb[..., 0] | (rgb[..., 1] << 8) | (rgb[..., 2] << 16)
+    host = ca.host_library()
+    host.cth_raythread_reset()
+    host.cth_raythread_options(ca.RNG_HASH, 0, 0, 1)
+    scene = ca.HostScene(os.path.join(assets, "scene_import.json"))
+    scene.set_settings(supersampling=0)
+    want, calls = _frames(scene, 640, 640, b"wwda")
+    host.cth_raythread_reset()
+    assert calls == 5 and (shown == want).all() and (want != 0).any()
+    # no scene file -> usage and exit 0, wireframe scenes are refused (cobbletrace.cpp:20-24, 108-114)
+    assert subprocess.run([exe], capture_output=True).returncode == 0
+    wire = tmp_path / "wire.json"
+    wire.write_text(text.replace('"wireframe": false', '"wireframe": true'))
+    proc = subprocess.run([exe, str(wire)], cwd=assets, capture_output=True, text=True, timeout=60)
+    assert proc.returncode == 1 and "wireframe" in proc.stderr
+
+
 def test_raythread_over_several_devices(assets):
     """RayThread splitting every frame over 3 contexts (device ordinals wrap around the GPUs present,
     so on a one-GPU box they share it): interleaved row tiles, peer-to-peer gather, assembly -- the

@@ -291,6 +291,15 @@ def test_parallel_ply_import_equals_the_serial_reader(shape, tmp_path, monkeypat
     serial.close()
 
 
+def test_viewer_builds_against_the_sdl_double():
+    """The windowed viewer and Blit's SDL branch compile and link against tests/sdl_double (the image has no SDL2); the GPU
+    suite runs the loop (tests/test_gpu_raythread.py).  Here: usage without a scene file, exit 0 like Help() (cobbletrace.cpp:20-24)."""
+    exe = os.path.join(ROOT, "cobbletrace_amd", "host", "cobbletrace_viewer_double")
+    assert os.path.exists(exe), "make -C cobbletrace_amd/host"
+    proc = subprocess.run([exe], capture_output=True, text=True, timeout=60)
+    assert proc.returncode == 0 and "provide a scene file" in proc.stderr
+
+
 def test_blit_is_a_frame_sink_without_sdl(tmp_path, monkeypatch):
     """Blit (draw2d.h:22-64) without SDL2 / without a renderer: counts frames and, with CT_BLIT_PPM, leaves the bitmap
     as a PPM -- bytes R, G, B of every 0x00BBGGRR word, row-major, top-down (what the SDL surface masks select)."""
