@@ -748,8 +748,48 @@ extern "C" __attribute__((visibility("default"))) int ctgpu_debug_packet_trace(u
 // ORDERED: chunks the frame before found heavy come first, in parts where that frame's packets were few (ct_params.h,
 // OrderParams), then every other chunk in the usual order; each packet adds its fetches to its chunk's cost word.
 // CULL: the tree holds cull nodes (ct_device.h; a scene without them runs the instantiation that does not carry the code).
+// The launch's arguments, read again (the frame's shadow walk).  A persistent kernel keeps its arguments in scalar
+// registers for the whole launch, ~150 of them alive across the walk, and the compiler parks what does not fit in lanes of
+// spare vector registers: 140 v_readlane per packet in the shadow ray's set-up alone, on the vector pipe.  The kernel
+// argument segment sits in the scalar cache, so each phase of a packet takes a fresh copy of what IT needs through s_load
+// (the empty asm makes the segment's address a new value: nothing can be carried over from the copy before).  Measured
+// (profiles/r04_args_again.log, both builds on one box, rocprofv3 counters): shadow walk 809.1 M -> 776.9 M vector
+// instructions per launch, 22.6 M -> 28.0 M scalar loads, 1.543 -> 1.523 ms.  The primary walk has little set-up to
+// save (-0.5 % vector instructions) and pays for the loads (+56 % scalar loads, +2 % time, +7 % single-sample): it keeps
+// its arguments as they come.
+#ifndef CT_ARGS_AGAIN
+#define CT_ARGS_AGAIN 1
+#endif
+typedef const __attribute__((address_space(4))) unsigned char *KernargBytes;
+template <typename T>
+__device__ __forceinline__ void kernarg_again(T &out, uint32_t byte_offset) {
+    KernargBytes base = (KernargBytes)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(base));
+    // (word by word through the constant address space, so that every read is a scalar load whatever the optimiser
+    //  makes of a copy; the words nobody reads are never loaded)
+    static_assert(sizeof(T) % 4 == 0 && alignof(T) >= 4, "kernel argument structs are made of words");
+    const __attribute__((address_space(4))) uint32_t *src = (const __attribute__((address_space(4))) uint32_t *)(base + byte_offset);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(&out);
+#pragma unroll
+    for (uint32_t i = 0; i < sizeof(T) / 4; i++) dst[i] = src[i];
+}
+// (arguments lie in the segment in order, each at its natural alignment)
+constexpr uint32_t kWalkArgsW = (uint32_t)((sizeof(FrameParams) + alignof(PipelineParams) - 1) / alignof(PipelineParams) * alignof(PipelineParams));
+
 template <int KIND, bool SS, bool HANDOVER = false, bool ORDERED = false, bool CULL = false>
-__global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const FrameParams P, const PipelineParams W) {
+__global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const FrameParams P_launch, const PipelineParams W_launch) {
+    FrameParams P = P_launch;
+    PipelineParams W = W_launch;
+    constexpr bool AGAIN = CT_ARGS_AGAIN != 0 && KIND == 1;
+#ifndef CT_ARGS_POINTS
+#define CT_ARGS_POINTS 15
+#endif
+#define ARGS_AGAIN_AT(bit) do { if (AGAIN && ((CT_ARGS_POINTS >> (bit)) & 1)) { kernarg_again(P, 0u); kernarg_again(W, kWalkArgsW); } } while (0)
+#define ARGS_AGAIN() do { if (AGAIN) { kernarg_again(P, 0u); kernarg_again(W, kWalkArgsW); } } while (0)
+    ARGS_AGAIN();
+    // (the layout assumption, checked once per wave on first and last members: a frame of nothing beats a wild pointer)
+    if (AGAIN) if (P.nodes != P_launch.nodes || P.rng_seed != P_launch.rng_seed || W.coords != W_launch.coords || W.n_samples != W_launch.n_samples ||
+        W.order[1].totals_out != W_launch.order[1].totals_out || P.counters != P_launch.counters) return;
     const uint32_t q_chunk = (KIND == 1) ? W.chunk_shadow : W.chunk;      // ray ids per queue atomic
     constexpr bool LIST = KIND >= 2;                 // rays come from W.ray_list instead of the frame's samples
     if (LIST && W.list_gate && *W.list_gate == 0u) return;      // (a bounce level nobody reached)
@@ -824,6 +864,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
         //  launch from it -- the root box relative to the eye, in binary64, i.e. in vector registers -- it keeps in
         //  scratch and reloads per packet, 0.3 GB of traffic per launch; six additions per packet are cheaper)
         if (KIND == 0) asm volatile("" : "+s"(eye.x), "+s"(eye.y), "+s"(eye.z));
+        ARGS_AGAIN_AT(0);
         // ---------------- fetch a packet: every lane gets a ray (or stays empty at the end)
         has_ray = false;
         root_pass = false;
@@ -990,6 +1031,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
         const uint32_t trace_rays = (uint32_t)__popcll(__ballot(has_ray));
 #endif
         // phase 2 (once per packet, all its lanes together): the rays themselves
+        ARGS_AGAIN_AT(1);
         if (has_ray) {
             float t_start = kNoHit;
             if (LIST) {
@@ -1033,6 +1075,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
         // inside the frame's gate; a caller's closest-hit ray only when it starts at 1e30f like a frame's ray (with any
         // other start a "hit" that does not lower ray.t still records its triangle, bvh.cpp:212).  A closest-hit ray
         // skips only while its ray.t is at least tau (looked at where a skip is decided).
+        ARGS_AGAIN_AT(2);
         unsigned long long cull_lanes = 0ull;
         if (CULL && P.cull.d_lim > 0.0f) {
             const double d_lim = (double)P.cull.d_lim, o_lim = (double)P.cull.o_lim;
@@ -1435,6 +1478,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
         }   // passes
 
         // ---------------- retire the packet
+        ARGS_AGAIN_AT(3);
 #ifdef CT_PACKET_TRACE
         if (lane == 0 && !LIST) {
             const unsigned int at = atomicAdd(&ct_packet_trace_n, 1u);
@@ -1497,6 +1541,8 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
     }
 }
 #undef RAY_O
+#undef ARGS_AGAIN
+#undef ARGS_AGAIN_AT
 
 // ------------------------------------------------------------------------------------
 // ct_shade: lighting of every sample of a pixel in order, running blend, pixel store.

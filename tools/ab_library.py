@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Two builds of libctgpu.so beside each other on the same box: per-walk times of the headline frame, alternating.
-     python tools/ab_library.py variants/libctgpu_r3.so [scene] [reps]
+     python tools/ab_library.py variants/libctgpu_r3.so [more.so ...] [scene] [reps]
 (the other library may be an earlier round's: symbols it lacks are skipped, CTGPU_OLDER_LIBRARY)"""
 import os, subprocess, sys
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -25,11 +25,12 @@ if os.environ.get("AB_CHILD") == "1":
         print("RESULT ss=%d frame %.3f primary %.3f shadow %.3f gate %.3f shade %.3f" % (ss, sum(ms), ms[1], ms[3], ms[2], ms[4]))
     ctx.close()
     sys.exit(0)
-other = os.path.abspath(sys.argv[1])
-name = sys.argv[2] if len(sys.argv) > 2 else "dragon"
-reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+others = [os.path.abspath(a) for a in sys.argv[1:] if a.endswith(".so")]
+rest = [a for a in sys.argv[1:] if not a.endswith(".so")]
+name = rest[0] if rest else "dragon"
+reps = int(rest[1]) if len(rest) > 1 else 3
 for r in range(reps):
-    for label, lib in (("other  ", other), ("current", None)):
+    for label, lib in [(os.path.basename(o)[:-3].replace("libctgpu_", "").ljust(10), o) for o in others] + [("current".ljust(10), None)]:
         env = dict(os.environ, AB_CHILD="1")
         if lib: env.update(CTGPU_LIBRARY=lib, CTGPU_OLDER_LIBRARY="1")
         out = subprocess.run([sys.executable, os.path.abspath(__file__), name], env=env, capture_output=True, text=True)
