@@ -773,6 +773,21 @@ __device__ __forceinline__ void kernarg_again(T &out, uint32_t byte_offset) {
 #pragma unroll
     for (uint32_t i = 0; i < sizeof(T) / 4; i++) dst[i] = src[i];
 }
+// A pointer that arrives as two words is a generic pointer to the compiler (flat_load, and a wait on two counters per
+// use); the pointers of a launch all point into HBM, and saying so gives the global loads back.
+template <typename T>
+__device__ __forceinline__ void in_hbm(T *&p) { p = (T *)(__attribute__((address_space(1))) T *)(unsigned long long)p; }
+__device__ __forceinline__ void args_point_into_hbm(FrameParams &P, PipelineParams &W) {
+    in_hbm(P.nodes); in_hbm(P.quads); in_hbm(P.quad_boxes); in_hbm(P.quads_flat); in_hbm(P.quad_node_of_flat); in_hbm(P.ref_nodes);
+    in_hbm(P.tris); in_hbm(P.materials); in_hbm(P.lights); in_hbm(P.spheres); in_hbm(P.sphere_nodes); in_hbm(P.sphere_indexes);
+    in_hbm(P.rand_table); in_hbm(P.row_ordinal); in_hbm(P.out); in_hbm(P.counters); in_hbm(P.overflow);
+    in_hbm(W.coords); in_hbm(W.hits); in_hbm(W.shadow); in_hbm(W.queue); in_hbm(W.shadow_lights); in_hbm(W.walk_work);
+    in_hbm(W.handed); in_hbm(W.handed_ids[0]); in_hbm(W.handed_ids[1]); in_hbm(W.ray_list); in_hbm(W.ray_hits); in_hbm(W.ray_live);
+    in_hbm(W.list_gate);
+    for (int k = 0; k < 2; k++) {
+        in_hbm(W.order[k].cost_out); in_hbm(W.order[k].listed); in_hbm(W.order[k].list); in_hbm(W.order[k].count); in_hbm(W.order[k].totals_out);
+    }
+}
 // (arguments lie in the segment in order, each at its natural alignment)
 constexpr uint32_t kWalkArgsW = (uint32_t)((sizeof(FrameParams) + alignof(PipelineParams) - 1) / alignof(PipelineParams) * alignof(PipelineParams));
 
@@ -784,8 +799,8 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
 #ifndef CT_ARGS_POINTS
 #define CT_ARGS_POINTS 15
 #endif
-#define ARGS_AGAIN_AT(bit) do { if (AGAIN && ((CT_ARGS_POINTS >> (bit)) & 1)) { kernarg_again(P, 0u); kernarg_again(W, kWalkArgsW); } } while (0)
-#define ARGS_AGAIN() do { if (AGAIN) { kernarg_again(P, 0u); kernarg_again(W, kWalkArgsW); } } while (0)
+#define ARGS_AGAIN_AT(bit) do { if (AGAIN && ((CT_ARGS_POINTS >> (bit)) & 1)) { kernarg_again(P, 0u); kernarg_again(W, kWalkArgsW); args_point_into_hbm(P, W); } } while (0)
+#define ARGS_AGAIN() do { if (AGAIN) { kernarg_again(P, 0u); kernarg_again(W, kWalkArgsW); args_point_into_hbm(P, W); } } while (0)
     ARGS_AGAIN();
     // (the layout assumption, checked once per wave on first and last members: a frame of nothing beats a wild pointer)
     if (AGAIN) if (P.nodes != P_launch.nodes || P.rng_seed != P_launch.rng_seed || W.coords != W_launch.coords || W.n_samples != W_launch.n_samples ||
@@ -1045,7 +1060,9 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                 // P = origin + tclosest * dir (raythread.cpp:360); tclosest = ray.t when a triangle was
                 // recorded, else 2^32
                 const uint64_t sample = ray_id - light_base;
-                (void)sample_position<SS>(P, W, sample, px, py);
+                // (a shadow ray's sample was hit, so it is a pixel of the frame: with a grid buffer its position is just read)
+                if (SS) { const float2 c = W.coords[sample]; px = c.x; py = c.y; }
+                else (void)sample_position<SS>(P, W, sample, px, py);
                 const uint2 h = W.hits[sample];
                 const float tclosest = (h.y != kNoNode) ? __uint_as_float(h.x) : kFarAway;
                 shadow_o = eye + scale((double)tclosest, primary_direction(P, px, py));
@@ -1366,8 +1383,13 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                             stack_ref = level ? (int)next_ref : stack_ref;
                             stack_mask_lo = level ? (int)(uint32_t)next_mask : stack_mask_lo;
                             stack_mask_hi = level ? (int)(uint32_t)(next_mask >> 32) : stack_mask_hi;
-                            st.parent[sp] = node_id * 4u + next_entry;                // every lane, same word: read on the exact path only
-                            if (!ANY_HIT) st.put_tmin(sp, lane, next_tmin);      // (an any-hit ray's tmin < ray.t holds for as long as it is traced)
+                            // (an any-hit ray's tmin < ray.t holds for as long as it is traced -- ray.t is the 1e30f it started
+                            //  with until the ray leaves -- whichever level decided it when the entry was pushed: nothing waits
+                            //  with the entry, neither a tmin nor the way to its binary64 box)
+                            if (!ANY_HIT) {
+                                st.parent[sp] = node_id * 4u + next_entry;            // every lane, same word: read on the exact path only
+                                st.put_tmin(sp, lane, next_tmin);
+                            }
                             sp += 1;
                         }
                         next_ref = sq.ref(k);
@@ -1390,14 +1412,20 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                 const unsigned long long pushed = ((unsigned long long)pushed_lo | ((unsigned long long)pushed_hi << 32)) & tracing;
                 if (pushed == 0ull) continue;
                 bool keep = false;
+                if (ANY_HIT && !CULL) {
+                    // an any-hit ray's deferred  tmin < ray.t  was settled when the entry was pushed (ray.t is 1e30f for as long
+                    // as the ray is traced; the filter's rays have |tmin| < 2^84 -- ray_filter's e_limit --, the others were
+                    // judged by the exact levels against that same 1e30f): whoever was pushed and is still traced goes in
+                    mask = pushed;
+                    cur = (uint32_t)__builtin_amdgcn_readlane(stack_ref, (int)sp);
+                    PK_T1(2);
+                    continue;
+                }
                 if (!CULL) {
                     // (a tree without cull nodes: the pop as it has always been -- every wave-level operation here is paid per pop)
                     if (__builtin_amdgcn_inverse_ballot_w64(pushed)) {
-                        // the deferred  tmin < ray.t : from the filter's tmin, good to M(tmin) -- and settled beforehand for an
-                        // any-hit ray the filter takes (ray.t = 1e30f while it is traced, |tmin| < 2^84: ray_filter's e_limit)
-                        bool settled;
-                        if (ANY_HIT) { keep = true; settled = rf.noi_z_e.y != __builtin_inff(); }
-                        else settled = deferred_verdict_f32(st.get_tmin(sp, lane), rf.noi_z_e.y, t, keep);
+                        // the deferred  tmin < ray.t : from the filter's tmin, good to M(tmin)
+                        const bool settled = deferred_verdict_f32(st.get_tmin(sp, lane), rf.noi_z_e.y, t, keep);
                         if (!settled) {
                         // too close to ray.t to trust (or a ray the filter does not take: e = inf): tmin from
                         // the binary64 box, one step off at most -- and if that is still too close, the whole
@@ -1422,7 +1450,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                 }
                 bool unsettled = false;
                 if (__builtin_amdgcn_inverse_ballot_w64(pushed)) {
-                    if (ANY_HIT) { keep = true; unsettled = rf.noi_z_e.y == __builtin_inff(); }
+                    if (ANY_HIT) keep = true;
                     else { bool settled = deferred_verdict_f32(st.get_tmin(sp, lane), rf.noi_z_e.y, t, keep); unsettled = !settled; }
                 }
                 cur = (uint32_t)__builtin_amdgcn_readlane(stack_ref, (int)sp);
@@ -1435,7 +1463,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                     PK_T1(2);
                     continue;
                 }
-                if (__ballot(unsettled) != 0ull) {
+                if (!ANY_HIT && __ballot(unsettled) != 0ull) {
                     if (unsettled) {
                         // too close to ray.t to trust (or a ray the filter does not take: e = inf): tmin from
                         // the binary64 box, one step off at most -- and if that is still too close, the whole
