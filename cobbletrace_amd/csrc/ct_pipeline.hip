@@ -1145,7 +1145,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
         // (read back with v_readlane, the level as lane select): no LDS round trip on a pop
         int stack_ref = 0, stack_mask_lo = 0, stack_mask_hi = 0;
 #ifdef CT_SKIP_WALK                        // diagnostic build: time ray set-up and retirement alone
-        if (KIND == CT_SKIP_WALK) mask = 0ull;
+        if (KIND == CT_SKIP_WALK) asm volatile("s_mov_b64 %0, 0" : "=s"(mask));      // (opaque: the ray set-up must not be optimised away with the walk)
 #endif
 
         // ---------------- the shared walk
