@@ -55,7 +55,7 @@ def parse_args(argv=None):
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--supersampling", type=int, default=-1, help="-1: scene file's setting")
-    ap.add_argument("--inflight", type=int, default=0, help="frames in flight (1 = strictly serial frames; default 3, 4 from 8 ranks on)")
+    ap.add_argument("--inflight", type=int, default=0, help="frames in flight (1 = strictly serial frames; default 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=60.0, help="budget of the CPU baseline leg (it drops variants to fit)")
     ap.add_argument("--collective", default="native", choices=["native", "torch", "host"],
@@ -305,8 +305,9 @@ def main():
     # stream of frames runs.  Each slot owns a context (scene copy + scratch arrays), a stream, a communicator,
     # a device framebuffer and a pinned host framebuffer.
     # (measured on one GPU with rank 0's share of the frame, a round-1 measurement, repeated by tools/rank_share.py: an eighth of the frame takes 0.49 ms with
-    # three frames in flight and 0.46 ms with four; the whole frame is best with three)
-    inflight = args.inflight if args.inflight > 0 else (4 if world >= 8 else 3)      # (tools/rank_share.py, profiles/r03_rank_share.log: within run-to-run noise)
+    # three frames in flight and 0.46 ms with four; the whole frame was best with three until round 4's shorter shadow walk:
+    # profiles/r04_inflight_sweep.log, one GPU, whole frame: 2 / 3 / 4 / 5 in flight = 3.05 / 2.66 / 2.62 / 2.71 ms per frame)
+    inflight = args.inflight if args.inflight > 0 else 4
     # Throughput tuning through the library's documented knobs (read at context creation): with several
     # frames in flight and only an eighth of the frame per rank, a smaller persistent grid per context
     # and 128-ray-id chunks beat the defaults, which are tuned for one frame's latency.
