@@ -24,4 +24,4 @@ cd $R && python3 tools/summarise_profiles.py $tag
 cd /tmp
 rm -rf $R/gpurun_out/${tag}_stats_default
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${tag}_stats_default -- python3 $R/bench.py --no-cpu-baseline > $R/gpurun_out/${tag}_stats_default.log 2>&1
-cd $R && { echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline   (the default command: 3 frames in flight)"; echo; echo '```'; python3 tools/kstats.py gpurun_out/${tag}_stats_default "kernel stats"; echo '```'; echo; echo "bench line of that run:"; echo; echo '```'; grep '^{' gpurun_out/${tag}_stats_default.log; echo '```'; } > gpurun_out/${tag}_stats_default.md
+cd $R && { echo "# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline   (the default command: several frames in flight, see frames_in_flight in the bench line)"; echo; echo '```'; python3 tools/kstats.py gpurun_out/${tag}_stats_default "kernel stats"; echo '```'; echo; echo "bench line of that run:"; echo; echo '```'; grep '^{' gpurun_out/${tag}_stats_default.log; echo '```'; } > gpurun_out/${tag}_stats_default.md
