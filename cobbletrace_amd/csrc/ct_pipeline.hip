@@ -789,7 +789,10 @@ __device__ __forceinline__ void args_point_into_hbm(FrameParams &P, PipelinePara
     }
 }
 // (arguments lie in the segment in order, each at its natural alignment)
-constexpr uint32_t kWalkArgsW = (uint32_t)((sizeof(FrameParams) + alignof(PipelineParams) - 1) / alignof(PipelineParams) * alignof(PipelineParams));
+#ifndef CT_ARGS_SKEW                 // (diagnostic builds: a wrong offset, to see the check below report it)
+#define CT_ARGS_SKEW 0
+#endif
+constexpr uint32_t kWalkArgsW = (uint32_t)((sizeof(FrameParams) + alignof(PipelineParams) - 1) / alignof(PipelineParams) * alignof(PipelineParams)) + CT_ARGS_SKEW;
 
 template <int KIND, bool SS, bool HANDOVER = false, bool ORDERED = false, bool CULL = false>
 __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const FrameParams P_launch, const PipelineParams W_launch) {
@@ -802,9 +805,13 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
 #define ARGS_AGAIN_AT(bit) do { if (AGAIN && ((CT_ARGS_POINTS >> (bit)) & 1)) { kernarg_again(P, 0u); kernarg_again(W, kWalkArgsW); args_point_into_hbm(P, W); } } while (0)
 #define ARGS_AGAIN() do { if (AGAIN) { kernarg_again(P, 0u); kernarg_again(W, kWalkArgsW); args_point_into_hbm(P, W); } } while (0)
     ARGS_AGAIN();
-    // (the layout assumption, checked once per wave on first and last members: a frame of nothing beats a wild pointer)
+    // (the layout assumption, checked once per wave on first and last members: nothing is read through a copy that does not
+    //  match, and the frame ends with an error -- word 2 in the flag the host looks at when the frame is done)
     if (AGAIN) if (P.nodes != P_launch.nodes || P.rng_seed != P_launch.rng_seed || W.coords != W_launch.coords || W.n_samples != W_launch.n_samples ||
-        W.order[1].totals_out != W_launch.order[1].totals_out || P.counters != P_launch.counters) return;
+        W.order[1].totals_out != W_launch.order[1].totals_out || P.counters != P_launch.counters) {
+        if (threadIdx.x == 0) *P_launch.overflow = 2u;
+        return;
+    }
     const uint32_t q_chunk = (KIND == 1) ? W.chunk_shadow : W.chunk;      // ray ids per queue atomic
     constexpr bool LIST = KIND >= 2;                 // rays come from W.ray_list instead of the frame's samples
     if (LIST && W.list_gate && *W.list_gate == 0u) return;      // (a bounce level nobody reached)

@@ -1064,6 +1064,10 @@ uint32_t tile_count(const FrameParams &P) { return ((P.square + 7u) / 8u) * ((P.
 int check_overflow(ctgpu_ctx *ctx) {
     uint32_t flag = 0;
     HIP_TRY(hipMemcpy(&flag, ctx->overflow.ptr, sizeof flag, hipMemcpyDeviceToHost));
+    if (flag == 2u) {
+        HIP_TRY(hipMemset(ctx->overflow.ptr, 0, sizeof flag));
+        return ctgpu_fail(CTGPU_ERR_HIP, "the shadow walk found its kernel arguments laid out differently from what it re-reads (ct_pipeline.hip, kernarg_again): nothing was traced");
+    }
     if (flag) {
         HIP_TRY(hipMemset(ctx->overflow.ptr, 0, sizeof flag));
         return ctgpu_fail(CTGPU_ERR_STACK, "traversal stack overflow (tree depth %u)", ctx->scene->tree_depth);
