@@ -91,7 +91,8 @@ class SceneInfo(C.Structure):
                 ("n_quads", C.c_uint32), ("n_quads_flat", C.c_uint32), ("quad_root", C.c_uint32), ("quad_root_flat", C.c_uint32),
                 ("quad_pending", C.c_uint32), ("root_ref", C.c_uint32), ("slot_of_triangle0", C.c_uint32), ("shared_by", C.c_uint32),
                 ("plane_bound", C.c_float * 3), ("pad_", C.c_uint32), ("build_ms", C.c_double), ("pack_ms", C.c_double),
-                ("hbm_bytes", C.c_uint64)]
+                ("hbm_bytes", C.c_uint64), ("shadow_tree_nodes", C.c_uint32), ("shadow_tree_pending", C.c_uint32),
+                ("shadow_tree_ms", C.c_double), ("shadow_tree_gamma", C.c_double)]
 
 
 class Config(C.Structure):
@@ -100,7 +101,9 @@ class Config(C.Structure):
                 ("blocks_per_cu", C.c_int32), ("chunk", C.c_int32), ("chunk_shadow", C.c_int32), ("lds_depth", C.c_int32),
                 ("packet_lds_levels", C.c_int32), ("probe_above", C.c_int32), ("packet_budget", C.c_int32), ("packet_lanes", C.c_int32),
                 ("order", C.c_int32), ("order_heavy", C.c_float * 4), ("order_floor", C.c_int32), ("order_split_below", C.c_int32),
-                ("order_parts", C.c_int32 * 4), ("shadow_split_gap", C.c_float), ("big_leaf_min", C.c_int32), ("big_leaf_share", C.c_int32), ("pack_on_host", C.c_int32),
+                ("order_parts", C.c_int32 * 4), ("shadow_split_gap", C.c_float), ("big_leaf_min", C.c_int32), ("big_leaf_share", C.c_int32),
+                ("shadow_tree", C.c_int32), ("shadow_tree_build", C.c_int32), ("shadow_tree_leaf", C.c_int32),
+                ("shadow_tree_leaf_fill", C.c_int32), ("pack_on_host", C.c_int32),
                 ("thresh", C.c_int32 * 3), ("walk_thresh", C.c_int32 * 3), ("debug", C.c_uint32)]
 
     def as_dict(self):

@@ -88,6 +88,29 @@ struct CullLimits {
     float tau;          // ... and, once it has a closest hit, while its ray.t >= tau (closest-hit walks)
 };
 
+// ---------------------------------------------------------------- the shadow tree (DESIGN appendix E)
+// A shadow ray only asks WHETHER some triangle the reference tests lowers ray.t (raythread.cpp:303-307: no tMax, any
+// update blocks the light).  Until its first update the ray carries ray.t = 1e30f, so which leaves the reference enters is
+// a matter of box tests against that constant, and the answer is
+//     exists triangle T:  IntersectTriangle(T) lowers ray.t  AND  the reference enters T's leaf,
+// whatever the order the triangles are looked at in.  The shadow walk therefore need not walk the reference's
+// midpoint-split tree: it walks a tree of its own over the same TriRecords -- four-wide QuadNodes, built by a binned
+// surface-area heuristic over the triangles' boxes, single triangles (kLeafBit | kOneBit | slot) as the lowest entries --
+// whose boxes only ever EXCLUDE (the cull nodes' rule, appendix D: a lane stays out of an entry only when that proves
+// every triangle test below returns false or leaves ray.t alone), and a triangle that does lower ray.t counts only after
+// the reference's own test of its leaf's box (binary64, the three exact levels) has passed for that ray: with nested boxes
+// (checked at upload) and no zero direction component, the leaf's box passing implies every ancestor's (appendix B2).
+// The boxes are the triangles' grown boxes (k_tri_boxes) grown once more by `gamma`, a scene constant that swallows every
+// rounding of the binary32 slab arithmetic for rays inside the gate below -- so the walk's test is the bare
+// tmax >= max(tmin, 0) with no per-entry margin.  Rays outside the gate (a zero / tiny / huge direction component, an
+// origin far outside the scene) are LEFT: their shadow byte becomes kShadowLeft and a second launch of the shadow walk
+// over the reference's tree (ct_walk_packet<1>) traces them.
+struct ShadowTreeLimits {
+    float d_min, d_max;   // a shadow ray walks the shadow tree only if every |d_i| is in [d_min, d_max] ...
+    float o_max;          // ... and every |o_i| <= o_max
+};
+static constexpr uint8_t kShadowLeft = 3;      // shadow byte: a needed ray the shadow tree's walk did not take
+
 struct Material { uint32_t color; int32_t specular; float reflection; };
 struct Light { int32_t type; float intensity; double position[3]; double direction[3]; };
 

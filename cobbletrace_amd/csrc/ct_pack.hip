@@ -470,6 +470,17 @@ __global__ void k_cull_emit(QuadNode *quads, uint32_t n_quads, uint32_t root, ui
 
 }  // namespace
 
+int ctgpu_triangle_boxes_on_device(const void *d_tris, uint32_t n, float *d_box, uint32_t stats[8]) {
+    uint32_t *d_stats = nullptr;
+    HIP_TRY(hipMalloc((void **)&d_stats, 12 * sizeof(uint32_t)));
+    struct Free { uint32_t *p; ~Free() { (void)hipFree(p); } } free_stats{d_stats};
+    HIP_TRY(hipMemsetAsync(d_stats, 0, 12 * sizeof(uint32_t), nullptr));
+    hipLaunchKernelGGL(k_tri_boxes, dim3(blocks_for(n)), dim3(kBlock), 0, nullptr, (const TriRecord *)d_tris, n, d_box, d_stats);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(stats, d_stats, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return CTGPU_OK;
+}
+
 // The cull nodes of the folded tree's big leaves (whoever packed the tree: ct_pack's kernels or the host restatement).
 // d_quads (n_quads QuadNodes, root reference quad_root) is left as it is; when any leaf gets cull nodes, out->quads is a
 // second, longer array -- the tree's own QuadNodes first, unchanged but for the references to those leaves, then the cull

@@ -17,14 +17,19 @@ namespace ctd {
 // the number of rays taking part (tools/lane_stats.py)
 constexpr int kCounterWords = 48;
 // ray-queue head words: walk 0 primary rays, walks 1..L the shadow rays of the scene's L shadow-casting lights, walks
-// L+1 / L+2 the handed-over primary / shadow rays; 8 shards each, one 128-byte line per head word; then 32 words
-// for the two hand-over counters (everything cleared together, per frame)
-__host__ __device__ constexpr uint32_t queue_walks(uint32_t n_shadow_lights) { return n_shadow_lights + 3u; }
+// L+1 / L+2 the handed-over primary / shadow rays, walks L+3..2L+2 the same lights' shadow rays once more (the second
+// shadow launch of a frame whose shadow rays walk the shadow tree: the rays that tree does not take, ct_walk_shadow_tree);
+// 8 shards each, one 128-byte line per head word; then 32 words for the two hand-over counters (everything cleared
+// together, per frame)
+__host__ __device__ constexpr uint32_t queue_walks(uint32_t n_shadow_lights) { return 2u * n_shadow_lights + 3u; }
+__host__ __device__ constexpr uint32_t queue_second_shadow_walk(uint32_t n_shadow_lights) { return n_shadow_lights + 3u; }
 __host__ __device__ constexpr size_t queue_words(uint32_t n_shadow_lights) { return (size_t)queue_walks(n_shadow_lights) * 8u * 16u; }
 // ... and behind them: the two hand-over counters (32 words), then the head words of the heavy-chunk lists (ORDERED
 // walks: class 0 / 1 of the primary walk, class 0 / 1 of the shadow walk, 16 words apart).  One block, cleared per frame.
 __host__ __device__ constexpr size_t queue_order_heads(uint32_t n_shadow_lights) { return queue_words(n_shadow_lights) + 32u; }
-__host__ __device__ constexpr size_t queue_block_words(uint32_t n_shadow_lights) { return queue_words(n_shadow_lights) + 32u + 64u; }
+// ... and one more line: word 0 counts the shadow rays the shadow tree's walk left to the second shadow launch
+__host__ __device__ constexpr size_t queue_left_word(uint32_t n_shadow_lights) { return queue_words(n_shadow_lights) + 32u + 64u; }
+__host__ __device__ constexpr size_t queue_block_words(uint32_t n_shadow_lights) { return queue_words(n_shadow_lights) + 32u + 64u + 16u; }
 constexpr int kCounterElided = 16;
 
 struct FrameParams {
@@ -55,6 +60,11 @@ struct FrameParams {
     float    plane_bound[3];      // >= |plane| of every box in the tree AND of every triangle box, per axis (+inf: no filter)
     uint32_t cull_first;          // QuadNodes from this index on are cull nodes (ct_device.h; kNoNode: the scene has none)
     CullLimits cull;              // which rays may skip their entries (d_lim = 0: none), from the scene's magnitudes and the eye
+    // the shadow-only tree (ct_device.h "shadow tree", DESIGN appendix E; stree == NULL: the frame's shadow rays walk `quads`)
+    const QuadNode *stree;        // its nodes, root = node 0
+    const TriRecord *stree_tris;  // the TriRecords in its own leaf order (a leaf entry: kLeafBit | first slot, `remaining` as in tris[])
+    const uint32_t *leaf_of_slot; // slot of stree_tris -> the reference node (a leaf of ref_nodes[]) that holds that triangle
+    ShadowTreeLimits stree_lim;   // which shadow rays may walk it
 
     // frame
     int32_t  width, height, half; // bitmap size; half = height/2
@@ -114,6 +124,7 @@ struct PipelineParams {
     uint32_t n_shadow_lights;
     uint32_t lds_depth, spill_depth, walk_blocks;
     uint32_t listed_blocks;      // grid of the per-lane launches that trace the handed-over rays
+    uint32_t stree_blocks;       // grid of ct_walk_shadow_tree (0: walk_blocks)
     uint32_t chunk;              // ray ids a wave reserves per queue atomic (multiple of 64)
     uint32_t chunk_shadow;       // the same for the shadow walk (its candidates are only partly rays)
     uint32_t packet;             // 1: supersampled frames use ct_walk_packet (shared walk per wave)
@@ -140,6 +151,9 @@ struct PipelineParams {
     const uint32_t *list_gate;   // when set and *list_gate == 0 the list holds no ray: the walk's waves leave at once
     float    shadow_split_gap;   // shadow packets: a window's hit samples go out as two groups when their primary hits' depths fall into
                                  // two ranges at least this far apart (relative to the middle depth); < 0: never
+    uint32_t shadow_live;        // the shadow byte that marks a ray the shadow walk has to trace: 0 (ct_light_gate), or kShadowLeft in the
+                                 // launch that traces what ct_walk_shadow_tree left (it then also clears the byte of an unblocked ray)
+    unsigned long long *shadow_left;   // [1] rays ct_walk_shadow_tree left to that launch (it returns at once on 0)
     uint32_t ordered;            // 1: the frame's packet walks are the ORDERED instantiations, order[] is set
     OrderParams order[2];
 };
@@ -184,6 +198,7 @@ struct BounceParams {
 uint64_t pipeline_sample_count(const FrameParams &P, bool ss);
 int  pipeline_walk_occupancy(size_t lds_bytes);
 int  pipeline_packet_occupancy(uint32_t depth, uint32_t lds_levels);
+int  pipeline_stree_occupancy();
 constexpr int kPipelineKernels = 5;      // ct_sample_grid, primary walk, ct_light_gate, shadow walk, ct_shade
 void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hipStream_t stream, hipEvent_t *marks,
                      const BounceParams *bounce = nullptr, const OrderBuild *order = nullptr);

@@ -783,7 +783,7 @@ __device__ __forceinline__ void args_point_into_hbm(FrameParams &P, PipelinePara
     in_hbm(P.rand_table); in_hbm(P.row_ordinal); in_hbm(P.out); in_hbm(P.counters); in_hbm(P.overflow);
     in_hbm(W.coords); in_hbm(W.hits); in_hbm(W.shadow); in_hbm(W.queue); in_hbm(W.shadow_lights); in_hbm(W.walk_work);
     in_hbm(W.handed); in_hbm(W.handed_ids[0]); in_hbm(W.handed_ids[1]); in_hbm(W.ray_list); in_hbm(W.ray_hits); in_hbm(W.ray_live);
-    in_hbm(W.list_gate);
+    in_hbm(W.list_gate); in_hbm(W.shadow_left); in_hbm(P.stree); in_hbm(P.stree_tris); in_hbm(P.leaf_of_slot);
     for (int k = 0; k < 2; k++) {
         in_hbm(W.order[k].cost_out); in_hbm(W.order[k].listed); in_hbm(W.order[k].list); in_hbm(W.order[k].count); in_hbm(W.order[k].totals_out);
     }
@@ -830,7 +830,10 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
     // (a wave mask becomes a lane predicate with inverse_ballot: the mask goes straight into EXEC)
     const uint64_t n_samples = W.n_samples;
     const uint32_t n_shards = (KIND != 1) ? kShards : kShards * W.n_shadow_lights;
-    unsigned long long *heads = W.queue + (size_t)(KIND != 1 ? 0u : kShards) * 16u;
+    // (the frame's shadow walk drains walks 1..L; the launch behind ct_walk_shadow_tree, which traces the rays that walk
+    //  left -- W.shadow_live == kShadowLeft --, a second set of head words, and leaves at once when nothing was left)
+    if (KIND == 1 && W.shadow_live != 0u && *W.shadow_left == 0ull) return;
+    unsigned long long *heads = W.queue + (size_t)(KIND != 1 ? 0u : (W.shadow_live != 0u ? queue_second_shadow_walk(W.n_shadow_lights) : 1u) * kShards) * 16u;
     const uint64_t shard_span = ((n_samples + kShards - 1) / kShards + q_chunk - 1) / q_chunk * q_chunk;
     uint32_t shard = blockIdx.x % n_shards, shards_done = 0;
     uint64_t light_base = 0, chunk_light_base = 0;       // first ray id of the packet's / the current chunk's light
@@ -975,7 +978,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                 // open the next window of the chunk: which of its ids are rays, and how deep their primary hits lie
                 const uint32_t n_ids = chunk_end - chunk_next < 128u ? (uint32_t)(chunk_end - chunk_next) : 128u;
                 const uint64_t id0 = chunk_next + lane, id1 = chunk_next + 64u + lane;
-                const bool live0 = lane < n_ids && W.shadow[id0] == 0, live1 = 64u + lane < n_ids && W.shadow[id1] == 0;
+                const bool live0 = lane < n_ids && W.shadow[id0] == W.shadow_live, live1 = 64u + lane < n_ids && W.shadow[id1] == W.shadow_live;
                 bool far0 = false, far1 = false;
                 unsigned long long m_live0 = __ballot(live0), m_live1 = __ballot(live1);
                 if (W.shadow_split_gap >= 0.0f && (m_live0 | m_live1) != 0ull) {       // (an experiment that lost: off by default)
@@ -1027,7 +1030,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                     live = sample_position<SS>(P, W, id, px, py);
                     if (!live) W.hits[id] = make_uint2(__float_as_uint(kNoHit), kInvalidSample);
                 } else if (KIND == 1) {
-                    live = W.shadow[id] == 0;
+                    live = W.shadow[id] == W.shadow_live;
                 } else if (W.ray_live) {
                     live = W.ray_live[id] != 0;               // (the frame's own bounce lists: not every sample has a ray)
                 }
@@ -1554,6 +1557,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
             }
             else if (KIND == 0) W.hits[packet_base + lane] = make_uint2(__float_as_uint(t), slot);
             else if (t != kNoHit) W.shadow[ray_id] = 1;
+            else if (W.shadow_live != 0u) W.shadow[ray_id] = 0;       // (a ray the shadow tree's walk left, and nothing blocks it)
         }
     }
 
@@ -1588,6 +1592,336 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
 #undef RAY_O
 #undef ARGS_AGAIN
 #undef ARGS_AGAIN_AT
+
+// ------------------------------------------------------------------------------------
+// ct_walk_shadow_tree: the frame's shadow rays through the SHADOW TREE (ct_device.h "the shadow tree", DESIGN appendix E)
+// instead of the reference's tree.  Same packets as ct_walk_packet<1> (windows of 128 ray ids under one light, 64 live
+// ids a packet), same shared walk -- one {entry, lane mask} per stack level in the lanes of three vector registers, nodes
+// and triangle records through the scalar cache -- but of a tree whose shape is this build's own:
+//   * an entry's box only excludes, and the test is bare: three packed fmas, max3 / min3 by the packet's octant,
+//     tmax >= max(tmin, 0).  No margin, no undecided lanes, no binary64 boxes, no exact levels: the boxes were grown at
+//     build time by what the binary32 arithmetic can be off for any ray inside the gate (P.stree_lim);
+//   * the lowest entries are single triangles with their own boxes, so a triangle is tested by the lanes that meet ITS box;
+//   * a triangle test that lowers ray.t is followed, for those lanes, by the reference's own test of the box of the leaf
+//     that holds the triangle in the REFERENCE's tree (binary64, the exact levels of appendix A): only then would the
+//     reference have made this test at all.  A lane whose leaf box fails carries on as if nothing had happened;
+//   * rays outside the gate are left to a second launch of ct_walk_packet<1> (shadow byte kShadowLeft, W.shadow_left).
+// Results are those of the reference's full traversal: raythread.cpp:303-307 asks only whether ray.t moved.
+// ------------------------------------------------------------------------------------
+#ifndef CT_STREE_WAVES
+#define CT_STREE_WAVES 8
+#endif
+struct RayLine {              // t(plane) = fma(plane, 1/d, -o/d) in binary32
+    f32x2 inv_xy, noi_xy;     // {1/d.x, 1/d.y}, {-o.x/d.x, -o.y/d.y}
+    f32x2 z;                  // {1/d.z, -o.z/d.z}: one register pair serves both operands of the z axis' packed fma
+};
+template <int OCT>
+__device__ __forceinline__ bool line_enters(const RayLine &r, f32x2 px, f32x2 py, f32x2 pz) {
+    f32x2 tx, ty, tz;
+    float tmin, tmax, from;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(tx) : "s"(px), "v"(r.inv_xy), "v"(r.noi_xy));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[1,1,1]" : "=v"(ty) : "s"(py), "v"(r.inv_xy), "v"(r.noi_xy));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(tz) : "s"(pz), "v"(r.z), "v"(r.z));
+    if (OCT == 8) {           // a packet whose rays point different ways: each axis' two parameters sorted per lane
+        float nx, ny, nz, fx, fy, fz;
+        asm("v_min_f32 %0, %1, %2" : "=v"(nx) : "v"(tx.x), "v"(tx.y));
+        asm("v_min_f32 %0, %1, %2" : "=v"(ny) : "v"(ty.x), "v"(ty.y));
+        asm("v_min_f32 %0, %1, %2" : "=v"(nz) : "v"(tz.x), "v"(tz.y));
+        asm("v_max_f32 %0, %1, %2" : "=v"(fx) : "v"(tx.x), "v"(tx.y));
+        asm("v_max_f32 %0, %1, %2" : "=v"(fy) : "v"(ty.x), "v"(ty.y));
+        asm("v_max_f32 %0, %1, %2" : "=v"(fz) : "v"(tz.x), "v"(tz.y));
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmin) : "v"(nx), "v"(ny), "v"(nz));
+        asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tmax) : "v"(fx), "v"(fy), "v"(fz));
+    } else {                  // (box_filter_f32_oct's selection: the near plane of an axis is known from the sign of 1/d)
+        asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmin) : "v"((OCT & 1) ? tx.y : tx.x), "v"((OCT & 2) ? ty.y : ty.x), "v"((OCT & 4) ? tz.y : tz.x));
+        asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tmax) : "v"((OCT & 1) ? tx.x : tx.y), "v"((OCT & 2) ? ty.x : ty.y), "v"((OCT & 4) ? tz.x : tz.y));
+    }
+    asm("v_max_f32 %0, 0, %1" : "=v"(from) : "v"(tmin));
+    return tmax >= from;
+}
+__device__ __forceinline__ uint32_t scalar_load_word(const uint32_t *p) {
+    uint32_t r;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(r) : "s"(p) : "memory");
+    return r;
+}
+typedef int sgpr8_t __attribute__((ext_vector_type(8)));
+struct ScalarBox {            // the first 48 bytes of a reference node: bmin xyz, bmax xyz
+    sgpr8_t a;
+    sgpr4_t b;
+    __device__ __forceinline__ double f64(int i) const {
+        const int lo = (i < 4) ? a[2 * i] : b[2 * (i - 4)];
+        const int hi = (i < 4) ? a[2 * i + 1] : b[2 * (i - 4) + 1];
+        return __hiloint2double(hi, lo);
+    }
+};
+__device__ __forceinline__ ScalarBox scalar_load_box(const ctgpu_node *n) {
+    ScalarBox r;
+    asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x20\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(r.a), "=&s"(r.b)
+                 : "s"(n)
+                 : "memory");
+    return r;
+}
+
+template <bool SS>
+__global__ __launch_bounds__(kWave, CT_STREE_WAVES) void ct_walk_shadow_tree(const FrameParams P_launch, const PipelineParams W_launch) {
+    FrameParams P = P_launch;
+    PipelineParams W = W_launch;
+    // (the launch's arguments read again per phase of a packet, as in ct_walk_packet<1>: kernarg_again)
+#define STREE_ARGS() do { if (CT_ARGS_AGAIN != 0) { kernarg_again(P, 0u); kernarg_again(W, kWalkArgsW); args_point_into_hbm(P, W); } } while (0)
+    STREE_ARGS();
+    if (CT_ARGS_AGAIN != 0) if (P.nodes != P_launch.nodes || P.rng_seed != P_launch.rng_seed || W.coords != W_launch.coords || W.n_samples != W_launch.n_samples ||
+        W.order[1].totals_out != W_launch.order[1].totals_out || P.counters != P_launch.counters) {
+        if (threadIdx.x == 0) *P_launch.overflow = 2u;
+        return;
+    }
+    const uint32_t q_chunk = W.chunk_shadow;
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    LdsWord *win_list = (LdsWord *)lds_raw;          // [128] the open window's live ray offsets
+    const uint32_t lane = threadIdx.x;
+    const uint64_t n_samples = W.n_samples;
+    const uint32_t n_shards = kShards * W.n_shadow_lights;
+    unsigned long long *heads = W.queue + (size_t)kShards * 16u;
+    const uint64_t shard_span = ((n_samples + kShards - 1) / kShards + q_chunk - 1) / q_chunk * q_chunk;
+    uint32_t shard = blockIdx.x % n_shards, shards_done = 0;
+    uint64_t light_base = 0, chunk_light_base = 0;
+    uint32_t light_index = 0, chunk_light_index = 0;
+    d3 shadow_o = make_d3(0, 0, 0), d = make_d3(0, 0, 1);
+    RayLine rl = RayLine{};
+    float t = kNoHit;
+    bool has_ray = false;
+    uint64_t ray_id = 0;
+    uint64_t chunk_next = 0, chunk_end = 0;
+    bool wave_drained = false;
+    uint32_t n_traced = 0, n_left = 0;
+    uint32_t win_pos = 0, win_count = 0;
+    uint64_t win_base = 0;
+    uint32_t n_packets = 0, n_quads = 0, n_records = 0, n_blocked = 0, n_all_blocked = 0;
+
+    for (;;) {
+        STREE_ARGS();
+        // ---------------- fetch a packet (ct_walk_packet<1>'s windows)
+        has_ray = false;
+        for (;;) {
+            if (win_pos < win_count) {
+                const uint32_t n = win_count - win_pos < 64u ? win_count - win_pos : 64u;
+                if (lane < n) { ray_id = win_base + win_list[win_pos + lane]; has_ray = true; }
+                win_pos += n;
+                break;
+            }
+            if (wave_drained) break;
+            if (chunk_next >= chunk_end) {
+                unsigned long long offset = 0;
+                if (lane == 0) offset = atomicAdd(heads + (size_t)shard * 16u, (unsigned long long)q_chunk);
+                offset = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)offset) |
+                         ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(offset >> 32)) << 32);
+                const uint32_t light = shard / kShards, part = shard % kShards;
+                const uint64_t lo = (uint64_t)part * shard_span + offset;
+                if (offset >= shard_span || lo >= n_samples) {
+                    shards_done += 1;
+                    shard = (shard + 1u) % n_shards;
+                    if (shards_done >= n_shards) wave_drained = true;
+                    continue;
+                }
+                uint64_t hi = lo + q_chunk;
+                if (hi > ((uint64_t)part + 1u) * shard_span) hi = ((uint64_t)part + 1u) * shard_span;
+                if (hi > n_samples) hi = n_samples;
+                chunk_light_base = (uint64_t)light * n_samples;
+                chunk_next = chunk_light_base + lo;
+                chunk_end = chunk_light_base + hi;
+                chunk_light_index = (uint32_t)__builtin_amdgcn_readfirstlane((int)W.shadow_lights[light]);
+            }
+            // open the next window of the chunk: which of its ids are rays
+            const uint32_t n_ids = chunk_end - chunk_next < 128u ? (uint32_t)(chunk_end - chunk_next) : 128u;
+            const uint64_t id0 = chunk_next + lane, id1 = chunk_next + 64u + lane;
+            const bool live0 = lane < n_ids && W.shadow[id0] == 0, live1 = 64u + lane < n_ids && W.shadow[id1] == 0;
+            const unsigned long long m_live0 = __ballot(live0), m_live1 = __ballot(live1);
+            const uint32_t n_live0 = (uint32_t)__popcll(m_live0);
+            const auto rank_in = [&](unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
+            if (live0) win_list[rank_in(m_live0)] = lane;
+            if (live1) win_list[n_live0 + rank_in(m_live1)] = 64u + lane;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            win_base = chunk_next;
+            win_pos = 0; win_count = n_live0 + (uint32_t)__popcll(m_live1);
+            chunk_next += n_ids;
+            light_base = chunk_light_base;
+            light_index = chunk_light_index;
+        }
+        if (__ballot(has_ray) == 0ull) {
+            if (wave_drained) break;
+            continue;
+        }
+        // ---------------- the rays (raythread.cpp:360, 289-303), and which of them the shadow tree takes
+        STREE_ARGS();
+        bool left = false;
+        if (has_ray) {
+            const uint64_t sample = ray_id - light_base;
+            float px, py;
+            if (SS) { const float2 c = W.coords[sample]; px = c.x; py = c.y; }
+            else (void)sample_position<SS>(P, W, sample, px, py);
+            const uint2 h = W.hits[sample];
+            const float tclosest = (h.y != kNoNode) ? __uint_as_float(h.x) : kFarAway;
+            shadow_o = make_d3(P.cam[0], P.cam[1], P.cam[2]) + scale((double)tclosest, primary_direction(P, px, py));
+            const Light &shadow_light = P.lights[light_index];
+            d = (shadow_light.type == CTGPU_LIGHT_POINT) ? load_d3(shadow_light.position) - shadow_o
+                                                         : load_d3(shadow_light.direction);
+            t = kNoHit;
+            const d3 inv = make_d3(quick_reciprocal(d.x), quick_reciprocal(d.y), quick_reciprocal(d.z));
+            rl.inv_xy = f32x2{(float)inv.x, (float)inv.y};
+            rl.noi_xy = f32x2{-(float)(shadow_o.x * inv.x), -(float)(shadow_o.y * inv.y)};
+            rl.z = f32x2{(float)inv.z, -(float)(shadow_o.z * inv.z)};
+            // the gate (appendix E.2): magnitudes for which the boxes' growth covers the binary32 arithmetic and appendix D's
+            // lemma covers the reference's; anything else -- a zero component first of all -- is left to the second launch
+            const double d_min = (double)P.stree_lim.d_min, d_max = (double)P.stree_lim.d_max, o_max = (double)P.stree_lim.o_max;
+            const double ax = __builtin_fabs(d.x), ay = __builtin_fabs(d.y), az = __builtin_fabs(d.z);
+            const bool inside = ax >= d_min && ax <= d_max && ay >= d_min && ay <= d_max && az >= d_min && az <= d_max &&
+                                __builtin_fabs(shadow_o.x) <= o_max && __builtin_fabs(shadow_o.y) <= o_max && __builtin_fabs(shadow_o.z) <= o_max;
+            left = !inside;
+            if (left) { W.shadow[ray_id] = kShadowLeft; has_ray = false; }
+        }
+        n_left += (uint32_t)__popcll(__ballot(left));
+        unsigned long long tracing = __ballot(has_ray);
+        n_traced += (uint32_t)__popcll(tracing);
+        if (tracing == 0ull) continue;
+        n_packets += 1;
+        uint32_t octant = 8u;
+        {
+            const unsigned long long down_x = __ballot(has_ray && __float_as_int(rl.inv_xy.x) < 0);
+            const unsigned long long down_y = __ballot(has_ray && __float_as_int(rl.inv_xy.y) < 0);
+            const unsigned long long down_z = __ballot(has_ray && __float_as_int(rl.z.x) < 0);
+            if ((down_x == 0ull || down_x == tracing) && (down_y == 0ull || down_y == tracing) && (down_z == 0ull || down_z == tracing))
+                octant = (down_x ? 1u : 0u) | (down_y ? 2u : 0u) | (down_z ? 4u : 0u);
+        }
+        STREE_ARGS();
+        const unsigned long long rays = tracing;
+        uint32_t cur = 0u;                      // the root is node 0 (a tree always has one)
+        unsigned long long mask = tracing;
+        uint32_t sp = 0;
+        int stack_ref = 0, stack_mask_lo = 0, stack_mask_hi = 0;
+        uint32_t hit_at = 0u;                   // the TriRecord whose test moved this lane's ray.t
+
+        auto shared_walk = [&](auto octant_tag) {
+        constexpr int OCT = decltype(octant_tag)::value;
+        while (mask != 0ull) {
+            if (cur & kLeafBit) {
+                // a leaf: a run of triangles (mostly one or two), tested by the lanes that met the leaf's box
+                const uint32_t first = cur & kSlotMask;
+                const bool mine = __builtin_amdgcn_inverse_ballot_w64(mask);
+                uint32_t count = 1;
+                for (uint32_t k = 0; k < count; k++) {
+                    const ScalarTri tr = scalar_load_tri(P.stree_tris + first + k);
+                    if (k == 0) { count = tr.remaining(); n_records += count; }
+                    if (mine && t == kNoHit) {
+                        const d3 p1 = make_d3(tr.f64(0), tr.f64(1), tr.f64(2)), e1 = make_d3(tr.f64(3), tr.f64(4), tr.f64(5)),
+                                 e2 = make_d3(tr.f64(6), tr.f64(7), tr.f64(8));
+                        (void)triangle_test(shadow_o, d, t, p1, e1, e2);
+                        if (t != kNoHit) hit_at = first + k;
+                    }
+                }
+                // (a lane whose ray.t moved stops here; whether the reference would have made that test at all is looked
+                //  at after the walk, once per packet: "the verdict of the leaf's box" below)
+                tracing &= __ballot(t == kNoHit);
+                if (tracing == 0ull) sp = 0;               // every ray of the packet has its blocker
+                mask = 0ull;
+            } else {
+                n_quads += 1;
+                const ScalarQuad sq = scalar_load_quad(P.stree + cur);
+                unsigned long long enter[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    enter[k] = __ballot(line_enters<OCT>(rl, sq.planes(k, 0), sq.planes(k, 1), sq.planes(k, 2))) & mask;
+                // (an absent entry holds an inside-out box: no ray line enters it)
+                uint32_t next_ref = 0;
+                unsigned long long next_mask = 0ull;
+#pragma unroll
+                for (int k = 3; k >= 0; k--) {
+                    if (enter[k] != 0ull) {
+                        if (next_mask != 0ull) {
+                            const bool level = lane == sp;
+                            stack_ref = level ? (int)next_ref : stack_ref;
+                            stack_mask_lo = level ? (int)(uint32_t)next_mask : stack_mask_lo;
+                            stack_mask_hi = level ? (int)(uint32_t)(next_mask >> 32) : stack_mask_hi;
+                            sp += 1;
+                        }
+                        next_ref = sq.ref(k);
+                        next_mask = enter[k];
+                    }
+                }
+                cur = next_ref;
+                mask = next_mask;
+                if (mask != 0ull) continue;
+            }
+            while (mask == 0ull && sp > 0) {
+                sp -= 1;
+                const uint32_t pushed_lo = (uint32_t)__builtin_amdgcn_readlane(stack_mask_lo, (int)sp);
+                const uint32_t pushed_hi = (uint32_t)__builtin_amdgcn_readlane(stack_mask_hi, (int)sp);
+                mask = ((unsigned long long)pushed_lo | ((unsigned long long)pushed_hi << 32)) & tracing;
+                cur = (uint32_t)__builtin_amdgcn_readlane(stack_ref, (int)sp);
+            }
+        }
+        };
+        switch (octant) {
+            case 0: shared_walk(std::integral_constant<int, 0>{}); break;
+            case 1: shared_walk(std::integral_constant<int, 1>{}); break;
+            case 2: shared_walk(std::integral_constant<int, 2>{}); break;
+            case 3: shared_walk(std::integral_constant<int, 3>{}); break;
+            case 4: shared_walk(std::integral_constant<int, 4>{}); break;
+            case 5: shared_walk(std::integral_constant<int, 5>{}); break;
+            case 6: shared_walk(std::integral_constant<int, 6>{}); break;
+            case 7: shared_walk(std::integral_constant<int, 7>{}); break;
+            default: shared_walk(std::integral_constant<int, 8>{}); break;
+        }
+
+        // ---------------- the verdict of the leaf's box
+        // A triangle test moved the ray's ray.t: would the reference have made that test?  Only inside the triangle's leaf,
+        // i.e. if that leaf's box passes IntersectAABB for this ray at ray.t = 1e30f (bvh.cpp:165-179, 200); its
+        // ancestors' boxes then pass too -- nested boxes, and no NaN parameter since the gate keeps zero components out
+        // (appendix B2).  The reference's node, its binary64 box, the exact levels of appendix A.  A ray whose box FAILS
+        // (the triangle test and the box test disagree at the box's rim: one ray in millions) has stopped half-way through
+        // its walk; it is left to the second launch like a ray outside the gate.
+        STREE_ARGS();
+        if (has_ray && t != kNoHit) {
+            const ctgpu_node *leaf = P.ref_nodes + P.leaf_of_slot[hit_at];
+            const double4 b0 = *reinterpret_cast<const double4 *>(&leaf->bmin[0]);     // bmin xyz, bmax x
+            const double2 b1 = *reinterpret_cast<const double2 *>(&leaf->bmax[1]);     // bmax yz
+            const double bmin[3] = {b0.x, b0.y, b0.z}, bmax[3] = {b0.w, b1.x, b1.y};
+            const d3 inv = make_d3(quick_reciprocal(d.x), quick_reciprocal(d.y), quick_reciprocal(d.z));
+            float tmin64, tmax64;
+            bool verdict;
+            slab_approx(shadow_o, inv, bmin, bmax, tmin64, tmax64);
+            if (!box_verdict_positive_t(tmin64, tmax64, kNoHit, verdict)) {
+                (void)slab_in_sequence(shadow_o, d, bmin, bmax, tmin64, tmax64);
+                verdict = tmax64 >= tmin64 && tmin64 < kNoHit && tmax64 > 0;
+            }
+            if (!verdict) { W.shadow[ray_id] = kShadowLeft; has_ray = false; left = true; }
+        }
+        {
+            const uint32_t undone = (uint32_t)__popcll(__ballot(left && t != kNoHit));
+            n_left += undone;
+            n_traced -= undone;
+        }
+        // ---------------- retire the packet
+        {
+            const unsigned long long blocked = __ballot(has_ray && t != kNoHit);
+            n_blocked += (uint32_t)__popcll(blocked);
+            n_all_blocked += (blocked == rays) ? 1u : 0u;
+        }
+        if (has_ray && t != kNoHit) W.shadow[ray_id] = 1;
+    }
+
+    if (lane == 0) {
+        atomicAdd(&P.counters[1], (unsigned long long)n_traced);
+        if (n_left) atomicAdd(W.shadow_left, (unsigned long long)n_left);
+        unsigned long long *work = W.walk_work + (size_t)(blockIdx.x & 63u) * 8u;
+        atomicAdd(work + 3, (unsigned long long)n_packets);
+        atomicAdd(work + 4, (unsigned long long)n_quads);
+        atomicAdd(work + 5, (unsigned long long)n_records);
+        atomicAdd(work + 6, (unsigned long long)n_blocked);
+        atomicAdd(work + 7, (unsigned long long)n_all_blocked);
+    }
+}
+#undef STREE_ARGS
 
 // ------------------------------------------------------------------------------------
 // ct_shade: lighting of every sample of a pixel in order, running blend, pixel store.
@@ -2051,6 +2385,13 @@ int pipeline_packet_occupancy(uint32_t depth, uint32_t lds_levels) {
     return a < b ? a : b;
 }
 
+int pipeline_stree_occupancy() {
+    int a = 0, b = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, ct_walk_shadow_tree<true>, kWave, 512);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, ct_walk_shadow_tree<false>, kWave, 512);
+    return a < b ? a : b;
+}
+
 // ct_order_build: the heavy lists of this frame's two packet walks from the costs the frame before left (blockIdx.y:
 // the walk).  A chunk is heavy when its packets made `heavy[class]` times the mean packet's fetches (and at least
 // `floor`); it goes on its class's list in `parts[class]` pieces and is marked, so that the run over all chunks skips it.
@@ -2176,6 +2517,16 @@ void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hip
         mark(2);
         if (shadows) light_gate();
         mark(3);
+        if (shadows && P.stree && !handover) {
+            // the shadow tree takes the frame's shadow rays; what it leaves (rays outside its gate: shadow byte kShadowLeft,
+            // counted in *W.shadow_left) goes through the reference's tree in a launch whose waves return at once on zero
+            const dim3 grid_s(W.stree_blocks ? W.stree_blocks : W.walk_blocks);
+            if (ss) hipLaunchKernelGGL((ct_walk_shadow_tree<true>), grid_s, wave, 512, stream, P, W);
+            else hipLaunchKernelGGL((ct_walk_shadow_tree<false>), grid_s, wave, 512, stream, P, W);
+            PipelineParams Wl = W;
+            Wl.shadow_live = kShadowLeft;
+            launch_frame_walk<1>(ss, false, false, P.cull_first != kNoNode, grid, wave, lds_p, stream, P, Wl);
+        } else
         if (shadows) launch_frame_walk<1>(ss, handover, ordered, P.cull_first != kNoNode, grid, wave, lds_p, stream, P, W);
         if (shadows && handover && ss) hipLaunchKernelGGL((ct_walk<1, true, true>), grid_l, wave, lds_l, stream, P, W);
         if (shadows && handover && !ss) hipLaunchKernelGGL((ct_walk<1, false, true>), grid_l, wave, lds_l, stream, P, W);

@@ -91,6 +91,14 @@ struct SceneStore {
     uint32_t cull_first = kNoNode, n_cull = 0, n_big_leaves = 0, cull_levels = 0;
     float edge_bound = 0, vertex_bound = 0;
     bool cull_usable = false;
+    // the shadow tree (ct_device.h, ct_shadow_tree.hip): what the frame's shadow rays walk instead of `quads`
+    DeviceArray<QuadNode> stree;
+    DeviceArray<TriRecord> stree_tris;          // the TriRecords once more, in that tree's own leaf order
+    DeviceArray<uint32_t> leaf_of_slot;         // slot of stree_tris -> reference leaf node (the verdict of the leaf's box)
+    ShadowTreeLimits stree_lim = {0, 0, 0};
+    uint32_t stree_pending = 0;
+    double stree_gamma = 0.0, stree_ms = 0.0;
+    bool stree_usable = false;
     DeviceArray<Material> materials;
     DeviceArray<Light> lights;
     DeviceArray<ctgpu_sphere> spheres;          // CTGPU_F_SPHERES
@@ -107,7 +115,7 @@ struct SceneStore {
     ~SceneStore() {
         (void)hipSetDevice(device);
         nodes.release(); quads.release(); quads_flat.release(); quad_boxes.release(); quad_node_of_flat.release();
-        tris.release(); quads_cull.release(); materials.release(); lights.release(); spheres.release(); sphere_nodes.release();
+        tris.release(); quads_cull.release(); stree.release(); stree_tris.release(); leaf_of_slot.release(); materials.release(); lights.release(); spheres.release(); sphere_nodes.release();
         sphere_indexes.release(); shadow_lights.release(); ref_nodes.release(); ref_indexes.release();
     }
 };
@@ -310,6 +318,7 @@ extern "C" int ctgpu_default_config(ctgpu_config *c) {
     for (int k = 0; k < 4; k++) { c->order_heavy[k] = heavy[k]; c->order_parts[k] = parts[k]; }
     c->order_floor = 64; c->order_split_below = 8;
     c->big_leaf_min = 8; c->big_leaf_share = 20;
+    c->shadow_tree = 1; c->shadow_tree_build = 0; c->shadow_tree_leaf = 2; c->shadow_tree_leaf_fill = 20;
     c->shadow_split_gap = -1.0f;
     const int thresh[3] = {40, 20, 12}, walk_thresh[3] = {64, 32, 24};       // (measured best on MI355X)
     for (int k = 0; k < 3; k++) { c->thresh[k] = thresh[k]; c->walk_thresh[k] = walk_thresh[k]; }
@@ -341,6 +350,10 @@ extern "C" int ctgpu_config_from_environment(ctgpu_config *c) {
     if (const char *t = std::getenv("CTGPU_SHADOW_SPLIT")) { float v; if (std::sscanf(t, "%f", &v) == 1 && v == v) c->shadow_split_gap = v; }
     number("CTGPU_BIG_LEAF", c->big_leaf_min, 0, big);
     number("CTGPU_BIG_LEAF_SHARE", c->big_leaf_share, 0, 100);
+    number("CTGPU_SHADOW_TREE", c->shadow_tree, 0, 2);
+    number("CTGPU_SHADOW_TREE_BUILD", c->shadow_tree_build, 0, 1);
+    number("CTGPU_SHADOW_TREE_LEAF", c->shadow_tree_leaf, 1, 4);
+    number("CTGPU_SHADOW_TREE_LEAF_FILL", c->shadow_tree_leaf_fill, 0, 100);
     number("CTGPU_PACKET_BUDGET", c->packet_budget, 0, big);
     number("CTGPU_PACKET_LANES", c->packet_lanes, 1, 64);
     number("CTGPU_PACKET_LDS_LEVELS", c->packet_lds_levels, 1, big);
@@ -377,6 +390,8 @@ extern "C" int ctgpu_create_with_config(int device, const ctgpu_config *config, 
     const auto part_ok = [](int x) { return x == 1 || x == 2 || x == 4 || x == 8 || x == 16; };
     if (c.lds_depth < 1 || c.packet_lds_levels < 1 || c.packet_lanes < 1 || c.packet_lanes > 64 || c.blocks_per_cu < 0 || c.chunk < 0 ||
         c.chunk_shadow < 0 || c.order < 0 || c.order > 3 || c.big_leaf_min < 0 || c.big_leaf_share < 0 || c.big_leaf_share > 100 ||
+        c.shadow_tree < 0 || c.shadow_tree > 2 || c.shadow_tree_build < 0 || c.shadow_tree_build > 1 ||
+        c.shadow_tree_leaf < 1 || c.shadow_tree_leaf > 4 || c.shadow_tree_leaf_fill < 0 || c.shadow_tree_leaf_fill > 100 ||
         c.packet_budget < 0 || c.order_floor < 0 || c.order_split_below < 0 || c.probe_above < 0 ||
         !(c.order_heavy[0] >= c.order_heavy[1] && c.order_heavy[1] >= c.order_heavy[2] && c.order_heavy[2] >= c.order_heavy[3] && c.order_heavy[3] > 0.0f) ||
         !part_ok(c.order_parts[0]) || !part_ok(c.order_parts[1]) || !part_ok(c.order_parts[2]) || !part_ok(c.order_parts[3]))
@@ -764,6 +779,21 @@ extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
         }
     }
 
+    if (ctx->cfg.shadow_tree != 0) {   // the shadow tree (the scenes that cannot have one simply keep walking the reference's)
+        ctgpu_shadow_tree st;
+        int rc = ctgpu_build_shadow_tree(ctx->device, S.tris.ptr, N, S.ref_nodes.ptr, M, ctx->cfg.shadow_tree_build,
+                                         (uint32_t)ctx->cfg.shadow_tree_leaf, (float)ctx->cfg.shadow_tree_leaf_fill * 0.01f, &st);
+        if (rc) return rc;
+        if (st.usable) {
+            S.stree.adopt((QuadNode *)st.nodes, st.n_nodes);
+            S.stree_tris.adopt((TriRecord *)st.records, N);
+            S.leaf_of_slot.adopt(st.leaf_of_slot, N);
+            S.stree_lim.d_min = st.d_min; S.stree_lim.d_max = st.d_max; S.stree_lim.o_max = st.o_max;
+            S.stree_pending = st.pending; S.stree_gamma = st.gamma; S.stree_ms = st.build_ms;
+            S.stree_usable = true;
+        }
+    }
+
     bool reflective = false;
     for (uint32_t i = 0; i < N; i++) reflective = reflective || (s->materials[i].reflection > 0);
     S.triangles_reflect = reflective;
@@ -876,7 +906,10 @@ extern "C" int ctgpu_scene_info(ctgpu_ctx *ctx, ctgpu_scene_info_t *out) {
     out->shared_by = (uint32_t)ctx->scene.use_count();
     out->hbm_bytes = S.nodes.count * sizeof(WideNode) + (S.quads.count + S.quads_flat.count + S.quads_cull.count) * sizeof(QuadNode) +
                      S.quad_boxes.count * sizeof(double) + S.quad_node_of_flat.count * sizeof(uint32_t) + S.tris.count * sizeof(TriRecord) +
-                     S.materials.count * sizeof(Material) + S.ref_nodes.count * sizeof(ctgpu_node) + S.ref_indexes.count * 4;
+                     S.materials.count * sizeof(Material) + S.ref_nodes.count * sizeof(ctgpu_node) + S.ref_indexes.count * 4 +
+                     S.stree.count * sizeof(QuadNode) + S.stree_tris.count * sizeof(TriRecord) + S.leaf_of_slot.count * 4;
+    out->shadow_tree_nodes = (uint32_t)S.stree.count; out->shadow_tree_pending = S.stree_pending;
+    out->shadow_tree_ms = S.stree_ms; out->shadow_tree_gamma = S.stree_gamma;
     return CTGPU_OK;
 }
 
@@ -896,6 +929,9 @@ extern "C" int ctgpu_debug_scene_array(ctgpu_ctx *ctx, int which, void *out, uin
         case 4: src = S.quad_node_of_flat.ptr; size = (uint64_t)S.n_quads_flat * 4 * sizeof(uint32_t); break;
         case 5: src = S.tris.ptr; size = (uint64_t)S.n_triangles * sizeof(TriRecord); break;
         case 6: src = S.quads_cull.ptr; size = (uint64_t)S.quads_cull.count * sizeof(QuadNode); break;
+        case 7: src = S.stree.ptr; size = (uint64_t)S.stree.count * sizeof(QuadNode); break;
+        case 8: src = S.leaf_of_slot.ptr; size = (uint64_t)S.leaf_of_slot.count * sizeof(uint32_t); break;
+        case 9: src = S.stree_tris.ptr; size = (uint64_t)S.stree_tris.count * sizeof(TriRecord); break;
         default: return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_debug_scene_array: unknown array %d", which);
     }
     *needed = size;
@@ -1013,6 +1049,11 @@ int fill_params(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, const ctgpu_partition
         P.quads = ctx->scene->quads_cull.ptr; P.quad_root = ctx->scene->quad_root_cull;
         P.cull_first = ctx->scene->cull_first;   // (the nodes are part of this tree whether or not the frame's rays may skip: d_lim = 0 -> nobody skips)
         P.cull = cull_limits(*ctx->scene, f->cam_pos);
+    }
+    // the shadow tree: supersampled frames' shadow rays (CTGPU_SHADOW_TREE=2: every frame's)
+    if (ctx->scene->stree_usable && (ctx->cfg.shadow_tree == 2 || (ctx->cfg.shadow_tree == 1 && (f->flags & CTGPU_F_SUPERSAMPLE) != 0))) {
+        P.stree = ctx->scene->stree.ptr; P.stree_tris = ctx->scene->stree_tris.ptr; P.leaf_of_slot = ctx->scene->leaf_of_slot.ptr;
+        P.stree_lim = ctx->scene->stree_lim;
     }
     std::memcpy(P.root_min, ctx->scene->root_min, 24);
     std::memcpy(P.root_max, ctx->scene->root_max, 24);
@@ -1335,6 +1376,11 @@ int fill_pipeline(ctgpu_ctx *ctx, uint64_t n_samples, PipelineParams &W, int kin
     HIP_TRY(ctx->queue.resize(queue_block_words(W.n_shadow_lights)));
     W.queue = ctx->queue.ptr;
     W.handed = ctx->queue.ptr + queue_words(W.n_shadow_lights);
+    W.shadow_left = ctx->queue.ptr + queue_left_word(W.n_shadow_lights);
+    {
+        const int stree_per_cu = ctx->blocks_per_cu > 0 ? ctx->blocks_per_cu : std::max(1, pipeline_stree_occupancy());
+        W.stree_blocks = (uint32_t)std::min<uint64_t>((uint64_t)stree_per_cu * ctx->cu_count, std::max<uint64_t>(waves_needed, 1));
+    }
     W.handed_room = 0;
     if (W.packet_budget) {
         W.handed_room = std::max<uint64_t>(n_samples / 2u, 4096u);

@@ -59,6 +59,27 @@ CTGPU_HIDDEN int ctgpu_pack_cull_on_device(int device, const void *d_tris, uint3
                                            uint32_t quad_root, uint32_t big_min, uint32_t share_percent, const float plane_bound[3],
                                            ctgpu_cull_scene *out);
 
+// (ct_pack.hip) the triangles' grown boxes (appendix D.1) and the scene's magnitudes: d_box[n][6] = {lo xyz, hi xyz} per
+// TriRecord slot; stats: 0 edge bound, 1 vertex bound, 2..4 plane bound per axis (float bits), 5 "something is not finite"
+CTGPU_HIDDEN int ctgpu_triangle_boxes_on_device(const void *d_tris, uint32_t n_triangles, float *d_box, uint32_t stats[8]);
+
+// the shadow tree (ct_device.h "the shadow tree", ct_shadow_tree.hip): made from the packed TriRecords and the reference's
+// node array, both already on the device.  strategy: 0 binned surface-area heuristic, 1 object medians (the comparison);
+// leaf_max / leaf_rho: a leaf holds up to leaf_max triangles where their boxes fill the leaf's (ct_shadow_tree_build.h).
+struct ctgpu_shadow_tree {
+    void *nodes = nullptr;                 // QuadNode[n_nodes], root = node 0; hipMalloc'ed, caller owns (NULL: the scene gets none)
+    void *records = nullptr;               // TriRecord[n_triangles] in the tree's own order (a leaf is a run); hipMalloc'ed, caller owns
+    uint32_t *leaf_of_slot = nullptr;      // [n_triangles] slot of `records` -> reference leaf node; hipMalloc'ed, caller owns
+    uint32_t n_nodes = 0;
+    uint32_t pending = 0;                  // most entries ever waiting on the walk's stack (<= 63)
+    float d_min = 0, d_max = 0, o_max = 0; // the gate (ShadowTreeLimits)
+    double gamma = 0;                      // what every stored plane was moved outward by
+    double build_ms = 0;                   // wall time of the build, copies included
+    bool usable = false;
+};
+CTGPU_HIDDEN int ctgpu_build_shadow_tree(int device, const void *d_tris, uint32_t n_triangles, const ctgpu_node *d_ref_nodes,
+                                         uint32_t n_nodes, int strategy, uint32_t leaf_max, float leaf_rho, ctgpu_shadow_tree *out);
+
 // one process, several devices (ctgpu_render_multi)
 CTGPU_HIDDEN int ctgpu_multi_comms(const int *devices, int n, std::vector<void *> &comms);
 CTGPU_HIDDEN void ctgpu_multi_comms_release(std::vector<void *> &comms, bool abort = false);

@@ -42,7 +42,7 @@
 extern "C" {
 #endif
 
-#define CTGPU_ABI_VERSION 3
+#define CTGPU_ABI_VERSION 4
 
 typedef struct ctgpu_ctx ctgpu_ctx;
 
@@ -206,6 +206,12 @@ typedef struct ctgpu_config {
                                      primary hits' depths fall into two ranges this far apart, relative to the middle depth (< 0: never) */
     int32_t big_leaf_min;         /* CTGPU_BIG_LEAF       leaves of at least this many triangles get cull nodes (0: none) */
     int32_t big_leaf_share;       /* CTGPU_BIG_LEAF_SHARE ... in scenes where at least this percentage of the triangles sits in such leaves */
+    int32_t shadow_tree;          /* CTGPU_SHADOW_TREE    the frame's shadow rays walk a tree of this library's own over the same triangles (order-free
+                                     any-hit query, raythread.cpp:303-307; DESIGN appendix E): 0 never, 1 supersampled frames (default), 2 every frame */
+    int32_t shadow_tree_build;    /* CTGPU_SHADOW_TREE_BUILD  how that tree is split: 0 binned surface-area heuristic (default), 1 object medians */
+    int32_t shadow_tree_leaf;     /* CTGPU_SHADOW_TREE_LEAF   most triangles one of its leaves holds (1..4, default 2) ... */
+    int32_t shadow_tree_leaf_fill;/* CTGPU_SHADOW_TREE_LEAF_FILL  ... and c > 1 of them only where c - sum(box area of each) / (box area of all) <= this
+                                     percentage of c (default 20): the triangles' boxes nearly fill the leaf's, a box test each would exclude little */
     int32_t pack_on_host;         /* CTGPU_PACK=host      1: re-lay-out an uploaded tree on the host (the restatement the device packing is tested against) */
     int32_t thresh[3];            /* CTGPU_THRESH         "a,b,c": general path, lanes that make a phase worth running */
     int32_t walk_thresh[3];       /* CTGPU_WALK_THRESH    "r,a,b": per-lane walk, the same (diagnostic builds: the middle number picks the walk they count) */
@@ -247,10 +253,15 @@ typedef struct ctgpu_scene_info_t {
     uint32_t pad_;
     double   build_ms, pack_ms;      /* device time of BuildBVH (0 when the caller brought the tree) and of the packing */
     uint64_t hbm_bytes;              /* what the scene occupies */
+    uint32_t shadow_tree_nodes;      /* the shadow tree: its QuadNodes (0: the scene has none), */
+    uint32_t shadow_tree_pending;    /*   the most entries its walk ever has waiting, */
+    double   shadow_tree_ms;         /*   wall time of its build, */
+    double   shadow_tree_gamma;      /*   what its planes were moved outward by */
 } ctgpu_scene_info_t;
 int  ctgpu_scene_info(ctgpu_ctx *ctx, ctgpu_scene_info_t *out);
-/* test hook: one packed array as bytes (0 WideNodes, 1 QuadNodes, 2 their boxes, 3 unfolded QuadNodes, 4 their
- * boxes, 5 TriRecords); *needed = its size, copied when `bytes` is enough */
+/* test hook: one packed array as bytes (0 WideNodes, 1 QuadNodes, 2 their boxes, 3 unfolded QuadNodes, 4 their entries'
+ * reference nodes, 5 TriRecords, 6 the QuadNodes with the cull nodes behind them, 7 the shadow tree's QuadNodes, 8 that tree's
+ * record slot -> reference leaf node, 9 its TriRecords, in its own order); *needed = its size, copied when `bytes` is enough */
 int  ctgpu_debug_scene_array(ctgpu_ctx *ctx, int which, void *out, uint64_t bytes, uint64_t *needed);
 
 /* One whole frame on this context's GPU into a caller-owned host framebuffer

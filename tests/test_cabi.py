@@ -30,7 +30,7 @@ def test_every_declared_symbol_is_exported():
 
 def test_abi_version_and_structs():
     lib = ca.gpu_library()
-    assert lib.ctgpu_abi_version() == 3
+    assert lib.ctgpu_abi_version() == 4
     # struct sizes the header promises
     assert C.sizeof(ca.Node) == 64 and C.sizeof(ca.Light) == 56 and C.sizeof(ca.Material) == 12
     assert C.sizeof(ca.Ray) == 56 and C.sizeof(ca.Hit) == 16
