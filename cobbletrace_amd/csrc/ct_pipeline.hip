@@ -1609,7 +1609,7 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
 // Results are those of the reference's full traversal: raythread.cpp:303-307 asks only whether ray.t moved.
 // ------------------------------------------------------------------------------------
 #ifndef CT_STREE_WAVES
-#define CT_STREE_WAVES 8
+#define CT_STREE_WAVES 7
 #endif
 struct RayLine {              // t(plane) = fma(plane, 1/d, -o/d) in binary32
     f32x2 inv_xy, noi_xy;     // {1/d.x, 1/d.y}, {-o.x/d.x, -o.y/d.y}
@@ -1639,30 +1639,64 @@ __device__ __forceinline__ bool line_enters(const RayLine &r, f32x2 px, f32x2 py
     asm("v_max_f32 %0, 0, %1" : "=v"(from) : "v"(tmin));
     return tmax >= from;
 }
-__device__ __forceinline__ uint32_t scalar_load_word(const uint32_t *p) {
-    uint32_t r;
-    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(r) : "s"(p) : "memory");
-    return r;
+// The four entries of a node against the packet's rays in ONE block of code (the packets whose rays share an octant:
+// OCT < 8): per entry three packed fmas, the near planes' max3, the far planes' min3, max(tmin, 0), one compare -- 28
+// vector instructions, the verdicts leaving as four wave masks.  Written as a single asm statement with its own seven
+// registers (v56..v62, clobbered): between separate asm statements the compiler cannot see that none of these
+// instructions writes part of a register and puts a wait state in front of every dependent one -- ten s_nop per visit, each
+// a slot of the CU's one scalar unit, which is what this walk is shortest of.
+#define CT_LINE_ENTRY(OUT, PX, PY, PZ, NX, FX, NY, FY, NZ, FZ)                                        \
+    "v_pk_fma_f32 v[56:57], " PX ", %16, %17 op_sel_hi:[1,0,0]\n\t"                                   \
+    "v_pk_fma_f32 v[58:59], " PY ", %16, %17 op_sel:[0,1,1] op_sel_hi:[1,1,1]\n\t"                    \
+    "v_pk_fma_f32 v[60:61], " PZ ", %18, %18 op_sel:[0,0,1] op_sel_hi:[1,0,1]\n\t"                    \
+    "v_max3_f32 v62, " NX ", " NY ", " NZ "\n\t"                                                     \
+    "v_min3_f32 v56, " FX ", " FY ", " FZ "\n\t"                                                     \
+    "v_max_f32 v62, 0, v62\n\t"                                                                      \
+    "v_cmp_ge_f32_e64 " OUT ", v56, v62\n\t"
+#define CT_LINE_NODE(NX, FX, NY, FY, NZ, FZ)                                                          \
+    CT_LINE_ENTRY("%0", "%4", "%5", "%6", NX, FX, NY, FY, NZ, FZ)                                      \
+    CT_LINE_ENTRY("%1", "%7", "%8", "%9", NX, FX, NY, FY, NZ, FZ)                                      \
+    CT_LINE_ENTRY("%2", "%10", "%11", "%12", NX, FX, NY, FY, NZ, FZ)                                   \
+    CT_LINE_ENTRY("%3", "%13", "%14", "%15", NX, FX, NY, FY, NZ, FZ)
+template <int OCT>
+__device__ __forceinline__ void node_enters(const RayLine &r, const ScalarQuad &sq, unsigned long long enter[4]) {
+    static_assert(OCT >= 0 && OCT < 8, "the packets whose rays share an octant");
+#define CT_LINE_ASM(TEXT)                                                                                             \
+    asm volatile(TEXT : "=s"(enter[0]), "=s"(enter[1]), "=s"(enter[2]), "=s"(enter[3])                                 \
+                 : "s"(sq.planes(0, 0)), "s"(sq.planes(0, 1)), "s"(sq.planes(0, 2)), "s"(sq.planes(1, 0)), "s"(sq.planes(1, 1)), "s"(sq.planes(1, 2)), \
+                   "s"(sq.planes(2, 0)), "s"(sq.planes(2, 1)), "s"(sq.planes(2, 2)), "s"(sq.planes(3, 0)), "s"(sq.planes(3, 1)), "s"(sq.planes(3, 2)), \
+                   "v"(r.inv_xy), "v"(r.noi_xy), "v"(r.z)                                                              \
+                 : "v56", "v57", "v58", "v59", "v60", "v61", "v62")
+    // (the near plane of an axis: the minimum plane -- the low half of the fma's pair -- where the rays go up, else the maximum)
+    if (OCT == 0) CT_LINE_ASM(CT_LINE_NODE("v56", "v57", "v58", "v59", "v60", "v61"));
+    if (OCT == 1) CT_LINE_ASM(CT_LINE_NODE("v57", "v56", "v58", "v59", "v60", "v61"));
+    if (OCT == 2) CT_LINE_ASM(CT_LINE_NODE("v56", "v57", "v59", "v58", "v60", "v61"));
+    if (OCT == 3) CT_LINE_ASM(CT_LINE_NODE("v57", "v56", "v59", "v58", "v60", "v61"));
+    if (OCT == 4) CT_LINE_ASM(CT_LINE_NODE("v56", "v57", "v58", "v59", "v61", "v60"));
+    if (OCT == 5) CT_LINE_ASM(CT_LINE_NODE("v57", "v56", "v58", "v59", "v61", "v60"));
+    if (OCT == 6) CT_LINE_ASM(CT_LINE_NODE("v56", "v57", "v59", "v58", "v61", "v60"));
+    if (OCT == 7) CT_LINE_ASM(CT_LINE_NODE("v57", "v56", "v59", "v58", "v61", "v60"));
+#undef CT_LINE_ASM
 }
-typedef int sgpr8_t __attribute__((ext_vector_type(8)));
-struct ScalarBox {            // the first 48 bytes of a reference node: bmin xyz, bmax xyz
-    sgpr8_t a;
-    sgpr4_t b;
-    __device__ __forceinline__ double f64(int i) const {
-        const int lo = (i < 4) ? a[2 * i] : b[2 * (i - 4)];
-        const int hi = (i < 4) ? a[2 * i + 1] : b[2 * (i - 4) + 1];
-        return __hiloint2double(hi, lo);
-    }
-};
-__device__ __forceinline__ ScalarBox scalar_load_box(const ctgpu_node *n) {
-    ScalarBox r;
-    asm volatile("s_load_dwordx8 %0, %2, 0x0\n\ts_load_dwordx4 %1, %2, 0x20\n\ts_waitcnt lgkmcnt(0)"
+// A node / a triangle record through the scalar cache at base + byte offset, the offset in a register: the tree's
+// references ARE byte offsets (ct_shadow_tree.hip), and the second load's base is the array's own base + 64, kept beside
+// it -- no address arithmetic on the walk's chain.
+__device__ __forceinline__ ScalarQuad scalar_load_quad_at(const void *base, const void *base64, uint32_t offset) {
+    ScalarQuad r;
+    asm volatile("s_load_dwordx16 %0, %2, %4\n\ts_load_dwordx16 %1, %3, %4\n\ts_waitcnt lgkmcnt(0)"
                  : "=&s"(r.a), "=&s"(r.b)
-                 : "s"(n)
+                 : "s"(base), "s"(base64), "s"(offset)
                  : "memory");
     return r;
 }
-
+__device__ __forceinline__ ScalarTri scalar_load_tri_at(const void *base, const void *base64, uint32_t offset) {
+    ScalarTri r;
+    asm volatile("s_load_dwordx16 %0, %2, %4\n\ts_load_dwordx4 %1, %3, %4\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(r.a), "=&s"(r.b)
+                 : "s"(base), "s"(base64), "s"(offset)
+                 : "memory");
+    return r;
+}
 template <bool SS>
 __global__ __launch_bounds__(kWave, CT_STREE_WAVES) void ct_walk_shadow_tree(const FrameParams P_launch, const PipelineParams W_launch) {
     FrameParams P = P_launch;
@@ -1795,6 +1829,8 @@ __global__ __launch_bounds__(kWave, CT_STREE_WAVES) void ct_walk_shadow_tree(con
         }
         STREE_ARGS();
         const unsigned long long rays = tracing;
+        const unsigned char *nodes_base = (const unsigned char *)P.stree, *nodes_base64 = nodes_base + 64;
+        const unsigned char *tris_base = (const unsigned char *)P.stree_tris, *tris_base64 = tris_base + 64;
         uint32_t cur = 0u;                      // the root is node 0 (a tree always has one)
         unsigned long long mask = tracing;
         uint32_t sp = 0;
@@ -1806,17 +1842,17 @@ __global__ __launch_bounds__(kWave, CT_STREE_WAVES) void ct_walk_shadow_tree(con
         while (mask != 0ull) {
             if (cur & kLeafBit) {
                 // a leaf: a run of triangles (mostly one or two), tested by the lanes that met the leaf's box
-                const uint32_t first = cur & kSlotMask;
+                const uint32_t first = cur & ~kLeafBit;              // (byte offset of the leaf's first record)
                 const bool mine = __builtin_amdgcn_inverse_ballot_w64(mask);
                 uint32_t count = 1;
                 for (uint32_t k = 0; k < count; k++) {
-                    const ScalarTri tr = scalar_load_tri(P.stree_tris + first + k);
+                    const ScalarTri tr = scalar_load_tri_at(tris_base, tris_base64, first + k * (uint32_t)sizeof(TriRecord));
                     if (k == 0) { count = tr.remaining(); n_records += count; }
                     if (mine && t == kNoHit) {
                         const d3 p1 = make_d3(tr.f64(0), tr.f64(1), tr.f64(2)), e1 = make_d3(tr.f64(3), tr.f64(4), tr.f64(5)),
                                  e2 = make_d3(tr.f64(6), tr.f64(7), tr.f64(8));
                         (void)triangle_test(shadow_o, d, t, p1, e1, e2);
-                        if (t != kNoHit) hit_at = first + k;
+                        if (t != kNoHit) hit_at = first + k * (uint32_t)sizeof(TriRecord);
                     }
                 }
                 // (a lane whose ray.t moved stops here; whether the reference would have made that test at all is looked
@@ -1826,12 +1862,18 @@ __global__ __launch_bounds__(kWave, CT_STREE_WAVES) void ct_walk_shadow_tree(con
                 mask = 0ull;
             } else {
                 n_quads += 1;
-                const ScalarQuad sq = scalar_load_quad(P.stree + cur);
+                const ScalarQuad sq = scalar_load_quad_at(nodes_base, nodes_base64, cur);      // (cur: the node's byte offset)
                 unsigned long long enter[4];
+                if constexpr (OCT < 8) {
+                    node_enters<OCT>(rl, sq, enter);
 #pragma unroll
-                for (int k = 0; k < 4; k++)
-                    enter[k] = __ballot(line_enters<OCT>(rl, sq.planes(k, 0), sq.planes(k, 1), sq.planes(k, 2))) & mask;
-                // (an absent entry holds an inside-out box: no ray line enters it)
+                    for (int k = 0; k < 4; k++) enter[k] &= mask;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        enter[k] = __ballot(line_enters<OCT>(rl, sq.planes(k, 0), sq.planes(k, 1), sq.planes(k, 2))) & mask;
+                }
+                // (an entry the node does not have is a far corner point with a safe reference: ct_shadow_tree_build.h)
                 uint32_t next_ref = 0;
                 unsigned long long next_mask = 0ull;
 #pragma unroll
@@ -1882,7 +1924,7 @@ __global__ __launch_bounds__(kWave, CT_STREE_WAVES) void ct_walk_shadow_tree(con
         // its walk; it is left to the second launch like a ray outside the gate.
         STREE_ARGS();
         if (has_ray && t != kNoHit) {
-            const ctgpu_node *leaf = P.ref_nodes + P.leaf_of_slot[hit_at];
+            const ctgpu_node *leaf = P.ref_nodes + P.leaf_of_slot[hit_at / (uint32_t)sizeof(TriRecord)];
             const double4 b0 = *reinterpret_cast<const double4 *>(&leaf->bmin[0]);     // bmin xyz, bmax x
             const double2 b1 = *reinterpret_cast<const double2 *>(&leaf->bmax[1]);     // bmax yz
             const double bmin[3] = {b0.x, b0.y, b0.z}, bmax[3] = {b0.w, b1.x, b1.y};

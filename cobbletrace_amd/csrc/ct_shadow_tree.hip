@@ -143,7 +143,8 @@ int ctgpu_build_shadow_tree(int device, const void *d_tris, uint32_t n, const ct
     ctst::BuildOptions opt;
     opt.strategy = strategy; opt.leaf_max = leaf_max; opt.leaf_rho = leaf_rho; opt.threads = n < (1u << 16) ? 1u : std::min(hw, 32u);
     const uint32_t need = ctst::build_shadow_tree(boxes.data(), n, opt, gamma, bound, quads, order, remaining);
-    if (need > 63u || quads.size() >= (size_t)kOneBit) return CTGPU_OK;      // (the walk's stack: the lanes of a register)
+    if (need > 63u) return CTGPU_OK;                                         // (the walk's stack: the lanes of a register)
+    if (!ctst::references_to_byte_offsets(quads, n, (uint32_t)sizeof(TriRecord))) return CTGPU_OK;
 
     QuadNode *d_quads = nullptr;
     TriRecord *d_records = nullptr;

@@ -370,5 +370,16 @@ inline uint32_t build_shadow_tree(const Box *boxes, uint32_t n, const BuildOptio
     return need;
 }
 
+// What the walk reads: the same nodes with every reference turned into the BYTE OFFSET of what it names (a node: index *
+// 128; a leaf: kLeaf | first record * record_bytes), so that a visit's scalar loads take the reference as it is.
+// false: an offset would not fit below kLeaf.
+inline bool references_to_byte_offsets(std::vector<Quad> &quads, uint32_t n, uint32_t record_bytes) {
+    if ((uint64_t)quads.size() * sizeof(Quad) >= (uint64_t)kLeaf || (uint64_t)n * record_bytes >= (uint64_t)kLeaf) return false;
+    for (Quad &q : quads)
+        for (int k = 0; k < 4; k++)
+            q.ref[k] = (q.ref[k] & kLeaf) ? (kLeaf | ((q.ref[k] & ~kLeaf) * record_bytes)) : q.ref[k] * (uint32_t)sizeof(Quad);
+    return true;
+}
+
 }  // namespace ctst
 #endif

@@ -211,7 +211,7 @@ typedef struct ctgpu_config {
     int32_t shadow_tree_build;    /* CTGPU_SHADOW_TREE_BUILD  how that tree is split: 0 binned surface-area heuristic (default), 1 object medians */
     int32_t shadow_tree_leaf;     /* CTGPU_SHADOW_TREE_LEAF   most triangles one of its leaves holds (1..4, default 2) ... */
     int32_t shadow_tree_leaf_fill;/* CTGPU_SHADOW_TREE_LEAF_FILL  ... and c > 1 of them only where c - sum(box area of each) / (box area of all) <= this
-                                     percentage of c (default 20): the triangles' boxes nearly fill the leaf's, a box test each would exclude little */
+                                     percentage of c (default 50): the triangles' boxes nearly fill the leaf's, a box test each would exclude little */
     int32_t pack_on_host;         /* CTGPU_PACK=host      1: re-lay-out an uploaded tree on the host (the restatement the device packing is tested against) */
     int32_t thresh[3];            /* CTGPU_THRESH         "a,b,c": general path, lanes that make a phase worth running */
     int32_t walk_thresh[3];       /* CTGPU_WALK_THRESH    "r,a,b": per-lane walk, the same (diagnostic builds: the middle number picks the walk they count) */
