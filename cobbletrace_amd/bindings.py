@@ -221,6 +221,7 @@ _HOST_SYMBOLS = {
     "cth_raythread_reset": (None, []),
     "cth_intersect_bvh": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_int, C.c_void_p]),
     "cth_move_tree_in_place": (C.c_int, [C.c_void_p, C.c_double]),
+    "cth_move_one_triangle": (C.c_int, [C.c_void_p, C.c_uint32, C.c_double]),
     "cth_raythread_frames": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_char_p]),
     "cth_last_frame_stats": (None, [C.POINTER(Stats)]),
 }

@@ -2559,7 +2559,9 @@ void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hip
         mark(2);
         if (shadows) light_gate();
         mark(3);
-        if (shadows && P.stree && !handover) {
+        if (shadows && P.stree && !handover && !ordered) {
+            // (frames whose chunks are handed out heaviest first -- few packets per wave, launches as long as their slowest
+            //  packet -- keep the walk that knows the order; every other frame:)
             // the shadow tree takes the frame's shadow rays; what it leaves (rays outside its gate: shadow byte kShadowLeft,
             // counted in *W.shadow_left) goes through the reference's tree in a launch whose waves return at once on zero
             const dim3 grid_s(W.stree_blocks ? W.stree_blocks : W.walk_blocks);

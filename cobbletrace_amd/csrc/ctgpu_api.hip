@@ -288,7 +288,10 @@ extern "C" int ctgpu_rand_stream(uint32_t seed, uint64_t offset, uint64_t n, int
 
 // ------------------------------------------------------------------ basic entry points
 extern "C" int ctgpu_abi_version(void) { return CTGPU_ABI_VERSION; }
-extern "C" const char *ctgpu_build_id(void) { return CTGPU_BUILD_ID; }
+#ifndef CTGPU_BUILD_VARIANT
+#define CTGPU_BUILD_VARIANT ""           // (diagnostic builds: a suffix that sets their id apart from the product's, Makefile)
+#endif
+extern "C" const char *ctgpu_build_id(void) { return CTGPU_BUILD_ID CTGPU_BUILD_VARIANT; }
 extern "C" const char *ctgpu_last_error(void) { return g_last_error.c_str(); }
 
 extern "C" int ctgpu_device_count(int *count) {
@@ -704,6 +707,10 @@ extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
     if (s->n_triangles == 0 || !s->vertices || !s->materials || (!build_here && (s->n_nodes == 0 || !s->nodes || !s->indexes)))
         return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_upload_scene: empty scene or null array");
     if (s->n_lights && !s->lights) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_upload_scene: null light array");
+    // (leaf references carry two flag bits above the TriRecord slot: kLeafBit, kOneBit -- kSlotMask, ct_device.h)
+    static_assert(kSlotMask == 0x3fffffffu && (kLeafBit | kOneBit | kSlotMask) == 0xffffffffu, "slots and node indices stay below 2^30");
+    if (s->n_triangles >= (1u << 30) || s->n_nodes >= (1u << 31))
+        return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_upload_scene: %u triangles / %u nodes: the walks' references hold slots below 2^30", s->n_triangles, s->n_nodes);
     if (ctx->pending.active) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_upload_scene: a frame is in flight on this context (ctgpu_render_poll)");
     HIP_TRY(hipSetDevice(ctx->device));
     // (frames of this context that may still be running read the old scene: it stays alive until they are done)

@@ -225,6 +225,18 @@ int cth_move_tree_in_place(void *p, double dx) {
     return (int)b.nodesUsed;
 }
 
+// ONE triangle of the scene's own tree moved by (0, 0, dz) where it lies -- no rebuild, no refit, nothing else touched:
+// the smallest edit a caller of the operator-level boundary can make between two queries
+int cth_move_one_triangle(void *p, uint32_t triangle, double dz) {
+    Handle *h = H(p);
+    ensure_packed(h);
+    bvh_state_t &b = h->packed.bvh;
+    if (triangle >= b.triangles.size) return -1;
+    triangle_t &t = b.triangles.data[triangle];
+    t.p1.z += dz; t.p2.z += dz; t.p3.z += dz;
+    return 0;
+}
+
 // First call renders; each byte of `keys` is then delivered as one key-down event followed
 // by one more RayThread call (one frame per key).  Returns the number of RayThread calls.
 int cth_raythread_frames(void *p, int width, int height, uint32_t *fb, const char *keys) {

@@ -309,35 +309,32 @@ struct QueryTree {
     const bvh_node_t *nodes = nullptr;
     const triangle_t *triangles = nullptr;
     uint32_t nodes_used = 0, size = 0;
-    uint64_t fingerprint = 0;             // of a sample of the arrays' CONTENT (tree_fingerprint)
+    uint64_t fingerprint = 0;             // of the arrays' CONTENT, all of it (tree_fingerprint)
 };
 
-// FNV-1a over a SAMPLE of what the walk reads -- the root, up to 256 nodes, index entries and triangles at even strides and
-// the last of each -- so that a tree rebuilt in place, or another tree at a freed one's addresses, is uploaded again (the
-// reference walks whatever is in memory at call time, bvh.cpp:181-222).  An edit that leaves every sampled element as it was
-// is not seen: RayThreadReset() drops the resident copy.  (Hashing everything would cost more than the query's launch.)
+// A hash of EVERYTHING the walk reads -- every node's box, links and count, every index entry, every triangle's three
+// vertices -- so that a tree edited, refitted or rebuilt in place, or another tree at a freed one's addresses, is uploaded again
+// (the reference walks whatever is in memory at call time, bvh.cpp:181-222).  Round 4 hashed a sample of ~257 elements and
+// answered from the old copy when an edit missed all of them; a word-at-a-time multiply-xorshift over the whole tree is
+// ~0.1 ms per megabyte on one core -- nothing for the trees this one-ray-a-call boundary is used with (BvhTest's 256
+// triangles: bvh.cpp:223-310), 20 ms a call at the dragon's size, which is what being right costs there.
 uint64_t tree_fingerprint(const bvh_state_t *state) {
-    uint64_t h = 0xcbf29ce484222325ull;
-    auto mix = [&h](const void *p, size_t n) {
-        const unsigned char *b = static_cast<const unsigned char *>(p);
-        for (size_t i = 0; i < n; i++) h = (h ^ b[i]) * 0x100000001b3ull;
-    };
-    auto sampled = [](uint32_t count, auto &&visit) {
-        if (count == 0) return;
-        const uint32_t step = count / 256u + 1u;
-        for (uint32_t i = 0; i < count; i += step) visit(i);
-        visit(count - 1u);
-    };
-    sampled(state->nodesUsed, [&](uint32_t i) {                    // (the fields, not the struct's padding)
+    uint64_t h = 0x9ae16a3b2f90404full;
+    auto mix = [&h](uint64_t w) { h = (h ^ w) * 0x9e3779b97f4a7c15ull; h ^= h >> 29; };
+    auto word = [](const void *p) { uint64_t w; std::memcpy(&w, p, 8); return w; };
+    for (uint32_t i = 0; i < state->nodesUsed; i++) {                // (the fields, not the struct's padding)
         const bvh_node_t &n = state->bvhNodes[i];
-        mix(&n.aabbMin, sizeof n.aabbMin); mix(&n.aabbMax, sizeof n.aabbMax);
-        mix(&n.leftNode, 4); mix(&n.firstTriangleIndex, 4); mix(&n.triangleCount, 4);
-    });
-    sampled(state->triangles.size, [&](uint32_t i) {
-        mix(&state->triangles.indexes[i], 4);
+        const double box[6] = {n.aabbMin.x, n.aabbMin.y, n.aabbMin.z, n.aabbMax.x, n.aabbMax.y, n.aabbMax.z};
+        for (int k = 0; k < 6; k++) mix(word(&box[k]));
+        mix((uint64_t)n.leftNode | ((uint64_t)n.firstTriangleIndex << 32));
+        mix((uint64_t)n.triangleCount);
+    }
+    for (uint32_t i = 0; i < state->triangles.size; i++) {
         const triangle_t &t = state->triangles.data[i];
-        mix(&t.p1, sizeof t.p1); mix(&t.p2, sizeof t.p2); mix(&t.p3, sizeof t.p3);
-    });
+        const double v[9] = {t.p1.x, t.p1.y, t.p1.z, t.p2.x, t.p2.y, t.p2.z, t.p3.x, t.p3.y, t.p3.z};
+        for (int k = 0; k < 9; k++) mix(word(&v[k]));
+        mix((uint64_t)state->triangles.indexes[i]);
+    }
     return h;
 }
 

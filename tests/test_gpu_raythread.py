@@ -307,3 +307,42 @@ def test_operator_level_boundary_sees_a_tree_rebuilt_in_place():
     finally:
         ca.host_library().cth_raythread_reset()
         scene.close()
+
+
+def test_operator_level_boundary_sees_one_triangle_moved():
+    """The smallest edit: ONE triangle of a 120,000-triangle tree moved where it lies, nothing rebuilt -- addresses, counts and
+    every other element as they were (round 4's fingerprint sampled ~257 elements and missed such an edit).  The ray that hit
+    that triangle must not hit it any more."""
+    rng = np.random.default_rng(21)
+    n = 120000
+    centres = rng.random((n, 1, 3)) * np.array([40.0, 40.0, 4.0]) + np.array([-20.0, -20.0, 6.0])
+    verts = (centres + rng.normal(size=(n, 3, 3)) * 0.05).reshape(n, 9)
+    scene = ca.HostScene(vertices=verts)
+    try:
+        def ask(rays):
+            got = np.zeros(len(rays), dtype=ca.bindings.HIT_DTYPE)
+            assert scene.lib.cth_intersect_bvh(scene.handle, rays.ctypes.data, len(rays), 1, got.ctypes.data) == 0
+            return got
+        # rays through the middle of triangles 1000 .. 1015 (not one of them a multiple of anything a sampler would pick)
+        picked = np.arange(1000, 1016) * 7 + 3
+        mid = verts[picked].reshape(-1, 3, 3).mean(axis=1)
+        rays = np.zeros(len(picked), dtype=ca.bindings.RAY_DTYPE)
+        rays["origin"] = np.array([0.0, 0.0, -30.0])
+        rays["direction"] = mid - rays["origin"]
+        rays["t"] = np.float32(1e30)
+        before = ask(rays)
+        hit_own = before["triangle"] == picked
+        assert hit_own.sum() >= 8                         # (some are hidden behind others)
+        victim = int(picked[np.nonzero(hit_own)[0][0]])
+        assert scene.lib.cth_move_one_triangle(scene.handle, victim, 1000.0) == 0
+        after = ask(rays)
+        k = int(np.nonzero(picked == victim)[0][0])
+        assert after["triangle"][k] != victim or after["found"][k] == 0, "answered from the tree as it was"
+        others = np.arange(len(picked)) != k
+        assert (after["triangle"][others] == before["triangle"][others]).all()
+        assert scene.lib.cth_move_one_triangle(scene.handle, victim, -1000.0) == 0
+        again = ask(rays)
+        assert (again["triangle"] == before["triangle"]).all() and (again["t"].view(np.uint32) == before["t"].view(np.uint32)).all()
+    finally:
+        ca.host_library().cth_raythread_reset()
+        scene.close()

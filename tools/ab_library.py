@@ -32,7 +32,7 @@ reps = int(rest[1]) if len(rest) > 1 else 3
 for r in range(reps):
     for label, lib in [(os.path.basename(o)[:-3].replace("libctgpu_", "").ljust(10), o) for o in others] + [("current".ljust(10), None)]:
         env = dict(os.environ, AB_CHILD="1")
-        if lib: env.update(CTGPU_LIBRARY=lib, CTGPU_OLDER_LIBRARY="1")
+        if lib: env.update(CTGPU_LIBRARY=lib, CTGPU_OLDER_LIBRARY="1", CTGPU_ALLOW_FOREIGN_LIBRARY="1")
         out = subprocess.run([sys.executable, os.path.abspath(__file__), name], env=env, capture_output=True, text=True)
         for line in out.stdout.splitlines():
             if line.startswith("RESULT"): print("%s %s %s" % (name, label, line[7:]), flush=True)

@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for which in current other; do
   rm -rf $R/gpurun_out/pmc_$which
-  if [ $which = other ]; then export CTGPU_LIBRARY=$other; fi
+  if [ $which = other ]; then export CTGPU_LIBRARY=$other CTGPU_ALLOW_FOREIGN_LIBRARY=1 CTGPU_OLDER_LIBRARY=1; fi
   rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU --output-format csv -d $R/gpurun_out/pmc_$which -- python3 $R/bench.py --steps 4 --warmup 1 --no-cpu-baseline --inflight 1 > $R/gpurun_out/pmc_$which.log 2>&1 || { tail -5 $R/gpurun_out/pmc_$which.log; exit 1; }
 done
 python3 - <<PY > $R/gpurun_out/pmc_compare.txt

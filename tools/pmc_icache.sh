@@ -1,3 +1,4 @@
+#!/bin/bash
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 rm -rf $R/gpurun_out/pmc_icache
