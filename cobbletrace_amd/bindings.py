@@ -64,7 +64,15 @@ class FrameDesc(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("rays_primary", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_reflect", C.c_uint64),
                 ("pixels_written", C.c_uint64), ("node_visits", C.c_uint64), ("triangle_tests", C.c_uint64),
-                ("kernel_ms", C.c_double), ("total_ms", C.c_double), ("rays_shadow_elided", C.c_uint64)]
+                ("kernel_ms", C.c_double), ("total_ms", C.c_double), ("rays_shadow_elided", C.c_uint64),
+                ("walk_kind", C.c_uint32), ("bounce_kind", C.c_uint32), ("ordered", C.c_uint32), ("cull_tree", C.c_uint32),
+                ("shadow_tree", C.c_uint32), ("pad_", C.c_uint32), ("rays_shadow_left", C.c_uint64)]
+
+    def path(self):
+        """which code rendered the frame, as a dict (ctgpu.h CTGPU_WALK_* / CTGPU_BOUNCE_*)"""
+        return {"walk": ("general", "per-lane", "packet")[self.walk_kind], "bounce": ("none", "levels", "general")[self.bounce_kind],
+                "ordered": bool(self.ordered), "cull_tree": bool(self.cull_tree), "shadow_tree": bool(self.shadow_tree),
+                "shadow_rays_left": int(self.rays_shadow_left)}
 
     @property
     def rays(self):
@@ -136,6 +144,10 @@ class Hit(C.Structure):
 
 RAY_DTYPE = np.dtype([("origin", "<f8", 3), ("direction", "<f8", 3), ("t", "<f4"), ("pad_", "<u4")])
 HIT_DTYPE = np.dtype([("t", "<f4"), ("tclosest", "<f4"), ("triangle", "<u4"), ("found", "<u4")])
+
+
+WALK_GENERAL, WALK_PER_LANE, WALK_PACKET = 0, 1, 2          # ctgpu_stats.walk_kind
+BOUNCE_NONE, BOUNCE_LEVELS, BOUNCE_GENERAL = 0, 1, 2        # ctgpu_stats.bounce_kind
 
 
 def identity_rotation():

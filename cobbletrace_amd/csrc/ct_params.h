@@ -15,7 +15,9 @@ namespace ctd {
 // 17 / 18 primary / shadow rays the packet walk handed over to the per-lane walk; 19..23 triangle-test stages (CT_TRI_STATS);
 // 24..47 histograms of the CT_WALK_STATS build, eight bins of eight lanes each: node visits, triangle tests and packets by
 // the number of rays taking part (tools/lane_stats.py)
-constexpr int kCounterWords = 48;
+// 48 shadow rays ct_walk_shadow_tree left to the second shadow launch
+constexpr int kCounterWords = 50;
+constexpr int kCounterLeft = 48;
 // ray-queue head words: walk 0 primary rays, walks 1..L the shadow rays of the scene's L shadow-casting lights, walks
 // L+1 / L+2 the handed-over primary / shadow rays, walks L+3..2L+2 the same lights' shadow rays once more (the second
 // shadow launch of a frame whose shadow rays walk the shadow tree: the rays that tree does not take, ct_walk_shadow_tree);

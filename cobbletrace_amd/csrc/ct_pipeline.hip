@@ -1697,7 +1697,9 @@ __device__ __forceinline__ ScalarTri scalar_load_tri_at(const void *base, const 
                  : "memory");
     return r;
 }
-template <bool SS>
+// ORDERED: as in ct_walk_packet -- the chunks the frame before found heavy come first (in parts where its packets were few),
+// then the run over all chunks skips them; every packet adds its fetches to its chunk's cost word.
+template <bool SS, bool ORDERED = false>
 __global__ __launch_bounds__(kWave, CT_STREE_WAVES) void ct_walk_shadow_tree(const FrameParams P_launch, const PipelineParams W_launch) {
     FrameParams P = P_launch;
     PipelineParams W = W_launch;
@@ -1731,6 +1733,7 @@ __global__ __launch_bounds__(kWave, CT_STREE_WAVES) void ct_walk_shadow_tree(con
     uint32_t win_pos = 0, win_count = 0;
     uint64_t win_base = 0;
     uint32_t n_packets = 0, n_quads = 0, n_records = 0, n_blocked = 0, n_all_blocked = 0;
+    uint32_t order_phase = ORDERED ? 0u : 2u, order_at = blockIdx.x, chunk_cost_at = 0, cost_at = 0, cost_mark = 0;
 
     for (;;) {
         STREE_ARGS();
@@ -1745,6 +1748,33 @@ __global__ __launch_bounds__(kWave, CT_STREE_WAVES) void ct_walk_shadow_tree(con
             }
             if (wave_drained) break;
             if (chunk_next >= chunk_end) {
+                bool from_list = false;
+                if (ORDERED && order_phase < 2u) {
+                    // the heavy lists, heaviest class first: wave b takes entries b, b + grid, ... (ct_walk_packet)
+                    const OrderParams &O = W.order[1];
+                    uint32_t at = order_at, cls = 0;
+                    for (; cls < (uint32_t)kOrderClasses; cls++) {
+                        uint32_t listed_entries = (uint32_t)__builtin_amdgcn_readfirstlane((int)O.count[cls]);
+                        if (listed_entries > O.cap) listed_entries = O.cap;
+                        if (at < listed_entries) break;
+                        at -= listed_entries;
+                    }
+                    if (cls == (uint32_t)kOrderClasses) { order_phase = 2u; continue; }
+                    order_at += gridDim.x;
+                    const uint4 e = O.list[(size_t)cls * O.cap + at];
+                    const uint32_t e_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.x), e_n = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.y);
+                    const uint32_t e_light = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.z);
+                    if (e_lo == ~0u || e_lo >= n_samples || e_light >= W.n_shadow_lights) continue;
+                    uint64_t hi = (uint64_t)e_lo + e_n;
+                    if (hi > n_samples) hi = n_samples;
+                    chunk_light_base = (uint64_t)e_light * n_samples;
+                    chunk_next = chunk_light_base + e_lo;
+                    chunk_end = chunk_light_base + hi;
+                    chunk_cost_at = (uint32_t)__builtin_amdgcn_readfirstlane((int)e.w);
+                    chunk_light_index = (uint32_t)__builtin_amdgcn_readfirstlane((int)W.shadow_lights[e_light]);
+                    from_list = true;
+                }
+                if (!from_list) {
                 unsigned long long offset = 0;
                 if (lane == 0) offset = atomicAdd(heads + (size_t)shard * 16u, (unsigned long long)q_chunk);
                 offset = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)offset) |
@@ -1757,6 +1787,11 @@ __global__ __launch_bounds__(kWave, CT_STREE_WAVES) void ct_walk_shadow_tree(con
                     if (shards_done >= n_shards) wave_drained = true;
                     continue;
                 }
+                if (ORDERED) {
+                    const OrderParams &O = W.order[1];
+                    chunk_cost_at = light * O.chunks_per_light + (uint32_t)(lo >> O.chunk_shift);
+                    if (__builtin_amdgcn_readfirstlane((int)O.listed[chunk_cost_at]) != 0) continue;      // went out with the heavy lists
+                }
                 uint64_t hi = lo + q_chunk;
                 if (hi > ((uint64_t)part + 1u) * shard_span) hi = ((uint64_t)part + 1u) * shard_span;
                 if (hi > n_samples) hi = n_samples;
@@ -1764,6 +1799,7 @@ __global__ __launch_bounds__(kWave, CT_STREE_WAVES) void ct_walk_shadow_tree(con
                 chunk_next = chunk_light_base + lo;
                 chunk_end = chunk_light_base + hi;
                 chunk_light_index = (uint32_t)__builtin_amdgcn_readfirstlane((int)W.shadow_lights[light]);
+                }
             }
             // open the next window of the chunk: which of its ids are rays
             const uint32_t n_ids = chunk_end - chunk_next < 128u ? (uint32_t)(chunk_end - chunk_next) : 128u;
@@ -1781,11 +1817,13 @@ __global__ __launch_bounds__(kWave, CT_STREE_WAVES) void ct_walk_shadow_tree(con
             chunk_next += n_ids;
             light_base = chunk_light_base;
             light_index = chunk_light_index;
+            if (ORDERED) cost_at = chunk_cost_at;
         }
         if (__ballot(has_ray) == 0ull) {
             if (wave_drained) break;
             continue;
         }
+        if (ORDERED) cost_mark = n_quads + n_records;
         // ---------------- the rays (raythread.cpp:360, 289-303), and which of them the shadow tree takes
         STREE_ARGS();
         bool left = false;
@@ -1944,6 +1982,7 @@ __global__ __launch_bounds__(kWave, CT_STREE_WAVES) void ct_walk_shadow_tree(con
             n_traced -= undone;
         }
         // ---------------- retire the packet
+        if (ORDERED && lane == 0) atomicAdd(W.order[1].cost_out + cost_at, n_quads + n_records - cost_mark);
         {
             const unsigned long long blocked = __ballot(has_ray && t != kNoHit);
             n_blocked += (uint32_t)__popcll(blocked);
@@ -1954,13 +1993,18 @@ __global__ __launch_bounds__(kWave, CT_STREE_WAVES) void ct_walk_shadow_tree(con
 
     if (lane == 0) {
         atomicAdd(&P.counters[1], (unsigned long long)n_traced);
-        if (n_left) atomicAdd(W.shadow_left, (unsigned long long)n_left);
+        if (n_left) { atomicAdd(W.shadow_left, (unsigned long long)n_left); atomicAdd(&P.counters[kCounterLeft], (unsigned long long)n_left); }
         unsigned long long *work = W.walk_work + (size_t)(blockIdx.x & 63u) * 8u;
         atomicAdd(work + 3, (unsigned long long)n_packets);
         atomicAdd(work + 4, (unsigned long long)n_quads);
         atomicAdd(work + 5, (unsigned long long)n_records);
         atomicAdd(work + 6, (unsigned long long)n_blocked);
         atomicAdd(work + 7, (unsigned long long)n_all_blocked);
+        if (ORDERED) {
+            unsigned long long *totals = W.order[1].totals_out + (size_t)(blockIdx.x & 63u) * 2u;
+            atomicAdd(totals + 0, (unsigned long long)(n_quads + n_records));
+            atomicAdd(totals + 1, (unsigned long long)n_packets);
+        }
     }
 }
 #undef STREE_ARGS
@@ -2429,9 +2473,12 @@ int pipeline_packet_occupancy(uint32_t depth, uint32_t lds_levels) {
 
 int pipeline_stree_occupancy() {
     int a = 0, b = 0;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, ct_walk_shadow_tree<true>, kWave, 512);
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, ct_walk_shadow_tree<false>, kWave, 512);
-    return a < b ? a : b;
+    int c = 0, e = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, ct_walk_shadow_tree<true, false>, kWave, 512);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, ct_walk_shadow_tree<false, false>, kWave, 512);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, ct_walk_shadow_tree<true, true>, kWave, 512);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&e, ct_walk_shadow_tree<false, true>, kWave, 512);
+    return std::min(std::min(a, b), std::min(c, e));
 }
 
 // ct_order_build: the heavy lists of this frame's two packet walks from the costs the frame before left (blockIdx.y:
@@ -2559,14 +2606,14 @@ void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hip
         mark(2);
         if (shadows) light_gate();
         mark(3);
-        if (shadows && P.stree && !handover && !ordered) {
-            // (frames whose chunks are handed out heaviest first -- few packets per wave, launches as long as their slowest
-            //  packet -- keep the walk that knows the order; every other frame:)
+        if (shadows && P.stree && !handover) {
             // the shadow tree takes the frame's shadow rays; what it leaves (rays outside its gate: shadow byte kShadowLeft,
             // counted in *W.shadow_left) goes through the reference's tree in a launch whose waves return at once on zero
             const dim3 grid_s(W.stree_blocks ? W.stree_blocks : W.walk_blocks);
-            if (ss) hipLaunchKernelGGL((ct_walk_shadow_tree<true>), grid_s, wave, 512, stream, P, W);
-            else hipLaunchKernelGGL((ct_walk_shadow_tree<false>), grid_s, wave, 512, stream, P, W);
+            if (ss && ordered) hipLaunchKernelGGL((ct_walk_shadow_tree<true, true>), grid_s, wave, 512, stream, P, W);
+            if (ss && !ordered) hipLaunchKernelGGL((ct_walk_shadow_tree<true, false>), grid_s, wave, 512, stream, P, W);
+            if (!ss && ordered) hipLaunchKernelGGL((ct_walk_shadow_tree<false, true>), grid_s, wave, 512, stream, P, W);
+            if (!ss && !ordered) hipLaunchKernelGGL((ct_walk_shadow_tree<false, false>), grid_s, wave, 512, stream, P, W);
             PipelineParams Wl = W;
             Wl.shadow_live = kShadowLeft;
             launch_frame_walk<1>(ss, false, false, P.cull_first != kNoNode, grid, wave, lds_p, stream, P, Wl);

@@ -21,6 +21,8 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <condition_variable>
 #include <cstring>
 #include <mutex>
@@ -141,7 +143,10 @@ int ctgpu_build_shadow_tree(int device, const void *d_tris, uint32_t n, const ct
     std::vector<ctst::Quad> quads;
     std::vector<uint32_t> order, remaining;
     ctst::BuildOptions opt;
-    opt.strategy = strategy; opt.leaf_max = leaf_max; opt.leaf_rho = leaf_rho; opt.threads = n < (1u << 16) ? 1u : std::min(hw, 32u);
+    opt.strategy = strategy; opt.leaf_max = leaf_max; opt.leaf_rho = leaf_rho; opt.threads = n < (1u << 16) ? 1u : std::min(hw, 16u);      // (a one-GPU box gives a process 16 cores)
+    double phase_ms[3] = {0, 0, 0};
+    opt.phase_ms = phase_ms;
+    const double before_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     const uint32_t need = ctst::build_shadow_tree(boxes.data(), n, opt, gamma, bound, quads, order, remaining);
     if (need > 63u) return CTGPU_OK;                                         // (the walk's stack: the lanes of a register)
     if (!ctst::references_to_byte_offsets(quads, n, (uint32_t)sizeof(TriRecord))) return CTGPU_OK;
@@ -175,5 +180,9 @@ int ctgpu_build_shadow_tree(int device, const void *d_tris, uint32_t n, const ct
     out->gamma = gamma;
     out->usable = true;
     out->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (std::getenv("CTGPU_DEBUG_SHADOW_TREE"))
+        std::fprintf(stderr, "shadow tree: %u triangles, %zu nodes; boxes + checks + copy down %.1f ms, binary tree %.1f ms (%u threads), four-wide %.1f ms, "
+                     "emit %.1f ms, copies up + records %.1f ms\n", n, quads.size(), before_ms, phase_ms[0], opt.threads, phase_ms[1], phase_ms[2],
+                     out->build_ms - before_ms - phase_ms[0] - phase_ms[1] - phase_ms[2]);
     return CTGPU_OK;
 }

@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstdint>
@@ -44,7 +45,22 @@ struct BinNode { Box box; uint32_t left, first, count; };
 
 constexpr int kBins = 16;
 constexpr uint32_t kSequentialBelow = 1u << 15;      // ranges a worker thread builds alone
+constexpr uint32_t kParallelAbove = 1u << 17;        // ranges whose passes over the triangles are cut into chunks for several threads
 constexpr uint32_t kMedianBelowDepth = 56;           // deeper than this the splits are medians (a bound on the depth)
+
+// fn(chunk, begin, end) over [0, count) cut into `chunks` pieces, one thread each (the caller's included)
+template <typename F>
+inline void in_chunks(uint32_t count, unsigned chunks, F &&fn) {
+    if (chunks <= 1u) { fn(0u, 0u, count); return; }
+    std::vector<std::thread> pool;
+    const uint32_t step = (count + chunks - 1u) / chunks;
+    for (unsigned c = 1; c < chunks; c++) {
+        const uint32_t b = std::min(count, c * step), e = std::min(count, (c + 1u) * step);
+        pool.emplace_back([&fn, c, b, e] { fn(c, b, e); });
+    }
+    fn(0u, 0u, std::min(count, step));
+    for (auto &t : pool) t.join();
+}
 
 struct Builder {
     const Box *tri;                   // [n] the triangles' boxes
@@ -56,6 +72,7 @@ struct Builder {
     float leaf_rho = 0.2f;            // ... and it holds c > 1 only if  c - sum(area_i) / area(leaf) <= rho c:  the triangles' boxes
                                       // fill the leaf's (the two halves of a grid cell have the cell's box each), so that a box test
                                       // per triangle (rho of a triangle test's cost) would exclude too little to pay for itself
+    unsigned threads = 1;
 
     std::mutex lock;
     std::condition_variable wake;
@@ -64,8 +81,9 @@ struct Builder {
     bool done = false;
 
     static float centre(const Box &b, int a) { return 0.5f * (b.lo[a] + b.hi[a]); }
+    struct Bins { Box box[3][kBins]; uint32_t n[3][kBins]; };
 
-    // split node `id` in place (its range of `order`); false: it stays a leaf (one triangle)
+    // split node `id` in place (its range of `order`); false: it stays a leaf
     bool split(uint32_t id, uint32_t depth) {
         BinNode &node = nodes[id];
         if (node.count <= 1u) return false;
@@ -77,52 +95,83 @@ struct Builder {
             for (uint32_t i = 0; i < count; i++) parts += tri[idx[i]].half_area();
             if (!(whole > 0.0f) || (float)count - parts / whole <= leaf_rho * (float)count) return false;
         }
-        uint32_t mid = 0;
+        const unsigned chunks = (count >= kParallelAbove && threads > 1u) ? std::min(threads, 16u) : 1u;
+        // pass 1: the centres' bounds
         float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
-        for (uint32_t i = 0; i < count; i++)
-            for (int a = 0; a < 3; a++) { const float c = centre(tri[idx[i]], a); clo[a] = std::min(clo[a], c); chi[a] = std::max(chi[a], c); }
-        int best_axis = -1, best_bin = 0;
-        float best_cost = INFINITY;
-        if (!median_only && depth < kMedianBelowDepth) {
-            for (int a = 0; a < 3; a++) {
-                const float extent = chi[a] - clo[a];
-                if (!(extent > 0.0f) || !std::isfinite(extent)) continue;
-                Box bin_box[kBins];
-                uint32_t bin_n[kBins];
-                for (int b = 0; b < kBins; b++) { bin_box[b].clear(); bin_n[b] = 0; }
-                const float scale = (float)kBins / extent;
-                for (uint32_t i = 0; i < count; i++) {
-                    int b = (int)((centre(tri[idx[i]], a) - clo[a]) * scale);
-                    b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
-                    bin_n[b] += 1; bin_box[b].grow(tri[idx[i]]);
+        {
+            std::vector<float> part((size_t)chunks * 6);
+            in_chunks(count, chunks, [&](unsigned c, uint32_t b, uint32_t e) {
+                float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+                for (uint32_t i = b; i < e; i++)
+                    for (int a = 0; a < 3; a++) { const float v = centre(tri[idx[i]], a); lo[a] = std::min(lo[a], v); hi[a] = std::max(hi[a], v); }
+                for (int a = 0; a < 3; a++) { part[(size_t)c * 6 + a] = lo[a]; part[(size_t)c * 6 + 3 + a] = hi[a]; }
+            });
+            for (unsigned c = 0; c < chunks; c++)
+                for (int a = 0; a < 3; a++) { clo[a] = std::min(clo[a], part[(size_t)c * 6 + a]); chi[a] = std::max(chi[a], part[(size_t)c * 6 + 3 + a]); }
+        }
+        uint32_t mid = 0;
+        Box left_box, right_box;
+        left_box.clear(); right_box.clear();
+        bool boxes_known = false;
+        float scale[3];
+        bool usable[3];
+        bool any_axis = false;
+        for (int a = 0; a < 3; a++) {
+            const float extent = chi[a] - clo[a];
+            usable[a] = extent > 0.0f && std::isfinite(extent);
+            scale[a] = usable[a] ? (float)kBins / extent : 0.0f;
+            any_axis = any_axis || usable[a];
+        }
+        const auto bin_of = [&](uint32_t s, int a) {
+            int b = (int)((centre(tri[s], a) - clo[a]) * scale[a]);
+            return b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+        };
+        if (!median_only && depth < kMedianBelowDepth && any_axis) {
+            // pass 2: the three axes' bins at once
+            std::vector<Bins> part(chunks);
+            in_chunks(count, chunks, [&](unsigned c, uint32_t b, uint32_t e) {
+                Bins &B = part[c];
+                for (int a = 0; a < 3; a++) for (int k = 0; k < kBins; k++) { B.box[a][k].clear(); B.n[a][k] = 0; }
+                for (uint32_t i = b; i < e; i++) {
+                    const Box &t = tri[idx[i]];
+                    for (int a = 0; a < 3; a++) {
+                        if (!usable[a]) continue;
+                        const int k = bin_of(idx[i], a);
+                        B.n[a][k] += 1; B.box[a][k].grow(t);
+                    }
                 }
+            });
+            Bins &B = part[0];
+            for (unsigned c = 1; c < chunks; c++)
+                for (int a = 0; a < 3; a++) for (int k = 0; k < kBins; k++) if (part[c].n[a][k]) { B.n[a][k] += part[c].n[a][k]; B.box[a][k].grow(part[c].box[a][k]); }
+            int best_axis = -1, best_bin = 0;
+            float best_cost = INFINITY;
+            for (int a = 0; a < 3; a++) {
+                if (!usable[a]) continue;
                 float right_area[kBins];
                 uint32_t right_n[kBins];
                 Box acc; acc.clear();
                 uint32_t n_acc = 0;
                 for (int b = kBins - 1; b > 0; b--) {
-                    if (bin_n[b]) acc.grow(bin_box[b]);
-                    n_acc += bin_n[b];
+                    if (B.n[a][b]) acc.grow(B.box[a][b]);
+                    n_acc += B.n[a][b];
                     right_area[b] = n_acc ? acc.half_area() : 0.0f; right_n[b] = n_acc;
                 }
                 acc.clear(); n_acc = 0;
                 for (int b = 0; b + 1 < kBins; b++) {
-                    if (bin_n[b]) acc.grow(bin_box[b]);
-                    n_acc += bin_n[b];
+                    if (B.n[a][b]) acc.grow(B.box[a][b]);
+                    n_acc += B.n[a][b];
                     if (n_acc == 0 || right_n[b + 1] == 0) continue;
                     const float cost = acc.half_area() * (float)n_acc + right_area[b + 1] * (float)right_n[b + 1];
                     if (cost < best_cost) { best_cost = cost; best_axis = a; best_bin = b; }
                 }
             }
-        }
-        if (best_axis >= 0) {
-            const int a = best_axis;
-            const float scale = (float)kBins / (chi[a] - clo[a]);
-            mid = (uint32_t)(std::partition(idx, idx + count, [&](uint32_t s) {
-                int b = (int)((centre(tri[s], a) - clo[a]) * scale);
-                b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
-                return b <= best_bin;
-            }) - idx);
+            if (best_axis >= 0) {
+                const int a = best_axis;
+                mid = (uint32_t)(std::partition(idx, idx + count, [&](uint32_t s) { return bin_of(s, a) <= best_bin; }) - idx);
+                for (int b = 0; b < kBins; b++) if (B.n[a][b]) (b <= best_bin ? left_box : right_box).grow(B.box[a][b]);
+                boxes_known = true;
+            }
         }
         if (mid == 0 || mid == count) {
             // no plane separates the centres (or the depth bound is reached): the median along the widest axis
@@ -133,14 +182,18 @@ struct Builder {
                 const float cx = centre(tri[x], a), cy = centre(tri[y], a);
                 return cx < cy || (cx == cy && x < y);
             });
+            boxes_known = false;
         }
         const uint32_t left = used.fetch_add(2u);
         BinNode &l = nodes[left], &r = nodes[left + 1];
         l.first = node.first; l.count = mid; l.left = 0;
         r.first = node.first + mid; r.count = count - mid; r.left = 0;
-        l.box.clear(); r.box.clear();
-        for (uint32_t i = 0; i < mid; i++) l.box.grow(tri[idx[i]]);
-        for (uint32_t i = mid; i < count; i++) r.box.grow(tri[idx[i]]);
+        if (boxes_known) { l.box = left_box; r.box = right_box; }
+        else {
+            l.box.clear(); r.box.clear();
+            for (uint32_t i = 0; i < mid; i++) l.box.grow(tri[idx[i]]);
+            for (uint32_t i = mid; i < count; i++) r.box.grow(tri[idx[i]]);
+        }
         node.left = left;
         return true;
     }
@@ -179,14 +232,20 @@ struct Builder {
             }
         }
     }
-    void run(uint32_t n, unsigned threads) {
+    void run(uint32_t n, unsigned n_threads) {
+        threads = std::max(1u, n_threads);
         order.resize(n);
-        for (uint32_t i = 0; i < n; i++) order[i] = i;
         nodes.resize(2u * (size_t)n);
         BinNode &root = nodes[0];
         root.first = 0; root.count = n; root.left = 0;
+        const unsigned chunks = (n >= kParallelAbove && threads > 1u) ? std::min(threads, 16u) : 1u;
+        std::vector<Box> part(chunks);
+        in_chunks(n, chunks, [&](unsigned c, uint32_t b, uint32_t e) {
+            part[c].clear();
+            for (uint32_t i = b; i < e; i++) { order[i] = i; part[c].grow(tri[i]); }
+        });
         root.box.clear();
-        for (uint32_t i = 0; i < n; i++) root.box.grow(tri[i]);
+        for (unsigned c = 0; c < chunks; c++) root.box.grow(part[c]);
         todo.push_back({0u, 0u});
         std::vector<std::thread> pool;
         for (unsigned t = 1; t < threads; t++) pool.emplace_back([this] { worker(); });
@@ -194,85 +253,6 @@ struct Builder {
         for (auto &t : pool) t.join();
     }
 };
-
-// ------------------------------------------------------------------ four entries a node
-struct QuadEntry { Box box; uint32_t bin; bool triangle; };        // bin: the binary node the entry stands for; triangle: a leaf (a run of triangles)
-struct QuadDraft {
-    QuadEntry entry[4];
-    uint32_t count;
-    uint32_t need;          // most entries waiting on the walk's stack anywhere below, this node's own included
-    uint32_t child[4];      // draft index of an inner entry
-};
-
-struct Collapser {
-    const std::vector<BinNode> &bin;
-    const std::vector<uint32_t> &order;
-    std::vector<QuadDraft> drafts;
-    explicit Collapser(const Builder &b) : bin(b.nodes), order(b.order) {}
-
-    // the node that stands for binary node `id` (an inner one): its two children, the one with the largest box opened in
-    // turn until four entries are there or only triangles are left
-    uint32_t make(uint32_t root_bin) {
-        // (explicit stack: post-order, so that a node's `need` sees its children's)
-        struct Frame { uint32_t bin, draft, next_child; };
-        std::vector<Frame> stack;
-        const auto open = [&](uint32_t id) -> uint32_t {
-            QuadDraft q;
-            q.count = 0; q.need = 0;
-            uint32_t ids[4];
-            ids[q.count++] = bin[id].left; ids[q.count++] = bin[id].left + 1;
-            while (q.count < 4u) {
-                int widest = -1;
-                float area = -1.0f;
-                for (uint32_t k = 0; k < q.count; k++)
-                    if (bin[ids[k]].left != 0u && bin[ids[k]].box.half_area() > area) { area = bin[ids[k]].box.half_area(); widest = (int)k; }
-                if (widest < 0) break;
-                const uint32_t opened = ids[widest];
-                ids[widest] = bin[opened].left;
-                ids[q.count++] = bin[opened].left + 1;
-            }
-            for (uint32_t k = 0; k < q.count; k++) {
-                q.entry[k].box = bin[ids[k]].box; q.entry[k].bin = ids[k]; q.entry[k].triangle = bin[ids[k]].left == 0u;
-                q.child[k] = 0;
-            }
-            drafts.push_back(q);
-            return (uint32_t)drafts.size() - 1u;
-        };
-        const uint32_t root = open(root_bin);
-        stack.push_back({root_bin, root, 0u});
-        while (!stack.empty()) {
-            Frame &f = stack.back();
-            const uint32_t me = f.draft;
-            if (f.next_child < drafts[me].count) {
-                const uint32_t k = f.next_child++;
-                if (!drafts[me].entry[k].triangle) {
-                    const uint32_t child_bin = drafts[me].entry[k].bin;
-                    const uint32_t made = open(child_bin);         // (may move `drafts`: no reference is held across it)
-                    drafts[me].child[k] = made;
-                    stack.push_back({child_bin, made, 0u});
-                }
-                continue;
-            }
-            // all children are final: order the entries -- triangles first, then subtrees by what they need of the stack,
-            // least first -- so that the deepest subtree is entered with nothing of this node waiting
-            QuadDraft &q = drafts[me];
-            uint32_t perm[4] = {0, 1, 2, 3};
-            const auto key = [&](uint32_t k) { return q.entry[k].triangle ? 0u : 1u + drafts[q.child[k]].need; };
-            std::stable_sort(perm, perm + q.count, [&](uint32_t x, uint32_t y) { return key(x) < key(y); });
-            QuadDraft sorted = q;
-            for (uint32_t k = 0; k < q.count; k++) { sorted.entry[k] = q.entry[perm[k]]; sorted.child[k] = q.child[perm[k]]; }
-            sorted.need = 0;
-            for (uint32_t k = 0; k < q.count; k++) {
-                const uint32_t below = sorted.entry[k].triangle ? 0u : drafts[sorted.child[k]].need;
-                sorted.need = std::max(sorted.need, q.count - 1u - k + below);
-            }
-            q = sorted;
-            stack.pop_back();
-        }
-        return root;
-    }
-};
-
 
 // a plane moved outward by gamma and rounded outward to binary32
 inline float plane_down(float p, double gamma) {
@@ -283,12 +263,73 @@ inline float plane_down(float p, double gamma) {
 }
 inline float plane_up(float p, double gamma) { return -plane_down(-p, gamma); }
 
+// ------------------------------------------------------------------ four entries a node
+// The node that stands for an inner binary node: its two children, the one with the largest box opened in turn until four
+// entries are there or only leaves are left.  Per binary node that heads a four-wide node: its entries (binary node ids, in
+// the order the walk will meet them), how many, what its subtree needs of the walk's stack, how many four-wide nodes it
+// holds.  Entries are ordered leaves first, then subtrees by their need, least first: the deepest subtree is entered with
+// nothing of this node waiting, need(node) = max over k of (count - 1 - k + need(entry k)).
+struct FourWide {
+    const std::vector<BinNode> &bin;
+    std::vector<uint32_t> entry;      // [bin][4]
+    std::vector<uint8_t> count;       // [bin] 0: not (yet) a four-wide node's head
+    std::vector<uint32_t> need, size; // [bin]
+    explicit FourWide(const Builder &b) : bin(b.nodes), entry(b.nodes.size() * 4u), count(b.nodes.size(), 0), need(b.nodes.size(), 0), size(b.nodes.size(), 0) {}
+
+    uint32_t open(uint32_t id, uint32_t ids[4]) const {
+        uint32_t n = 0;
+        ids[n++] = bin[id].left; ids[n++] = bin[id].left + 1;
+        while (n < 4u) {
+            int widest = -1;
+            float area = -1.0f;
+            for (uint32_t k = 0; k < n; k++)
+                if (bin[ids[k]].left != 0u && bin[ids[k]].box.half_area() > area) { area = bin[ids[k]].box.half_area(); widest = (int)k; }
+            if (widest < 0) break;
+            const uint32_t opened = ids[widest];
+            ids[widest] = bin[opened].left;
+            ids[n++] = bin[opened].left + 1;
+        }
+        return n;
+    }
+    // post-order over the subtree of `root` (explicit stack): entries, order, need, size of every four-wide node in it
+    void settle(uint32_t root) {
+        struct Frame { uint32_t id; uint32_t ids[4]; uint32_t n, next; };
+        std::vector<Frame> stack;
+        const auto push = [&](uint32_t id) { Frame f; f.id = id; f.n = open(id, f.ids); f.next = 0; stack.push_back(f); };
+        if (count[root]) return;
+        push(root);
+        while (!stack.empty()) {
+            Frame &f = stack.back();
+            if (f.next < f.n) {
+                const uint32_t child = f.ids[f.next++];
+                if (bin[child].left != 0u && !count[child]) push(child);       // (may move `stack`: f is not used after it)
+                continue;
+            }
+            uint32_t key[4], perm[4] = {0, 1, 2, 3};
+            for (uint32_t k = 0; k < f.n; k++) key[k] = bin[f.ids[k]].left == 0u ? 0u : 1u + need[f.ids[k]];
+            for (uint32_t i = 1; i < f.n; i++)                                  // (insertion sort, stable)
+                for (uint32_t j = i; j > 0 && key[perm[j]] < key[perm[j - 1]]; j--) std::swap(perm[j], perm[j - 1]);
+            uint32_t worst = 0, nodes = 1;
+            for (uint32_t k = 0; k < f.n; k++) {
+                const uint32_t id = f.ids[perm[k]];
+                entry[(size_t)f.id * 4 + k] = id;
+                const bool leaf = bin[id].left == 0u;
+                worst = std::max(worst, f.n - 1u - k + (leaf ? 0u : need[id]));
+                nodes += leaf ? 0u : size[id];
+            }
+            need[f.id] = worst; size[f.id] = nodes;
+            count[f.id] = (uint8_t)f.n;
+            stack.pop_back();
+        }
+    }
+};
+
 // The whole build: boxes[n] (the triangles' grown boxes, slot order) -> nodes (root = node 0), every stored plane moved
-// outward by gamma; `bound` >= every |stored plane| (the absent entries' inside-out boxes sit there).  Returns the most
+// outward by gamma; `bound` >= every |stored plane| (the absent entries' corner point sits there).  Returns the most
 // entries the walk ever has waiting (its stack need).  strategy 0: binned surface-area heuristic, 1: object medians.
 // order[s]: the input triangle that sits at slot s of the tree's own triangle order (a leaf is a run of slots: an entry's
 // reference is kLeaf | first slot); remaining[s]: triangles from slot s to the end of its leaf.
-struct BuildOptions { int strategy = 0; uint32_t leaf_max = 2; float leaf_rho = 0.2f; unsigned threads = 1; };
+struct BuildOptions { int strategy = 0; uint32_t leaf_max = 2; float leaf_rho = 0.2f; unsigned threads = 1; double *phase_ms = nullptr; /* [3] binary tree, four-wide, emit */ };
 inline uint32_t build_shadow_tree(const Box *boxes, uint32_t n, const BuildOptions &opt, double gamma, float bound, std::vector<Quad> &quads,
                                   std::vector<uint32_t> &order, std::vector<uint32_t> &remaining) {
     quads.clear(); order.clear(); remaining.clear();
@@ -305,23 +346,14 @@ inline uint32_t build_shadow_tree(const Box *boxes, uint32_t n, const BuildOptio
         for (int a = 0; a < 3; a++) { node.plane[k][a][0] = plane_down(b.lo[a], gamma); node.plane[k][a][1] = plane_up(b.hi[a], gamma); }
     };
     if (n == 0u) return 0u;
-    if (n == 1u) {
-        Quad node;
-        std::memset(&node, 0, sizeof node);
-        store(node, 0, boxes[0]);
-        node.ref[0] = kLeaf | 0u;
-        for (int k = 1; k < 4; k++) absent(node, k, 0u);
-        node.count = 1;
-        quads.push_back(node);
-        order.assign(1, 0u); remaining.assign(1, 1u);
-        return 0u;
-    }
+    const auto clock0 = std::chrono::steady_clock::now();
     Builder builder;
     builder.tri = boxes;
     builder.median_only = opt.strategy == 1;
     builder.leaf_max = std::max(1u, opt.leaf_max);
     builder.leaf_rho = opt.leaf_rho;
     builder.run(n, std::max(1u, opt.threads));
+    const auto clock1 = std::chrono::steady_clock::now();
     remaining.assign(n, 1u);
     if (builder.nodes[0].left == 0u) {
         // the whole scene is one leaf: a root node with that one entry
@@ -333,40 +365,79 @@ inline uint32_t build_shadow_tree(const Box *boxes, uint32_t n, const BuildOptio
         node.count = 1;
         quads.push_back(node);
         for (uint32_t i = 0; i < n; i++) remaining[i] = n - i;
-        order = builder.order;
+        order = std::move(builder.order);
         return 0u;
     }
-    Collapser collapse(builder);
-    const uint32_t root = collapse.make(0u);
-    const uint32_t need = collapse.drafts[root].need;
-    // numbered in the walk's own order (depth first, entries as stored): a subtree's nodes lie together
-    std::vector<uint32_t> number(collapse.drafts.size(), 0u);
-    std::vector<uint32_t> stack{root};
-    std::vector<uint32_t> sequence;
-    sequence.reserve(collapse.drafts.size());
-    while (!stack.empty()) {
-        const uint32_t at = stack.back();
-        stack.pop_back();
-        number[at] = (uint32_t)sequence.size();
-        sequence.push_back(at);
-        const QuadDraft &q = collapse.drafts[at];
-        for (int k = (int)q.count - 1; k >= 0; k--) if (!q.entry[k].triangle) stack.push_back(q.child[k]);
-    }
-    quads.resize(sequence.size());
-    for (size_t i = 0; i < sequence.size(); i++) {
-        const QuadDraft &q = collapse.drafts[sequence[i]];
-        Quad &node = quads[i];
-        std::memset(&node, 0, sizeof node);
-        for (uint32_t k = 0; k < 4; k++) {
-            if (k >= q.count) { absent(node, (int)k, builder.nodes[q.entry[0].bin].first); continue; }
-            store(node, (int)k, q.entry[k].box);
-            const BinNode &b = builder.nodes[q.entry[k].bin];
-            node.ref[k] = q.entry[k].triangle ? (kLeaf | b.first) : number[q.child[k]];
-            if (q.entry[k].triangle) for (uint32_t i = 0; i < b.count; i++) remaining[b.first + i] = b.count - i;
+    // ---- four entries a node: the subtrees a few levels down settle side by side, then the top
+    const unsigned threads = std::max(1u, opt.threads);
+    FourWide four(builder);
+    std::vector<uint32_t> frontier;
+    std::vector<uint8_t> is_frontier(builder.nodes.size(), 0);
+    if (threads > 1u && n >= kParallelAbove) {
+        std::vector<std::pair<uint32_t, uint32_t>> walk{{0u, 0u}};
+        while (!walk.empty()) {
+            const auto [id, depth] = walk.back();
+            walk.pop_back();
+            if (depth == 5u) { frontier.push_back(id); is_frontier[id] = 1; continue; }
+            uint32_t ids[4];
+            const uint32_t c = four.open(id, ids);
+            for (uint32_t k = 0; k < c; k++) if (builder.nodes[ids[k]].left != 0u) walk.push_back({ids[k], depth + 1u});
         }
-        node.count = q.count;
     }
-    order = builder.order;
+    const auto over_frontier = [&](auto &&fn) {
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> pool;
+        const auto run = [&] { for (size_t i; (i = next.fetch_add(1)) < frontier.size();) fn(i); };
+        for (unsigned t = 1; t < std::min<size_t>(threads, frontier.size()); t++) pool.emplace_back(run);
+        run();
+        for (auto &t : pool) t.join();
+    };
+    if (!frontier.empty()) over_frontier([&](size_t i) { four.settle(frontier[i]); });
+    four.settle(0u);
+    const uint32_t need = four.need[0];
+    const auto clock2 = std::chrono::steady_clock::now();
+    // ---- numbered in the walk's own order (depth first, entries as stored: a subtree's nodes lie together), written out
+    quads.resize(four.size[0]);
+    const std::vector<BinNode> &bin = builder.nodes;
+    std::vector<std::pair<uint32_t, uint32_t>> jobs;          // {head, index} of the subtrees written side by side
+    const auto write = [&](uint32_t root, uint32_t root_index, bool top) {
+        std::vector<std::pair<uint32_t, uint32_t>> stack{{root, root_index}};
+        while (!stack.empty()) {
+            const auto [id, index] = stack.back();
+            stack.pop_back();
+            if (top && is_frontier[id]) { jobs.push_back({id, index}); continue; }
+            Quad &node = quads[index];
+            std::memset(&node, 0, sizeof node);
+            const uint32_t c = four.count[id];
+            uint32_t running = index + 1u;
+            for (uint32_t k = 0; k < 4u; k++) {
+                if (k >= c) { absent(node, (int)k, bin[four.entry[(size_t)id * 4]].first); continue; }
+                const uint32_t e = four.entry[(size_t)id * 4 + k];
+                const BinNode &b = bin[e];
+                store(node, (int)k, b.box);
+                if (b.left == 0u) {
+                    node.ref[k] = kLeaf | b.first;
+                    for (uint32_t i = 0; i < b.count; i++) remaining[b.first + i] = b.count - i;
+                } else {
+                    node.ref[k] = running;
+                    stack.push_back({e, running});
+                    running += four.size[e];
+                }
+            }
+            node.count = c;
+        }
+    };
+    write(0u, 0u, !frontier.empty());
+    if (!jobs.empty()) {
+        frontier.clear();          // (over_frontier runs over `jobs` now)
+        frontier.resize(jobs.size());
+        over_frontier([&](size_t i) { write(jobs[i].first, jobs[i].second, false); });
+    }
+    order = std::move(builder.order);
+    if (opt.phase_ms) {
+        const auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        opt.phase_ms[0] = ms(clock0, clock1); opt.phase_ms[1] = ms(clock1, clock2); opt.phase_ms[2] = ms(clock2, std::chrono::steady_clock::now());
+    }
     return need;
 }
 

@@ -25,7 +25,7 @@ using namespace ctd;
 
 // sizes the bindings (cobbletrace_amd/bindings.py) rely on
 static_assert(sizeof(ctgpu_node) == 64 && sizeof(ctgpu_light) == 56 && sizeof(ctgpu_material) == 12, "scene records");
-static_assert(sizeof(ctgpu_scene_desc) == 88 && sizeof(ctgpu_sphere) == 48 && sizeof(ctgpu_frame_desc) == 136 && sizeof(ctgpu_stats) == 72, "descriptors");
+static_assert(sizeof(ctgpu_scene_desc) == 88 && sizeof(ctgpu_sphere) == 48 && sizeof(ctgpu_frame_desc) == 136 && sizeof(ctgpu_stats) == 104, "descriptors");
 static_assert(sizeof(ctgpu_ray) == 56 && sizeof(ctgpu_hit) == 16 && sizeof(ctgpu_partition) == 12, "test-hook records");
 
 // ------------------------------------------------------------------ error plumbing
@@ -233,6 +233,7 @@ struct ctgpu_ctx {
         int kind = -1;                          // 0 / 1: a single-sample / supersampled frame on the fast path (walk choice)
         int reflective_kind = -1;               // 0 / 1: a reflective single-sample / supersampled frame (bounce choice)
     } pending;
+    struct Path { uint32_t walk_kind = 0, bounce_kind = 0, ordered = 0, cull_tree = 0, shadow_tree = 0; } path;     // what the latest frame ran on (ctgpu_stats)
     int big_leaf_min = 8;                       // CTGPU_BIG_LEAF: leaves of at least this many triangles go through the triangle boxes (0: off)
     int big_leaf_share = 20;                    // CTGPU_BIG_LEAF_SHARE: ... and only in scenes where at least this percentage of all triangles sits in such leaves
     int probe_above = 100;                      // CTGPU_PROBE_ABOVE: fetches per packet beyond which the per-lane walk gets a trial frame
@@ -1161,6 +1162,9 @@ int read_counters(ctgpu_ctx *ctx, ctgpu_stats *st) {
         st->rays_primary = c[0]; st->rays_shadow = c[1]; st->rays_reflect = c[2];
         st->node_visits = c[3]; st->triangle_tests = c[4];
         st->rays_shadow_elided = c[kCounterElided];
+        st->rays_shadow_left = c[kCounterLeft];
+        st->walk_kind = ctx->path.walk_kind; st->bounce_kind = ctx->path.bounce_kind; st->ordered = ctx->path.ordered;
+        st->cull_tree = ctx->path.cull_tree; st->shadow_tree = ctx->path.shadow_tree;
     }
     return CTGPU_OK;
 }
@@ -1282,6 +1286,9 @@ int launch_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, FrameParams &P, hipS
         launch_trace_tiles(P, tile_count(P), ss, ctx->scene->has_reflection && f->max_depth > 0, false, stream);
         HIP_TRY(hipGetLastError());
         ctx->order.last_ordered = false;
+        ctx->path = ctgpu_ctx::Path();
+        ctx->path.walk_kind = CTGPU_WALK_GENERAL;
+        ctx->path.bounce_kind = frame_reflects(ctx, f) ? CTGPU_BOUNCE_GENERAL : CTGPU_BOUNCE_NONE;
         return CTGPU_OK;
     }
     PipelineParams W;
@@ -1330,6 +1337,12 @@ int launch_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, FrameParams &P, hipS
     HIP_TRY(hipGetLastError());
     if (W.ordered) ctx->order.parity ^= 1;
     ctx->order.last_ordered = W.ordered != 0u;
+    ctx->path.walk_kind = W.packet ? CTGPU_WALK_PACKET : CTGPU_WALK_PER_LANE;
+    ctx->path.bounce_kind = bounces ? CTGPU_BOUNCE_LEVELS : CTGPU_BOUNCE_NONE;
+    ctx->path.ordered = W.ordered;
+    ctx->path.cull_tree = (W.packet && P.cull_first != kNoNode) ? 1u : 0u;
+    // (the same condition launch_pipeline takes the shadow tree under)
+    ctx->path.shadow_tree = (W.packet && W.n_shadow_lights != 0u && P.stree && W.packet_budget == 0u) ? 1u : 0u;
     return CTGPU_OK;
 }
 

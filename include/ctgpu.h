@@ -152,7 +152,23 @@ typedef struct ctgpu_stats {
     uint64_t rays_shadow_elided;     /* shadow rays ComputeLighting would start (raythread.cpp:303) whose answer
                                         cannot change the pixel (n.l <= 0 and no specular reach) and which are
                                         therefore not traced: rays_shadow + rays_shadow_elided is the reference's count */
+    /* Which code rendered the context's latest frame (several paths give the same pixels; a context picks by scene, by frame
+     * kind and -- where ctgpu_config says "measured" -- by its own timings, so a caller who measures wants to know): */
+    uint32_t walk_kind;              /* CTGPU_WALK_*                                                                    */
+    uint32_t bounce_kind;            /* CTGPU_BOUNCE_*: how TraceRay's recursion ran (frames whose materials reflect)   */
+    uint32_t ordered;                /* 1: heavy chunks were handed out first (ctgpu_order_info)                        */
+    uint32_t cull_tree;              /* 1: the tree the frame walked carries cull nodes in place of big leaves          */
+    uint32_t shadow_tree;            /* 1: the shadow rays walked the shadow tree (ctgpu_config.shadow_tree)            */
+    uint32_t pad_;
+    uint64_t rays_shadow_left;       /* ... and this many of them it left to the walk of the reference's tree (rays outside
+                                        its gate; counted in rays_shadow like the others)                               */
 } ctgpu_stats;
+#define CTGPU_WALK_GENERAL   0       /* the general path's one kernel (reflective frames it was chosen for, CTGPU_FORCE_MEGAKERNEL) */
+#define CTGPU_WALK_PER_LANE  1       /* wavefront pipeline, every lane its own walk (ct_walk)                          */
+#define CTGPU_WALK_PACKET    2       /* wavefront pipeline, the shared walk (ct_walk_packet)                           */
+#define CTGPU_BOUNCE_NONE    0
+#define CTGPU_BOUNCE_LEVELS  1       /* bounce levels on the pipeline                                                  */
+#define CTGPU_BOUNCE_GENERAL 2       /* inside the general path's kernel                                               */
 
 /* ---- partition of one frame over several GPUs ---- */
 typedef struct ctgpu_partition {

@@ -232,6 +232,7 @@ def test_frames_with_and_without_cull_nodes(ss, scenes, monkeypatch):
             ctx.read_walk_work()
             fb, st = ctx.render(frame)
             assert (fb == want).all(), (big, int((fb != want).sum()))
+            assert st.cull_tree == (1 if big and ss else 0) and st.walk_kind == ca.bindings.WALK_PACKET
             records[big] = sum(ctx.read_walk_work().triangle_records)
         finally:
             ctx.close()

@@ -654,6 +654,7 @@ def test_packet_walk_variant(scenes, gpu_ctx, monkeypatch):
                 got, sg = ctxs[name].render(frame)
                 assert (got == want).all(), (name, w, h, ss, sub)
                 assert sg.rays == sw.rays
+                assert sg.walk_kind == ca.bindings.WALK_PER_LANE and not sg.shadow_tree and not sg.cull_tree
     finally:
         for c in ctxs.values():
             c.close()

@@ -176,6 +176,7 @@ def test_frames_and_counts_equal_the_reference_trees_walk(name, size, scenes):
                 ctx.read_walk_work()
                 got, st = ctx.render(frame)
                 work = ctx.read_walk_work()
+                assert st.shadow_tree == 1 and wst.shadow_tree == 0 and st.rays_shadow_left == 0        # (ctgpu_stats says which code ran)
                 assert (got == want).all(), "%s ss=%d: %d pixels differ" % (name, ss, int((got != want).sum()))
                 assert (st.rays_primary, st.rays_shadow, st.rays_shadow_elided) == (wst.rays_primary, wst.rays_shadow, wst.rays_shadow_elided)
                 assert work.shadow_rays_blocked == wwork.shadow_rays_blocked
@@ -191,6 +192,31 @@ def test_frames_and_counts_equal_the_reference_trees_walk(name, size, scenes):
         ref.close()
         for ctx in trees:
             ctx.close()
+
+
+def test_heavy_chunks_first_through_the_shadow_tree(scenes):
+    """A single-sample 1080p frame has few packets per wave and hands its heavy chunks out first, in parts (ctgpu_order_info);
+    with CTGPU_SHADOW_TREE=2 its shadow rays walk the shadow tree, whose walk reads the same lists and writes the same cost
+    words: same pixels and counts as the unordered walk of the reference's tree, and lists that fill up."""
+    scene = scenes("dragon")
+    cfg = ca.config_from_environment()
+    cfg.shadow_tree, cfg.order, cfg.packet_walk = 0, 0, 1
+    plain = ca.GpuContext(0, cfg); plain.upload(scene.desc)
+    cfg = ca.config_from_environment()
+    cfg.shadow_tree, cfg.order, cfg.packet_walk = 2, 1, 1
+    tree = ca.GpuContext(0, cfg); tree.upload(scene.desc)
+    try:
+        frame = scene.frame(1920, 1080, supersampling=False)
+        want, wst = plain.render(frame)
+        for k in range(4):
+            got, st = tree.render(frame)
+            assert st.ordered == 1 and st.shadow_tree == 1 and st.walk_kind == ca.bindings.WALK_PACKET
+            assert (got == want).all(), "frame %d: %d pixels differ" % (k, int((got != want).sum()))
+            assert (st.rays_primary, st.rays_shadow, st.rays_shadow_elided) == (wst.rays_primary, wst.rays_shadow, wst.rays_shadow_elided)
+        entries, split = tree.order_info()
+        assert split and sum(entries[:4]) > 0 and sum(entries[4:]) > 0, entries
+    finally:
+        plain.close(); tree.close()
 
 
 def _write_scene(tmp_path, name, triangles, lights, camera):
@@ -242,9 +268,9 @@ def test_rays_the_tree_does_not_take(tmp_path):
             want, cst = _oracle().render(scene.desc, frame, os_threads=4)
             assert (got == want).all() and (other == want).all()
             assert (st.rays_primary, st.rays_shadow, st.rays_shadow_elided) == (ost.rays_primary, ost.rays_shadow, ost.rays_shadow_elided)
-            # the shadow tree took some rays and left others
+            # the shadow tree took some rays and left others: three of the five lights' rays, to be exact
             work = tree.read_walk_work()
-            assert 0 < work.packets[1]
+            assert 0 < work.packets[1] and st.shadow_tree == 1 and 0 < st.rays_shadow_left < st.rays_shadow and ost.rays_shadow_left == 0
     finally:
         tree.close(); ref.close()
 
@@ -279,6 +305,7 @@ def test_a_triangle_hit_outside_its_leafs_box_does_not_count(tmp_path):
             assert (got == want).all(), "%d pixels differ" % int((got != want).sum())
             other, ost = ref.render(frame)
             assert (other == want).all()
+            assert st.rays_shadow_left > 0                        # rays whose hit lay outside the shrunk box of its leaf went on to the second launch
             assert (st.rays_primary, st.rays_shadow, st.rays_shadow_elided) == (ost.rays_primary, ost.rays_shadow, ost.rays_shadow_elided)
     finally:
         tree.close(); ref.close()

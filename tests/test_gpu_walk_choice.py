@@ -142,6 +142,7 @@ def test_spheres_stay_on_the_fast_path(tmp_path, monkeypatch):
             fast.read_walk_work()
             got, st = fast.render(frame)
             assert fast.read_walk_work().packets[0] > 0                     # the packet walk traced the triangles
+            assert st.walk_kind == ca.bindings.WALK_PACKET and st.bounce_kind == ca.bindings.BOUNCE_NONE
             want, _ = oracle.render(scene.desc, frame, os_threads=4)
             other, _ = general.render(frame)
             diff = int((got != want).sum())
@@ -184,6 +185,8 @@ def test_reflection_bounces_on_the_fast_path(spheres, reflect_fix, assets, monke
                 got, st = fast.render(frame)
                 work = fast.read_walk_work()
                 other, so = general.render(frame)
+                assert (st.walk_kind, st.bounce_kind) == (ca.bindings.WALK_PACKET, ca.bindings.BOUNCE_LEVELS)
+                assert (so.walk_kind, so.bounce_kind) == (ca.bindings.WALK_GENERAL, ca.bindings.BOUNCE_GENERAL)
                 want, _ = oracle.render(scene.desc, frame, os_threads=8)
                 diff = np.abs(((got[..., None] >> shifts) & 255).astype(int) - ((want[..., None] >> shifts) & 255).astype(int)).max()
                 print("%s spheres=%d fix=%d ss=%d: fast path %.3f ms, general path %.3f ms; %d px differ from the oracle, %d from the general path; "
