@@ -39,9 +39,10 @@ struct Box {
     }
 };
 
-// binary tree: node i covers order[first .. first + count); an inner node's children are `left` and left + 1; a LEAF
-// (left == 0) holds its count triangles as one run
-struct BinNode { Box box; uint32_t left, first, count; };
+// binary tree: an inner node's children are `left` and `right`; a LEAF (left == kNone) holds `count` triangles, the entries
+// leaf_tri[first .. first + count) of the tree's triangle list
+constexpr uint32_t kNone = 0xffffffffu;
+struct BinNode { Box box; uint32_t left, right, first, count; };
 
 constexpr int kBins = 16;
 constexpr uint32_t kSequentialBelow = 1u << 15;      // ranges a worker thread builds alone
@@ -65,6 +66,7 @@ inline void in_chunks(uint32_t count, unsigned chunks, F &&fn) {
 struct Builder {
     const Box *tri;                   // [n] the triangles' boxes
     std::vector<uint32_t> order;      // slots, permuted as the ranges are split
+    std::vector<uint32_t> scratch;    // (the big splits move their triangles through it)
     std::vector<BinNode> nodes;       // 2n - 1
     std::atomic<uint32_t> used{1};
     bool median_only = false;
@@ -83,8 +85,9 @@ struct Builder {
     static float centre(const Box &b, int a) { return 0.5f * (b.lo[a] + b.hi[a]); }
     struct Bins { Box box[3][kBins]; uint32_t n[3][kBins]; };
 
-    // split node `id` in place (its range of `order`); false: it stays a leaf
-    bool split(uint32_t id, uint32_t depth) {
+    // split node `id` in place (its range of `order`); false: it stays a leaf.  wide: every thread works on this one split
+    // (the big ranges at the top, one after another), else the calling thread alone (the many ranges below, side by side)
+    bool split(uint32_t id, uint32_t depth, bool wide = false) {
         BinNode &node = nodes[id];
         if (node.count <= 1u) return false;
         uint32_t *idx = order.data() + node.first;
@@ -95,7 +98,7 @@ struct Builder {
             for (uint32_t i = 0; i < count; i++) parts += tri[idx[i]].half_area();
             if (!(whole > 0.0f) || (float)count - parts / whole <= leaf_rho * (float)count) return false;
         }
-        const unsigned chunks = (count >= kParallelAbove && threads > 1u) ? std::min(threads, 16u) : 1u;
+        const unsigned chunks = (wide && count >= kParallelAbove && threads > 1u) ? threads : 1u;
         // pass 1: the centres' bounds
         float clo[3] = {INFINITY, INFINITY, INFINITY}, chi[3] = {-INFINITY, -INFINITY, -INFINITY};
         {
@@ -168,6 +171,25 @@ struct Builder {
             }
             if (best_axis >= 0) {
                 const int a = best_axis;
+                if (chunks > 1u) {
+                    // every chunk counts its two sides, the counts become places, every chunk moves its triangles there
+                    std::vector<uint32_t> lefts(chunks + 1u, 0u);
+                    const uint32_t step = (count + chunks - 1u) / chunks;
+                    in_chunks(count, chunks, [&](unsigned c, uint32_t b, uint32_t e) {
+                        uint32_t l = 0;
+                        for (uint32_t i = b; i < e; i++) l += bin_of(idx[i], a) <= best_bin ? 1u : 0u;
+                        lefts[c + 1u] = l;
+                    });
+                    for (unsigned c = 0; c < chunks; c++) lefts[c + 1u] += lefts[c];
+                    mid = lefts[chunks];
+                    scratch.resize(order.size());
+                    uint32_t *out = scratch.data() + node.first;
+                    in_chunks(count, chunks, [&](unsigned c, uint32_t b, uint32_t e) {
+                        uint32_t l = lefts[c], r = mid + (std::min(count, c * step) - lefts[c]);
+                        for (uint32_t i = b; i < e; i++) { if (bin_of(idx[i], a) <= best_bin) out[l++] = idx[i]; else out[r++] = idx[i]; }
+                    });
+                    in_chunks(count, chunks, [&](unsigned, uint32_t b, uint32_t e) { std::memcpy(idx + b, out + b, (size_t)(e - b) * 4u); });
+                } else
                 mid = (uint32_t)(std::partition(idx, idx + count, [&](uint32_t s) { return bin_of(s, a) <= best_bin; }) - idx);
                 for (int b = 0; b < kBins; b++) if (B.n[a][b]) (b <= best_bin ? left_box : right_box).grow(B.box[a][b]);
                 boxes_known = true;
@@ -186,15 +208,15 @@ struct Builder {
         }
         const uint32_t left = used.fetch_add(2u);
         BinNode &l = nodes[left], &r = nodes[left + 1];
-        l.first = node.first; l.count = mid; l.left = 0;
-        r.first = node.first + mid; r.count = count - mid; r.left = 0;
+        l.first = node.first; l.count = mid; l.left = l.right = kNone;
+        r.first = node.first + mid; r.count = count - mid; r.left = r.right = kNone;
         if (boxes_known) { l.box = left_box; r.box = right_box; }
         else {
             l.box.clear(); r.box.clear();
             for (uint32_t i = 0; i < mid; i++) l.box.grow(tri[idx[i]]);
             for (uint32_t i = mid; i < count; i++) r.box.grow(tri[idx[i]]);
         }
-        node.left = left;
+        node.left = left; node.right = left + 1u;
         return true;
     }
     void build_alone(uint32_t id, uint32_t depth) {
@@ -204,7 +226,7 @@ struct Builder {
             stack.pop_back();
             if (!split(at, d)) continue;
             stack.push_back({nodes[at].left, d + 1});
-            stack.push_back({nodes[at].left + 1, d + 1});
+            stack.push_back({nodes[at].right, d + 1});
         }
     }
     void worker() {
@@ -222,7 +244,7 @@ struct Builder {
             else if (split(job.first, job.second)) {
                 std::lock_guard<std::mutex> hold(lock);
                 todo.push_back({nodes[job.first].left, job.second + 1});
-                todo.push_back({nodes[job.first].left + 1, job.second + 1});
+                todo.push_back({nodes[job.first].right, job.second + 1});
                 wake.notify_all();
             }
             {
@@ -237,8 +259,8 @@ struct Builder {
         order.resize(n);
         nodes.resize(2u * (size_t)n);
         BinNode &root = nodes[0];
-        root.first = 0; root.count = n; root.left = 0;
-        const unsigned chunks = (n >= kParallelAbove && threads > 1u) ? std::min(threads, 16u) : 1u;
+        root.first = 0; root.count = n; root.left = root.right = kNone;
+        const unsigned chunks = (n >= kParallelAbove && threads > 1u) ? threads : 1u;
         std::vector<Box> part(chunks);
         in_chunks(n, chunks, [&](unsigned c, uint32_t b, uint32_t e) {
             part[c].clear();
@@ -246,7 +268,16 @@ struct Builder {
         });
         root.box.clear();
         for (unsigned c = 0; c < chunks; c++) root.box.grow(part[c]);
-        todo.push_back({0u, 0u});
+        // the big ranges one after another, every thread on each; what they leave, side by side
+        std::vector<std::pair<uint32_t, uint32_t>> big{{0u, 0u}};
+        while (!big.empty()) {
+            const auto [id, depth] = big.back();
+            big.pop_back();
+            if (nodes[id].count < kParallelAbove || threads == 1u) { todo.push_back({id, depth}); continue; }
+            if (!split(id, depth, true)) continue;
+            big.push_back({nodes[id].left, depth + 1u});
+            big.push_back({nodes[id].right, depth + 1u});
+        }
         std::vector<std::thread> pool;
         for (unsigned t = 1; t < threads; t++) pool.emplace_back([this] { worker(); });
         worker();
@@ -266,28 +297,29 @@ inline float plane_up(float p, double gamma) { return -plane_down(-p, gamma); }
 // ------------------------------------------------------------------ four entries a node
 // The node that stands for an inner binary node: its two children, the one with the largest box opened in turn until four
 // entries are there or only leaves are left.  Per binary node that heads a four-wide node: its entries (binary node ids, in
-// the order the walk will meet them), how many, what its subtree needs of the walk's stack, how many four-wide nodes it
-// holds.  Entries are ordered leaves first, then subtrees by their need, least first: the deepest subtree is entered with
-// nothing of this node waiting, need(node) = max over k of (count - 1 - k + need(entry k)).
+// the order the walk will meet them), how many, what its subtree needs of the walk's stack, how many four-wide nodes and
+// triangles it holds.  Entries are ordered leaves first, then subtrees by their need, least first: the deepest subtree is
+// entered with nothing of this node waiting, need(node) = max over k of (count - 1 - k + need(entry k)).
 struct FourWide {
     const std::vector<BinNode> &bin;
     std::vector<uint32_t> entry;      // [bin][4]
     std::vector<uint8_t> count;       // [bin] 0: not (yet) a four-wide node's head
-    std::vector<uint32_t> need, size; // [bin]
-    explicit FourWide(const Builder &b) : bin(b.nodes), entry(b.nodes.size() * 4u), count(b.nodes.size(), 0), need(b.nodes.size(), 0), size(b.nodes.size(), 0) {}
+    std::vector<uint32_t> need, size, tris; // [bin]
+    explicit FourWide(const std::vector<BinNode> &nodes) : bin(nodes), entry(nodes.size() * 4u), count(nodes.size(), 0), need(nodes.size(), 0),
+                                                            size(nodes.size(), 0), tris(nodes.size(), 0) {}
 
     uint32_t open(uint32_t id, uint32_t ids[4]) const {
         uint32_t n = 0;
-        ids[n++] = bin[id].left; ids[n++] = bin[id].left + 1;
+        ids[n++] = bin[id].left; ids[n++] = bin[id].right;
         while (n < 4u) {
             int widest = -1;
             float area = -1.0f;
             for (uint32_t k = 0; k < n; k++)
-                if (bin[ids[k]].left != 0u && bin[ids[k]].box.half_area() > area) { area = bin[ids[k]].box.half_area(); widest = (int)k; }
+                if (bin[ids[k]].left != kNone && bin[ids[k]].box.half_area() > area) { area = bin[ids[k]].box.half_area(); widest = (int)k; }
             if (widest < 0) break;
             const uint32_t opened = ids[widest];
             ids[widest] = bin[opened].left;
-            ids[n++] = bin[opened].left + 1;
+            ids[n++] = bin[opened].right;
         }
         return n;
     }
@@ -302,40 +334,41 @@ struct FourWide {
             Frame &f = stack.back();
             if (f.next < f.n) {
                 const uint32_t child = f.ids[f.next++];
-                if (bin[child].left != 0u && !count[child]) push(child);       // (may move `stack`: f is not used after it)
+                if (bin[child].left != kNone && !count[child]) push(child);     // (may move `stack`: f is not used after it)
                 continue;
             }
             uint32_t key[4], perm[4] = {0, 1, 2, 3};
-            for (uint32_t k = 0; k < f.n; k++) key[k] = bin[f.ids[k]].left == 0u ? 0u : 1u + need[f.ids[k]];
+            for (uint32_t k = 0; k < f.n; k++) key[k] = bin[f.ids[k]].left == kNone ? 0u : 1u + need[f.ids[k]];
             for (uint32_t i = 1; i < f.n; i++)                                  // (insertion sort, stable)
                 for (uint32_t j = i; j > 0 && key[perm[j]] < key[perm[j - 1]]; j--) std::swap(perm[j], perm[j - 1]);
-            uint32_t worst = 0, nodes = 1;
+            uint32_t worst = 0, nodes = 1, below = 0;
             for (uint32_t k = 0; k < f.n; k++) {
                 const uint32_t id = f.ids[perm[k]];
                 entry[(size_t)f.id * 4 + k] = id;
-                const bool leaf = bin[id].left == 0u;
+                const bool leaf = bin[id].left == kNone;
                 worst = std::max(worst, f.n - 1u - k + (leaf ? 0u : need[id]));
                 nodes += leaf ? 0u : size[id];
+                below += leaf ? bin[id].count : tris[id];
             }
-            need[f.id] = worst; size[f.id] = nodes;
+            need[f.id] = worst; size[f.id] = nodes; tris[f.id] = below;
             count[f.id] = (uint8_t)f.n;
             stack.pop_back();
         }
     }
 };
 
-// The whole build: boxes[n] (the triangles' grown boxes, slot order) -> nodes (root = node 0), every stored plane moved
+// From a binary tree over the triangles (any builder's: this header's, or the device's -- ct_shadow_tree.hip) to what the
+// walk reads.  bin[root] is the root; a leaf's triangles are leaf_tri[first .. first + count).  Every stored plane moved
 // outward by gamma; `bound` >= every |stored plane| (the absent entries' corner point sits there).  Returns the most
-// entries the walk ever has waiting (its stack need).  strategy 0: binned surface-area heuristic, 1: object medians.
+// entries the walk ever has waiting (its stack need).
 // order[s]: the input triangle that sits at slot s of the tree's own triangle order (a leaf is a run of slots: an entry's
 // reference is kLeaf | first slot); remaining[s]: triangles from slot s to the end of its leaf.
-struct BuildOptions { int strategy = 0; uint32_t leaf_max = 2; float leaf_rho = 0.2f; unsigned threads = 1; double *phase_ms = nullptr; /* [3] binary tree, four-wide, emit */ };
-inline uint32_t build_shadow_tree(const Box *boxes, uint32_t n, const BuildOptions &opt, double gamma, float bound, std::vector<Quad> &quads,
-                                  std::vector<uint32_t> &order, std::vector<uint32_t> &remaining) {
-    quads.clear(); order.clear(); remaining.clear();
+inline uint32_t four_wide_from_binary(const std::vector<BinNode> &bin, uint32_t root, const uint32_t *leaf_tri, uint32_t n, double gamma, float bound,
+                                      unsigned threads, std::vector<Quad> &quads, std::vector<uint32_t> &order, std::vector<uint32_t> &remaining,
+                                      double *phase_ms = nullptr) {
     // An entry a node does not have: a one-point box at a corner beyond every plane -- a ray's line enters it only by
     // passing through that very point -- and, for the line that does, a reference that is always safe to follow: some
-    // triangle below this node.  (Testing a triangle more than the boxes ask for never changes the answer: the test is the
+    // leaf below this node.  (Testing a triangle more than the boxes ask for never changes the answer: the test is the
     // reference's own, and it counts only after the reference's own test of its leaf's box.)  The walk looks at all four
     // entries of every node and never asks how many there are.
     const auto absent = [&](Quad &node, int k, uint32_t some_slot) {
@@ -345,43 +378,35 @@ inline uint32_t build_shadow_tree(const Box *boxes, uint32_t n, const BuildOptio
     const auto store = [&](Quad &node, int k, const Box &b) {
         for (int a = 0; a < 3; a++) { node.plane[k][a][0] = plane_down(b.lo[a], gamma); node.plane[k][a][1] = plane_up(b.hi[a], gamma); }
     };
-    if (n == 0u) return 0u;
-    const auto clock0 = std::chrono::steady_clock::now();
-    Builder builder;
-    builder.tri = boxes;
-    builder.median_only = opt.strategy == 1;
-    builder.leaf_max = std::max(1u, opt.leaf_max);
-    builder.leaf_rho = opt.leaf_rho;
-    builder.run(n, std::max(1u, opt.threads));
     const auto clock1 = std::chrono::steady_clock::now();
-    remaining.assign(n, 1u);
-    if (builder.nodes[0].left == 0u) {
+    quads.clear();
+    order.assign(n, 0u); remaining.assign(n, 1u);
+    if (bin[root].left == kNone) {
         // the whole scene is one leaf: a root node with that one entry
         Quad node;
         std::memset(&node, 0, sizeof node);
-        store(node, 0, builder.nodes[0].box);
+        store(node, 0, bin[root].box);
         node.ref[0] = kLeaf | 0u;
         for (int k = 1; k < 4; k++) absent(node, k, 0u);
         node.count = 1;
         quads.push_back(node);
-        for (uint32_t i = 0; i < n; i++) remaining[i] = n - i;
-        order = std::move(builder.order);
+        for (uint32_t i = 0; i < n; i++) { remaining[i] = n - i; order[i] = leaf_tri[bin[root].first + i]; }
         return 0u;
     }
     // ---- four entries a node: the subtrees a few levels down settle side by side, then the top
-    const unsigned threads = std::max(1u, opt.threads);
-    FourWide four(builder);
+    threads = std::max(1u, threads);
+    FourWide four(bin);
     std::vector<uint32_t> frontier;
-    std::vector<uint8_t> is_frontier(builder.nodes.size(), 0);
+    std::vector<uint8_t> is_frontier(bin.size(), 0);
     if (threads > 1u && n >= kParallelAbove) {
-        std::vector<std::pair<uint32_t, uint32_t>> walk{{0u, 0u}};
+        std::vector<std::pair<uint32_t, uint32_t>> walk{{root, 0u}};
         while (!walk.empty()) {
             const auto [id, depth] = walk.back();
             walk.pop_back();
             if (depth == 5u) { frontier.push_back(id); is_frontier[id] = 1; continue; }
             uint32_t ids[4];
             const uint32_t c = four.open(id, ids);
-            for (uint32_t k = 0; k < c; k++) if (builder.nodes[ids[k]].left != 0u) walk.push_back({ids[k], depth + 1u});
+            for (uint32_t k = 0; k < c; k++) if (bin[ids[k]].left != kNone) walk.push_back({ids[k], depth + 1u});
         }
     }
     const auto over_frontier = [&](auto &&fn) {
@@ -393,52 +418,130 @@ inline uint32_t build_shadow_tree(const Box *boxes, uint32_t n, const BuildOptio
         for (auto &t : pool) t.join();
     };
     if (!frontier.empty()) over_frontier([&](size_t i) { four.settle(frontier[i]); });
-    four.settle(0u);
-    const uint32_t need = four.need[0];
+    four.settle(root);
+    const uint32_t need = four.need[root];
     const auto clock2 = std::chrono::steady_clock::now();
-    // ---- numbered in the walk's own order (depth first, entries as stored: a subtree's nodes lie together), written out
-    quads.resize(four.size[0]);
-    const std::vector<BinNode> &bin = builder.nodes;
-    std::vector<std::pair<uint32_t, uint32_t>> jobs;          // {head, index} of the subtrees written side by side
-    const auto write = [&](uint32_t root, uint32_t root_index, bool top) {
-        std::vector<std::pair<uint32_t, uint32_t>> stack{{root, root_index}};
+    // ---- numbered in the walk's own order (depth first, entries as stored: a subtree's nodes and triangles lie together)
+    quads.resize(four.size[root]);
+    struct Job { uint32_t head, index, slot; };
+    std::vector<Job> jobs;                                    // the subtrees written side by side
+    const auto write = [&](Job from, bool top) {
+        std::vector<Job> stack{from};
         while (!stack.empty()) {
-            const auto [id, index] = stack.back();
+            const Job at = stack.back();
             stack.pop_back();
-            if (top && is_frontier[id]) { jobs.push_back({id, index}); continue; }
-            Quad &node = quads[index];
+            if (top && is_frontier[at.head]) { jobs.push_back(at); continue; }
+            Quad &node = quads[at.index];
             std::memset(&node, 0, sizeof node);
-            const uint32_t c = four.count[id];
-            uint32_t running = index + 1u;
+            const uint32_t c = four.count[at.head];
+            uint32_t running = at.index + 1u, slot = at.slot;
             for (uint32_t k = 0; k < 4u; k++) {
-                if (k >= c) { absent(node, (int)k, bin[four.entry[(size_t)id * 4]].first); continue; }
-                const uint32_t e = four.entry[(size_t)id * 4 + k];
+                if (k >= c) { absent(node, (int)k, at.slot); continue; }        // (at.slot: where this node's first leaf begins)
+                const uint32_t e = four.entry[(size_t)at.head * 4 + k];
                 const BinNode &b = bin[e];
                 store(node, (int)k, b.box);
-                if (b.left == 0u) {
-                    node.ref[k] = kLeaf | b.first;
-                    for (uint32_t i = 0; i < b.count; i++) remaining[b.first + i] = b.count - i;
+                if (b.left == kNone) {
+                    node.ref[k] = kLeaf | slot;
+                    for (uint32_t i = 0; i < b.count; i++) { order[slot + i] = leaf_tri[b.first + i]; remaining[slot + i] = b.count - i; }
+                    slot += b.count;
                 } else {
                     node.ref[k] = running;
-                    stack.push_back({e, running});
+                    stack.push_back(Job{e, running, slot});
                     running += four.size[e];
+                    slot += four.tris[e];
                 }
             }
             node.count = c;
         }
     };
-    write(0u, 0u, !frontier.empty());
+    write(Job{root, 0u, 0u}, !frontier.empty());
     if (!jobs.empty()) {
-        frontier.clear();          // (over_frontier runs over `jobs` now)
-        frontier.resize(jobs.size());
-        over_frontier([&](size_t i) { write(jobs[i].first, jobs[i].second, false); });
+        frontier.assign(jobs.size(), 0u);                     // (over_frontier runs over `jobs` now)
+        over_frontier([&](size_t i) { write(jobs[i], false); });
     }
-    order = std::move(builder.order);
-    if (opt.phase_ms) {
+    if (phase_ms) {
         const auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-        opt.phase_ms[0] = ms(clock0, clock1); opt.phase_ms[1] = ms(clock1, clock2); opt.phase_ms[2] = ms(clock2, std::chrono::steady_clock::now());
+        phase_ms[1] = ms(clock1, clock2); phase_ms[2] = ms(clock2, std::chrono::steady_clock::now());
     }
     return need;
+}
+
+// The whole build on the host: boxes[n] (the triangles' grown boxes, slot order) -> a binary tree by the binned surface-area
+// heuristic (strategy 0) or object medians (1), leaves of up to leaf_max triangles -> four_wide_from_binary.
+struct BuildOptions { int strategy = 0; uint32_t leaf_max = 2; float leaf_rho = 0.2f; unsigned threads = 1; double *phase_ms = nullptr; /* [3] binary tree, four-wide, emit */ };
+inline uint32_t build_shadow_tree(const Box *boxes, uint32_t n, const BuildOptions &opt, double gamma, float bound, std::vector<Quad> &quads,
+                                  std::vector<uint32_t> &order, std::vector<uint32_t> &remaining) {
+    quads.clear(); order.clear(); remaining.clear();
+    if (n == 0u) return 0u;
+    const auto clock0 = std::chrono::steady_clock::now();
+    Builder builder;
+    builder.tri = boxes;
+    builder.median_only = opt.strategy == 1;
+    builder.leaf_max = std::max(1u, opt.leaf_max);
+    builder.leaf_rho = opt.leaf_rho;
+    builder.run(n, std::max(1u, opt.threads));
+    if (opt.phase_ms) opt.phase_ms[0] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - clock0).count();
+    return four_wide_from_binary(builder.nodes, 0u, builder.order.data(), n, gamma, bound, opt.threads, quads, order, remaining, opt.phase_ms);
+}
+
+// The top of a tree rebuilt by the surface-area heuristic.  Bottom-up clustering makes good small subtrees and mediocre tops
+// (the last merges join whatever is left along the curve); the top is also where every packet of rays passes.  So the tree
+// is cut where subtrees hold at most `cut` triangles, those subtrees' boxes become the primitives of a binned top-down
+// build (a few thousand of them: a millisecond), and its leaves are the subtrees.  bin grows by the new inner nodes; the
+// nodes above the cut stay in the array, unreferenced.  count_below: scratch.  Returns the new root.
+inline uint32_t resplit_top(std::vector<BinNode> &bin, uint32_t root, uint32_t n, uint32_t cut) {
+    if (cut == 0u || bin[root].left == kNone) return root;
+    std::vector<uint32_t> below(bin.size(), 0u);
+    for (size_t i = 0; i < bin.size(); i++)                       // (children lie below their parents in the array)
+        below[i] = bin[i].left == kNone ? bin[i].count : below[bin[i].left] + below[bin[i].right];
+    std::vector<uint32_t> heads;
+    std::vector<uint32_t> stack{root};
+    while (!stack.empty()) {
+        const uint32_t id = stack.back();
+        stack.pop_back();
+        if (bin[id].left == kNone || below[id] <= cut) { heads.push_back(id); continue; }
+        stack.push_back(bin[id].right); stack.push_back(bin[id].left);
+    }
+    if (heads.size() < 3u) return root;
+    std::vector<Box> boxes(heads.size());
+    for (size_t k = 0; k < heads.size(); k++) boxes[k] = bin[heads[k]].box;
+    Builder top;
+    top.tri = boxes.data();
+    top.leaf_max = 1;
+    top.run((uint32_t)heads.size(), 1u);
+    const uint32_t made = top.used.load();
+    const uint32_t base = (uint32_t)bin.size();
+    std::vector<uint32_t> id_of(made, kNone);
+    uint32_t fresh = 0;
+    for (uint32_t j = 0; j < made; j++)
+        id_of[j] = top.nodes[j].left == kNone ? heads[top.order[top.nodes[j].first]] : base + fresh++;
+    bin.resize((size_t)base + fresh);
+    for (uint32_t j = 0; j < made; j++) {
+        if (top.nodes[j].left == kNone) continue;
+        BinNode &node = bin[id_of[j]];
+        node.box = top.nodes[j].box;
+        node.left = id_of[top.nodes[j].left]; node.right = id_of[top.nodes[j].right];
+        node.first = 0; node.count = 0;
+    }
+    (void)n;
+    return id_of[0];
+}
+
+// A binary tree that came without leaf decisions (the device's agglomerative build: every leaf one triangle, leaf i =
+// triangle tri_of_leaf[i], inner nodes behind them): an inner node whose two children are single triangles becomes a leaf of
+// two where their boxes fill its own -- Builder's rule, c - sum(area_i) / area <= rho c -- its pair appended to leaf_tri.
+// bin[0 .. n) are the leaves on entry (first = i, count = 1); leaf_tri must have room for n + 2 * (bin.size() - n) entries.
+inline void pair_up_leaves(std::vector<BinNode> &bin, uint32_t n, float leaf_rho, std::vector<uint32_t> &leaf_tri) {
+    uint32_t at = n;
+    for (size_t id = n; id < bin.size(); id++) {
+        BinNode &b = bin[id];
+        if (b.left == kNone || b.left >= n || b.right >= n) continue;
+        const float whole = b.box.half_area(), parts = bin[b.left].box.half_area() + bin[b.right].box.half_area();
+        if (whole > 0.0f && 2.0f - parts / whole > leaf_rho * 2.0f) continue;
+        leaf_tri[at] = leaf_tri[b.left]; leaf_tri[at + 1u] = leaf_tri[b.right];
+        b.first = at; b.count = 2u; b.left = b.right = kNone;
+        at += 2u;
+    }
 }
 
 // What the walk reads: the same nodes with every reference turned into the BYTE OFFSET of what it names (a node: index *

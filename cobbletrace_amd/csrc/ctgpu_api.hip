@@ -355,7 +355,7 @@ extern "C" int ctgpu_config_from_environment(ctgpu_config *c) {
     number("CTGPU_BIG_LEAF", c->big_leaf_min, 0, big);
     number("CTGPU_BIG_LEAF_SHARE", c->big_leaf_share, 0, 100);
     number("CTGPU_SHADOW_TREE", c->shadow_tree, 0, 2);
-    number("CTGPU_SHADOW_TREE_BUILD", c->shadow_tree_build, 0, 1);
+    number("CTGPU_SHADOW_TREE_BUILD", c->shadow_tree_build, 0, 2);
     number("CTGPU_SHADOW_TREE_LEAF", c->shadow_tree_leaf, 1, 4);
     number("CTGPU_SHADOW_TREE_LEAF_FILL", c->shadow_tree_leaf_fill, 0, 100);
     number("CTGPU_PACKET_BUDGET", c->packet_budget, 0, big);
@@ -394,7 +394,7 @@ extern "C" int ctgpu_create_with_config(int device, const ctgpu_config *config, 
     const auto part_ok = [](int x) { return x == 1 || x == 2 || x == 4 || x == 8 || x == 16; };
     if (c.lds_depth < 1 || c.packet_lds_levels < 1 || c.packet_lanes < 1 || c.packet_lanes > 64 || c.blocks_per_cu < 0 || c.chunk < 0 ||
         c.chunk_shadow < 0 || c.order < 0 || c.order > 3 || c.big_leaf_min < 0 || c.big_leaf_share < 0 || c.big_leaf_share > 100 ||
-        c.shadow_tree < 0 || c.shadow_tree > 2 || c.shadow_tree_build < 0 || c.shadow_tree_build > 1 ||
+        c.shadow_tree < 0 || c.shadow_tree > 2 || c.shadow_tree_build < 0 || c.shadow_tree_build > 2 ||
         c.shadow_tree_leaf < 1 || c.shadow_tree_leaf > 4 || c.shadow_tree_leaf_fill < 0 || c.shadow_tree_leaf_fill > 100 ||
         c.packet_budget < 0 || c.order_floor < 0 || c.order_split_below < 0 || c.probe_above < 0 ||
         !(c.order_heavy[0] >= c.order_heavy[1] && c.order_heavy[1] >= c.order_heavy[2] && c.order_heavy[2] >= c.order_heavy[3] && c.order_heavy[3] > 0.0f) ||

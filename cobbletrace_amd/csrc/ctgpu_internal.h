@@ -64,7 +64,8 @@ CTGPU_HIDDEN int ctgpu_pack_cull_on_device(int device, const void *d_tris, uint3
 CTGPU_HIDDEN int ctgpu_triangle_boxes_on_device(const void *d_tris, uint32_t n_triangles, float *d_box, uint32_t stats[8]);
 
 // the shadow tree (ct_device.h "the shadow tree", ct_shadow_tree.hip): made from the packed TriRecords and the reference's
-// node array, both already on the device.  strategy: 0 binned surface-area heuristic, 1 object medians (the comparison);
+// node array, both already on the device.  strategy: 0 the binary tree clustered on the device (the host's binned builder
+// takes over should the clustering not finish), 1 binned surface-area heuristic on host threads, 2 object medians (host);
 // leaf_max / leaf_rho: a leaf holds up to leaf_max triangles where their boxes fill the leaf's (ct_shadow_tree_build.h).
 struct ctgpu_shadow_tree {
     void *nodes = nullptr;                 // QuadNode[n_nodes], root = node 0; hipMalloc'ed, caller owns (NULL: the scene gets none)

@@ -224,7 +224,8 @@ typedef struct ctgpu_config {
     int32_t big_leaf_share;       /* CTGPU_BIG_LEAF_SHARE ... in scenes where at least this percentage of the triangles sits in such leaves */
     int32_t shadow_tree;          /* CTGPU_SHADOW_TREE    the frame's shadow rays walk a tree of this library's own over the same triangles (order-free
                                      any-hit query, raythread.cpp:303-307; DESIGN appendix E): 0 never, 1 supersampled frames (default), 2 every frame */
-    int32_t shadow_tree_build;    /* CTGPU_SHADOW_TREE_BUILD  how that tree is split: 0 binned surface-area heuristic (default), 1 object medians */
+    int32_t shadow_tree_build;    /* CTGPU_SHADOW_TREE_BUILD  how that tree is made: 0 clustered on the device (default; nearest neighbours along a
+                                     space-filling curve merge round by round), 1 binned surface-area heuristic on host threads, 2 object medians (host) */
     int32_t shadow_tree_leaf;     /* CTGPU_SHADOW_TREE_LEAF   most triangles one of its leaves holds (1..4, default 2) ... */
     int32_t shadow_tree_leaf_fill;/* CTGPU_SHADOW_TREE_LEAF_FILL  ... and c > 1 of them only where c - sum(box area of each) / (box area of all) <= this
                                      percentage of c (default 50): the triangles' boxes nearly fill the leaf's, a box test each would exclude little */

@@ -9,6 +9,49 @@
 
 using namespace ctst;
 
+// The device's clustering (ct_shadow_tree.hip: k_nearest, k_mutual, k_merge) restated for the CPU, so that what the host does
+// with such a tree -- pair_up_leaves, four_wide_from_binary over leaves that are NOT runs of one array -- is held to the same
+// contract as the host builder's trees.  Clusters in input order (the device sorts along a curve first; any order is a tree).
+static void cluster_on_cpu(const std::vector<Box> &boxes, std::vector<BinNode> &bin, uint32_t &root, std::vector<uint32_t> &leaf_tri) {
+    const uint32_t n = (uint32_t)boxes.size(), m = 2u * n - 1u;
+    bin.assign(m, BinNode{});
+    leaf_tri.assign((size_t)n + 2u * (m - n), 0u);
+    std::vector<uint32_t> cluster(n), next;
+    for (uint32_t i = 0; i < n; i++) { bin[i].box = boxes[i]; bin[i].left = bin[i].right = kNone; bin[i].first = i; bin[i].count = 1; leaf_tri[i] = i; cluster[i] = i; }
+    uint32_t next_node = n;
+    const int r = 16;
+    while (cluster.size() > 1) {
+        const int live = (int)cluster.size();
+        std::vector<int> nearest(live);
+        for (int i = 0; i < live; i++) {
+            float best = INFINITY; int place = -1;
+            for (int d = -r; d <= r; d++) {
+                const int j = i + d;
+                if (d == 0 || j < 0 || j >= live) continue;
+                Box u = bin[cluster[i]].box; u.grow(bin[cluster[j]].box);
+                const float area = u.half_area();
+                if (area < best || place < 0) { best = area; place = j; }
+            }
+            nearest[i] = place;
+        }
+        next.clear();
+        for (int i = 0; i < live; i++) {
+            const int j = nearest[i];
+            const bool mutual = nearest[j] == i;
+            if (mutual && j < i) continue;
+            uint32_t id = cluster[i];
+            if (mutual) {
+                id = next_node++;
+                bin[id].left = cluster[i]; bin[id].right = cluster[j]; bin[id].first = 0; bin[id].count = 0;
+                bin[id].box = bin[cluster[i]].box; bin[id].box.grow(bin[cluster[j]].box);
+            }
+            next.push_back(id);
+        }
+        cluster.swap(next);
+    }
+    root = cluster[0];
+}
+
 static bool enters(const float plane[3][2], const float inv[3], const float noi[3]) {
     float tmin = -INFINITY, tmax = INFINITY;
     for (int a = 0; a < 3; a++) {
@@ -51,7 +94,19 @@ int main(int argc, char **argv) {
     opt.leaf_rho = argc > 7 ? (float)std::atoi(argv[7]) * 0.01f : 0.2f;
     double phase_ms[3] = {0, 0, 0};
     opt.phase_ms = phase_ms;
-    const uint32_t need = build_shadow_tree(boxes.data(), n, opt, gamma, bound, quads, order, remaining);
+    uint32_t need = 0;
+    if (strategy == 2 && n >= 2) {
+        std::vector<BinNode> bin;
+        std::vector<uint32_t> leaf_tri;
+        uint32_t root = 0;
+        cluster_on_cpu(boxes, bin, root, leaf_tri);
+        if (opt.leaf_max >= 2u) pair_up_leaves(bin, n, opt.leaf_rho, leaf_tri);
+        root = resplit_top(bin, root, n, n >= 64 ? 16u : 2u);          // (the top rebuilt over the subtrees of at most that many triangles)
+        need = four_wide_from_binary(bin, root, leaf_tri.data(), n, gamma, bound, threads, quads, order, remaining, phase_ms);
+        if (opt.leaf_max > 2u) opt.leaf_max = 2u;          // (pairs are all this path makes)
+    } else {
+        need = build_shadow_tree(boxes.data(), n, opt, gamma, bound, quads, order, remaining);
+    }
     if (quads.empty() || order.size() != n || remaining.size() != n) { std::printf("FAIL no nodes / orders\n"); return 1; }
     {   // order is a permutation; remaining counts down to 1 within each leaf
         std::vector<uint8_t> once(n, 0);

@@ -25,7 +25,7 @@ def _oracle():
     return oracle
 
 
-def _context(shadow_tree, desc, build=0, leaf=2, fill=20):
+def _context(shadow_tree, desc, build=0, leaf=2, fill=50):
     """a context that owns the knobs this file is about (the suite may run with CTGPU_SHADOW_TREE* in the environment)"""
     cfg = ca.config_from_environment()
     cfg.shadow_tree, cfg.shadow_tree_build, cfg.shadow_tree_leaf, cfg.shadow_tree_leaf_fill = shadow_tree, build, leaf, fill
@@ -36,7 +36,7 @@ def _context(shadow_tree, desc, build=0, leaf=2, fill=20):
 
 
 @pytest.mark.parametrize("name", ["import", "bunny"])
-@pytest.mark.parametrize("build,leaf,fill", [(0, 2, 20), (1, 1, 0), (0, 4, 60)])
+@pytest.mark.parametrize("build,leaf,fill", [(0, 2, 50), (0, 1, 0), (1, 2, 50), (2, 4, 60)])
 def test_the_tree_in_hbm(name, build, leaf, fill, scenes):
     """Every triangle under exactly one entry, every entry's box around what lies below it, a leaf's entry around its
     triangles grown by appendix D's 1/256 and by gamma; the tree's own records are the reference's, permuted, leaf by leaf;
@@ -165,7 +165,7 @@ def test_frames_and_counts_equal_the_reference_trees_walk(name, size, scenes):
     ray counts, the number of rays that found a blocker.  Supersampled and single-sample (CTGPU_SHADOW_TREE=2)."""
     scene = scenes(name)
     ref = _context(0, scene.desc)
-    trees = [_context(2, scene.desc, 0, 2, 20), _context(2, scene.desc, 1, 1, 0), _context(2, scene.desc, 0, 4, 70)]
+    trees = [_context(2, scene.desc, 0, 2, 50), _context(2, scene.desc, 1, 1, 0), _context(2, scene.desc, 2, 4, 70)]
     try:
         for ss in (True, False):
             frame = scene.frame(size[0], size[1], supersampling=ss, rng_seed=5)

@@ -27,14 +27,14 @@ def harness(tmp_path_factory):
 @pytest.mark.parametrize("layout", [0, 1, 2, 3, 4])
 def test_builder_contract(harness, layout):
     for n in (1, 2, 3, 4, 5, 9, 17, 300, 5000):
-        for strategy in (0, 1):
-            for leaf, fill in ((1, 0), (2, 20), (4, 70)):
+        for strategy in (0, 1, 2):             # 2: a tree as the device's clustering makes them (restated in the harness), through the host's four-wide pass
+            for leaf, fill in ((1, 0), (2, 50), (4, 70)):
                 out = subprocess.run([harness, str(n), str(11 + n), str(strategy), str(layout), "1", str(leaf), str(fill)],
                                      capture_output=True, text=True, timeout=120)
                 assert out.returncode == 0 and out.stdout.startswith("OK"), (n, strategy, layout, leaf, fill, out.stdout, out.stderr[-2000:])
 
 
 def test_builder_on_several_threads(harness):
-    for layout, leaf in ((0, 2), (4, 4)):
-        out = subprocess.run([harness, "90000", "5", "0", str(layout), "6", str(leaf), "30"], capture_output=True, text=True, timeout=300)
+    for layout, leaf, strategy in ((0, 2, 0), (4, 4, 0), (0, 2, 2)):
+        out = subprocess.run([harness, "140000", "5", str(strategy), str(layout), "6", str(leaf), "30"], capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and out.stdout.startswith("OK"), (out.stdout, out.stderr[-2000:])

@@ -15,7 +15,7 @@ FILES = {"cube": "scene_file_cube.json", "import": "scene_import.json", "bunny":
          "dragon": "scene_import_dragon.json", "one": "scene_file_1.json"}
 args = sys.argv[1:]
 size = (1920, 1080)
-builds = [(0, 2, 20)]
+builds = [(0, 2, 50)]
 single = False
 names = []
 i = 0
