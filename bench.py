@@ -57,6 +57,9 @@ def parse_args(argv=None):
     ap.add_argument("--supersampling", type=int, default=-1, help="-1: scene file's setting")
     ap.add_argument("--inflight", type=int, default=0, help="frames in flight (1 = strictly serial frames; default 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--orbit", type=int, default=16,
+                    help="views of the moving-camera leg (value_moving_camera: the same K frames, every frame another of this many "
+                         "rotations of the camera, the way a viewer re-renders -- raythread.cpp:557-572); 0: no such leg")
     ap.add_argument("--cpu-seconds", type=float, default=60.0, help="budget of the CPU baseline leg (it drops variants to fit)")
     ap.add_argument("--collective", default="native", choices=["native", "torch", "host"],
                     help="N > 1: the RCCL gather issued by libctgpu.so (default), by torch.distributed, or -- a REHEARSAL for boxes "
@@ -295,6 +298,7 @@ def main():
     scene = ca.HostScene(os.path.join(ROOT, "assets", SCENE_FILES[args.scene]))
     ss = None if args.supersampling < 0 else bool(args.supersampling)
     frame = scene.frame(args.width, args.height, supersampling=ss, rng_mode=ca.RNG_HASH, rng_seed=0)
+    frame_still = frame
     is_ss = bool(frame.flags & ca.F_SUPERSAMPLE)
     tile_rows = 8
     lights = [scene.desc.lights[i] for i in range(scene.desc.n_lights)]
@@ -397,11 +401,25 @@ def main():
         e.record(stream)
         return e
 
-    def one_frame(i, to_host=True, record=False):
+    # The moving-camera leg's views: the camera turned about its vertical and horizontal axes in steps of pi/64 (a quarter
+    # of the reference's key step, raythread.cpp:405-420: a viewer re-renders only when the camera moved, :557-562), a
+    # fixed list every rank walks in the same order.  The headline renders ONE view over and over, which keeps the same
+    # nodes in the caches; this says what a moving viewer gets.
+    views = []
+    for k in range(max(args.orbit, 0)):
+        import copy as _copy
+        f = _copy.copy(frame)
+        yaw = ((k * 5) % args.orbit - args.orbit // 2) * (np.pi / 64) * (8.0 / max(args.orbit, 8))
+        pitch = ((k * 3) % 5 - 2) * (np.pi / 128)
+        f.cam_rot = ca.camera_rotation(yaw, pitch, 0.0)
+        views.append(f)
+
+    def one_frame(i, to_host=True, record=False, moving=False):
         """Issue frame i: trace my tiles, gather to rank 0, assemble there, copy to the host framebuffer -- all
         asynchronous on the slot's stream."""
         s = slots[i % inflight]
         stream = s["stream"]
+        frame = views[i % len(views)] if moving else frame_still
         with torch.cuda.stream(stream):
             if s["native"]:         # (its phases are timed inside the library: ctgpu_read_phase_times)
                 s["ctx"].render_sharded(frame, tile_rows, s["fb"].data_ptr() if rank == 0 else 0, stream.cuda_stream)
@@ -434,14 +452,21 @@ def main():
                     phase_events.append(("d2h", e3, mark(stream)))
         return s
 
-    def timed(n_frames, to_host, record=False):
+    def timed(n_frames, to_host, record=False, moving=False):
         sync_all()
         t0 = time.perf_counter()
         for i in range(n_frames):
-            one_frame(i, to_host, record)
+            one_frame(i, to_host, record, moving)
         sync_all()
         return time.perf_counter() - t0
 
+    # what the communicator itself reports (ncclCommUserRank / ncclCommCount through ctgpu_comm_rank): [rank, ranks]
+    comm_seen = None
+    if use_comm and slots[0]["native"]:
+        try:
+            comm_seen = list(slots[0]["ctx"].comm_rank())
+        except RuntimeError as e:
+            comm_seen = "ctgpu_comm_rank failed: %s" % e
     # Warm-up.  Its first frames are also the native gather's first real use with this many ranks: should the library's
     # own RCCL path fail on some rank (an error, not a hang), every rank hears of it in the MIN below and all of them go
     # on with the gather through torch.distributed -- a number measured with the second-best collective, and saying so,
@@ -473,6 +498,8 @@ def main():
 
     counted = [s["ctx"].read_counters() for s in slots]
     times = [s["ctx"].read_kernel_times() for s in slots]
+    # (the last TIMED frame, as it arrived in the pinned host framebuffer: what the parity check compares -- the legs below draw over it)
+    headline_last = slots[(args.steps - 1) % inflight]["host_fb"].numpy().view(np.uint32).reshape(frame.height, frame.width).copy() if rank == 0 else None
     phases = {"trace": 0.0, "gather": 0.0, "assemble": 0.0, "d2h": 0.0}
     for s in slots:
         if s["native"]:
@@ -514,6 +541,24 @@ def main():
         t = torch.tensor([elapsed_device], dtype=torch.float64, device=red_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed_device = float(t.item())
+    # ---- the moving-camera leg: the same K frames, delivered to the host like the headline's, every frame another view
+    moving = None
+    if views:
+        for i in range(len(views)):              # (every view once, untimed: first-touch effects are not what is asked)
+            one_frame(i, True, False, True)
+        sync_all()
+        for s in slots:
+            s["ctx"].read_counters()
+        elapsed_moving = timed(args.steps, to_host=True, moving=True)
+        moved = [s["ctx"].read_counters() for s in slots]
+        t = torch.tensor([float(sum(c.rays for c in moved)), elapsed_moving], dtype=torch.float64, device=red_device)
+        if use_dist:
+            rays_sum = t[:1].clone(); dist.all_reduce(rays_sum, op=dist.ReduceOp.SUM)
+            t_max = t[1:].clone(); dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+            t = torch.cat([rays_sum, t_max])
+        moving = {"rays": float(t[0].item()), "elapsed": float(t[1].item()), "last_view": (args.steps - 1) % len(views)}
+        if rank == 0:
+            moving["last_frame"] = slots[(args.steps - 1) % inflight]["host_fb"].numpy().view(np.uint32).reshape(frame.height, frame.width).copy()
     serial = 5
     slots[0]["ctx"].kernel_timing(True)
     sync_all()
@@ -554,6 +599,12 @@ def main():
             "ct_shade": samples * (8 + (8 if is_ss else 0) + n_lights) + hits * 60 + pixels * 4,
         }
         alone_ms = [alone.total_ms[k] / max(alone.launches[k], 1) for k in range(5)]
+        # (the shadow rays' kernel by the name rocprofv3 shows it under: ct_walk_shadow_tree where the shadow tree took them)
+        path = counted[0].path()
+        KERNELS = list(globals()["KERNELS"])
+        if path["shadow_tree"]:
+            KERNELS[3] = "ct_walk_shadow_tree"
+            own["ct_walk_shadow_tree"] = own.pop("ct_walk_packet<shadow>")
         kernels = {KERNELS[k]: {"avg_ms": round(alone_ms[k], 4), "avg_ms_inflight": round(avg_ms[k], 4), "launches_inflight": int(launches[k]),
                                 "own_bytes": int(own[KERNELS[k]]),
                                 "own_GB/s": round(own[KERNELS[k]] / max(alone_ms[k], 1e-9) / 1e6, 1)} for k in range(5)}
@@ -606,7 +657,8 @@ def main():
                     "achieved_inflight": round(achieved_inflight, 1), "frac_inflight": round(achieved_inflight / HBM_PEAK_GBS, 4),
                     "bytes_per_launch": int(own[dom_name]),
                     "bytes_model": "the kernel's own requests: QuadNodes fetched x 128 B + triangle records fetched x 80 B "
-                                   "(counted by the kernel) + its per-sample / per-ray arrays",
+                                   "(counted by the kernel) + its per-sample / per-ray arrays" +
+                                   (" (ct_walk_shadow_tree: the shadow tree's nodes and its own copy of the records, same sizes)" if path["shadow_tree"] and dom == 3 else ""),
                     "per_launch": {"rays": int(per_launch_shadow if dom == 3 else per_launch_primary),
                                    "packets": int(packets[1 if dom == 3 else 0]), "quad_nodes": int(quads[1 if dom == 3 else 0]),
                                    "triangle_records": int(records[1 if dom == 3 else 0]),
@@ -658,6 +710,10 @@ def main():
             "build_id": {"libctgpu": ca.gpu_library().ctgpu_build_id().decode(), "libcthost": ca.host_library().cth_build_id().decode(),
                          "kernel_source_hash": kernel_source_hash()},
             "frames_in_flight": inflight, "ms_frame_latency": round(latency_ms, 4),
+            "path": dict(path, note="which code rendered the timed frames (ctgpu_stats): several paths give the same pixels, the context "
+                                    "picks by scene and frame kind; shadow_rays_left: per read, rays the shadow tree left to the reference-tree launch"),
+            "shadow_tree": {"nodes": int(scene_info.shadow_tree_nodes), "stack": int(scene_info.shadow_tree_pending),
+                            "build_ms": round(scene_info.shadow_tree_ms, 2), "gamma": scene_info.shadow_tree_gamma},
             "scene_setup": {"what": "vertices in host memory -> BuildBVH + walk layouts in HBM (ctgpu_upload_scene without a tree), "
                                     "once per rank; the frames in flight share that one copy",
                             "wall_ms": round(scene_setup_ms, 2), "device_build_ms": round(scene_info.build_ms, 3),
@@ -670,18 +726,31 @@ def main():
                         "(with several frames in flight they overlap other frames' work, so they do not add up to ms_per_step); "
                         "gather_ms on rank 0 ends when the slowest rank's tiles have arrived; wall_ms = that rank's wall time per frame",
                 "tile_rows": tile_rows,
+                "collective_used": collective, "native_gather": bool(slots[0]["native"]),
+                "rccl_ranks": comm_seen,
                 "ranks": [{"rank": r, "rays": int(v[0]), "trace_ms": round(v[1], 4), "gather_ms": round(v[2], 4),
                            "assemble_ms": round(v[3], 4), "d2h_ms": round(v[4], 4), "tile_pixels": int(v[5]),
                            "row_tiles": int(v[5]) // max(1, tile_rows * 2 * (frame.height // 2)), "wall_ms": round(v[6], 4)}
                           for r, v in enumerate(per_rank)]},
         }
+        if moving is not None:
+            out["value_moving_camera"] = round(moving["rays"] / moving["elapsed"] / 1e6, 2)
+            out["ms_per_step_moving_camera"] = round(moving["elapsed"] / args.steps * 1e3, 4)
+            out["moving_camera"] = {"views": len(views), "rays_per_frame": int(moving["rays"] / args.steps),
+                                    "what": "the timed region once more, every frame another of `views` camera rotations (yaw / pitch in steps "
+                                            "of pi/64 about the scene file's view), each frame delivered to the pinned host framebuffer",
+                                    "vs_still": round(out["value_moving_camera"] / max(out["value"], 1e-9), 4)}
         if world == 1 and not args.no_cpu_baseline:
-            last = slots[(args.steps - 1) % inflight]["host_fb"].numpy().view(np.uint32).reshape(frame.height, frame.width)
-            out["cpu_baseline"], out["parity"] = cpu_baseline(ca, scene, frame, last, args.cpu_seconds)
+            if moving is not None:
+                # the last timed frame of the moving-camera leg against the oracle's frame of that view, whole
+                from oracle import oracle as _oracle
+                want, _ = _oracle.render(scene.desc, views[moving["last_view"]], os_threads=0)
+                out["moving_camera"]["parity"] = {"view": moving["last_view"], "differing_pixels": int((want != moving["last_frame"]).sum()),
+                                                  "pixels": int(want.size)}
+            out["cpu_baseline"], out["parity"] = cpu_baseline(ca, scene, frame, headline_last, args.cpu_seconds)
             out["speedup_vs_cpu_ms_per_frame"] = round(out["cpu_baseline"]["ms_per_frame"] / ms_per_step, 1)
         if args.dump_frame:
-            last = slots[(args.steps - 1) % inflight]["host_fb"].numpy().view(np.uint32).reshape(frame.height, frame.width)
-            np.save(args.dump_frame, last)
+            np.save(args.dump_frame, headline_last)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     for s in slots:

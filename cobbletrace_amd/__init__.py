@@ -13,7 +13,7 @@ is missing -- there is no CPU fallback.
 """
 from .bindings import (  # noqa: F401
     FrameDesc, Hit, Light, Material, Node, Partition, Ray, SceneDesc, Sphere, Stats, WalkWork, KernelTimes, PhaseTimes, SceneInfo,
-    GpuContext, HostScene, NativeLibraryMissing, Config, default_config, config_from_environment,
+    GpuContext, HostScene, NativeLibraryMissing, Config, default_config, config_from_environment, camera_rotation,
     F_SUPERSAMPLE, F_SUBSAMPLE, F_SPHERES, F_REFLECT_FIX, RNG_HASH, RNG_LIBC, LIGHT_POINT, LIGHT_DIRECTIONAL, LIGHT_AMBIENT,
     build_bvh_on_device, gpu_library, host_library, identity_rotation, repo_root,
 )

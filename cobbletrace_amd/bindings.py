@@ -155,6 +155,17 @@ def identity_rotation():
     return (C.c_double * 9)(1.0, 0.0, 0.0, 0.0, 1.0, 0.0, -0.0, 0.0, 1.0)
 
 
+def camera_rotation(yaw, pitch, roll):
+    """camera.rotation for the angles HandleKeyboard accumulates (raythread.cpp:564-572): products of binary32 sines and
+    cosines, stored as doubles.  (numpy's float32 sin / cos may differ from glibc's in the last place; whoever compares two
+    renderers hands both this one matrix.)"""
+    f = np.float32
+    cy, sy, cp, sp, cr, sr = (f(np.cos(f(yaw))), f(np.sin(f(yaw))), f(np.cos(f(pitch))), f(np.sin(f(pitch))), f(np.cos(f(roll))), f(np.sin(f(roll))))
+    return (C.c_double * 9)(float(cy * cp), float(cy * sp * sr - sy * cr), float(cy * sp * cr + sy * sr),
+                            float(sy * cp), float(sy * sp * sr + cy * cr), float(sy * sp * cr - cy * sr),
+                            float(-sy), float(cp * sr), float(cp * cr))
+
+
 # ------------------------------------------------------------------ library loading
 _GPU_SYMBOLS = {
     # name: (restype, argtypes)
@@ -186,6 +197,7 @@ _GPU_SYMBOLS = {
     "ctgpu_comm_share": (C.c_int, [C.c_void_p, C.c_void_p]),
     "ctgpu_comm_rank": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "ctgpu_comm_destroy": (C.c_int, [C.c_void_p]),
+    "ctgpu_comm_debug_skew": (C.c_int, [C.c_void_p, C.c_int]),
     "ctgpu_gather_tiles": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int, C.c_void_p]),
     "ctgpu_render_sharded": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.c_int, C.c_void_p, C.c_void_p]),
     "ctgpu_download_frame": (C.c_int, [C.c_void_p, C.POINTER(FrameDesc), C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -597,6 +609,15 @@ class GpuContext:
     def comm_init(self, unique_id, rank, world):
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
         self._check(self.lib.ctgpu_comm_init(self.handle, buf, rank, world))
+
+    def comm_rank(self):
+        """(rank, world) as the communicator itself reports them (ncclCommUserRank / ncclCommCount where this RCCL has them)"""
+        r, w = C.c_int(0), C.c_int(0)
+        self._check(self.lib.ctgpu_comm_rank(self.ctx, C.byref(r), C.byref(w)))
+        return r.value, w.value
+
+    def comm_debug_skew(self, delta):
+        self._check(self.lib.ctgpu_comm_debug_skew(self.ctx, int(delta)))
 
     def comm_share(self, owner):
         self._check(self.lib.ctgpu_comm_share(self.handle, owner.handle))

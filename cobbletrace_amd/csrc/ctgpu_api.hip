@@ -220,6 +220,8 @@ struct ctgpu_ctx {
     } order;
 
     ctgpu_comm_state *comm = nullptr;           // ctgpu_comm_init: this rank's RCCL communicator
+    ctgpu_comm_stamp comm_stamp;                // which of the communicator's frames this context issues (ctgpu_comm.hip)
+    DeviceArray<unsigned long long> comm_tags;  // [2 + 2 * world]: my stamp, then (root) every rank's
     std::vector<void *> multi_comms;            // ctgpu_render_multi: one communicator per device, kept by the root context
     std::vector<int> multi_devices;
     bool multi_comm_failed = false;             // RCCL could not serve ctgpu_render_multi once: peer copies from then on
@@ -452,6 +454,15 @@ static int create_resources(ctgpu_ctx *ctx) {
 }
 
 ctgpu_comm_state *&ctgpu_comm_slot(ctgpu_ctx *ctx) { return ctx->comm; }
+ctgpu_comm_stamp &ctgpu_comm_stamp_of(ctgpu_ctx *ctx) { return ctx->comm_stamp; }
+int ctgpu_comm_stamp_buffers(ctgpu_ctx *ctx, int world, bool root, unsigned long long **mine, unsigned long long **all, uint32_t **flag) {
+    const size_t need = 2u + (root ? 2u * (size_t)world : 0u);
+    if (ctx->comm_tags.count < need) HIP_TRY(ctx->comm_tags.resize(need));
+    *mine = ctx->comm_tags.ptr;
+    *all = root ? ctx->comm_tags.ptr + 2 : nullptr;
+    *flag = ctx->overflow.ptr;
+    return CTGPU_OK;
+}
 int ctgpu_device_of(const ctgpu_ctx *ctx) { return ctx->device; }
 // one mark of a sharded frame's phases (ctgpu_read_phase_times); nothing happens unless timing is on
 int ctgpu_phase_mark(ctgpu_ctx *ctx, int which, hipStream_t stream) {
@@ -1113,6 +1124,11 @@ uint32_t tile_count(const FrameParams &P) { return ((P.square + 7u) / 8u) * ((P.
 int check_overflow(ctgpu_ctx *ctx) {
     uint32_t flag = 0;
     HIP_TRY(hipMemcpy(&flag, ctx->overflow.ptr, sizeof flag, hipMemcpyDeviceToHost));
+    if (flag & 4u) {
+        HIP_TRY(hipMemset(ctx->overflow.ptr, 0, sizeof flag));
+        return ctgpu_fail(CTGPU_ERR_COMM, "a gather brought together tiles of DIFFERENT frames: contexts that share a communicator (ctgpu_comm_share) "
+                          "must issue their sharded frames in the same order on every rank -- the framebuffers since the last check are not to be trusted");
+    }
     if (flag == 2u) {
         HIP_TRY(hipMemset(ctx->overflow.ptr, 0, sizeof flag));
         return ctgpu_fail(CTGPU_ERR_HIP, "the shadow walk found its kernel arguments laid out differently from what it re-reads (ct_pipeline.hip, kernarg_again): nothing was traced");

@@ -34,6 +34,8 @@ struct Rccl {
     decltype(&ncclGroupStart) group_start = nullptr;
     decltype(&ncclGroupEnd) group_end = nullptr;
     decltype(&ncclGetErrorString) error_string = nullptr;
+    decltype(&ncclCommCount) comm_count = nullptr;              // (optional: what the communicator itself says)
+    decltype(&ncclCommUserRank) comm_user_rank = nullptr;
     std::string why;            // set when loading failed
 };
 
@@ -68,6 +70,10 @@ Rccl &rccl() {
         RESOLVE(group_end, "ncclGroupEnd");
         RESOLVE(error_string, "ncclGetErrorString");
 #undef RESOLVE
+        if (ok) {
+            api.comm_count = reinterpret_cast<decltype(api.comm_count)>(dlsym(api.lib, "ncclCommCount"));
+            api.comm_user_rank = reinterpret_cast<decltype(api.comm_user_rank)>(dlsym(api.lib, "ncclCommUserRank"));
+        }
         if (!ok) api.lib = nullptr;
     });
     return api;
@@ -98,7 +104,56 @@ struct ctgpu_comm_state {
     int rank = 0, world = 1;
     int device = 0;
     int users = 1;              // contexts holding this communicator (ctgpu_comm_share)
+    uint32_t joined = 1;        // ... ever (the next sharer's place among them)
 };
+
+// ---- the order of the gathers
+// RCCL runs the collectives of one communicator in the order each rank issued them.  With several frames in flight
+// (contexts sharing the communicator) that is the right frames meeting only if every rank issues its contexts' frames in
+// the same order -- which the caller promises (bench.py: round robin) and nobody could see being broken: tiles of two
+// different frames would assemble into a plausible picture.  So every sharded frame's gather travels with a second, tiny
+// one: {the issuing context's place among the sharers, the number of frames it has issued}.  The root compares every rank's
+// pair with its own expectation and raises bit 2 of the context's error word, which the next counter read reports.
+__global__ void k_stamp(unsigned long long *mine, unsigned long long place, unsigned long long frames) { mine[0] = place; mine[1] = frames; }
+__global__ void k_compare_stamps(const unsigned long long *all, int world, unsigned long long place, unsigned long long frames, uint32_t *flag) {
+    const int r = (int)threadIdx.x;
+    if (r < world && (all[2 * r] != place || all[2 * r + 1] != frames)) atomicOr(flag, 4u);
+}
+namespace {
+int gather_with_stamp(ctgpu_ctx *ctx, ctgpu_comm_state *s, const void *d_tiles, uint64_t n, void *d_all, hipStream_t stream) {
+    ctgpu_comm_stamp &stamp = ctgpu_comm_stamp_of(ctx);
+    unsigned long long *mine = nullptr, *all = nullptr;
+    uint32_t *flag = nullptr;
+    int rc = ctgpu_comm_stamp_buffers(ctx, s->world, s->rank == 0, &mine, &all, &flag); if (rc) return rc;
+    const unsigned long long expected = stamp.frames;
+    stamp.frames += 1;
+    hipLaunchKernelGGL(k_stamp, dim3(1), dim3(1), 0, stream, mine, (unsigned long long)stamp.index, (unsigned long long)((long long)expected + stamp.skew));
+    HIP_TRY(hipGetLastError());
+    if (!s->comm) return ctgpu_fail(CTGPU_ERR_COMM, "this context's communicator was aborted after an earlier failure");
+    RCCL_TRY(rccl().group_start());
+    const ncclResult_t a = rccl().gather(d_tiles, d_all, (size_t)n, ncclUint32, 0, s->comm, stream);
+    const ncclResult_t b = rccl().gather(mine, all, 2, ncclUint64, 0, s->comm, stream);
+    const ncclResult_t e = rccl().group_end();
+    if (a != ncclSuccess) return ctgpu_fail(CTGPU_ERR_COMM, "ncclGather (tiles): %s", rccl().error_string(a));
+    if (b != ncclSuccess) return ctgpu_fail(CTGPU_ERR_COMM, "ncclGather (stamps): %s", rccl().error_string(b));
+    if (e != ncclSuccess) return ctgpu_fail(CTGPU_ERR_COMM, "ncclGroupEnd: %s", rccl().error_string(e));
+    if (s->rank == 0) {
+        if (s->world > 1024) return CTGPU_OK;
+        hipLaunchKernelGGL(k_compare_stamps, dim3(1), dim3(1024), 0, stream, (const unsigned long long *)all, s->world,
+                           (unsigned long long)stamp.index, expected, flag);
+        HIP_TRY(hipGetLastError());
+    }
+    return CTGPU_OK;
+}
+}  // namespace
+
+// test hook: from now on this context stamps its sharded frames `delta` frames off (what a rank that issued its contexts'
+// frames in another order than the root would send); 0 ends it
+extern "C" int ctgpu_comm_debug_skew(ctgpu_ctx *ctx, int delta) {
+    if (!ctx) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_comm_debug_skew: null argument");
+    ctgpu_comm_stamp_of(ctx).skew = delta;
+    return CTGPU_OK;
+}
 
 static_assert(CTGPU_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "ctgpu.h promises room for an ncclUniqueId");
 
@@ -124,6 +179,7 @@ extern "C" int ctgpu_comm_init(ctgpu_ctx *ctx, const void *id, int rank, int wor
     RCCL_TRY(rccl().comm_init_rank(&comm, world, uid, rank));
     slot = new ctgpu_comm_state();
     slot->comm = comm; slot->rank = rank; slot->world = world; slot->device = ctgpu_device_of(ctx);
+    ctgpu_comm_stamp_of(ctx) = ctgpu_comm_stamp();
     return CTGPU_OK;
 }
 
@@ -138,6 +194,8 @@ extern "C" int ctgpu_comm_share(ctgpu_ctx *ctx, ctgpu_ctx *owner) {
     if (!theirs) return ctgpu_fail(CTGPU_ERR_COMM, "ctgpu_comm_share: the other context has no communicator");
     if (theirs->device != ctgpu_device_of(ctx)) return ctgpu_fail(CTGPU_ERR_ARG, "ctgpu_comm_share: the contexts sit on different devices");
     theirs->users += 1;
+    ctgpu_comm_stamp_of(ctx) = ctgpu_comm_stamp();
+    ctgpu_comm_stamp_of(ctx).index = theirs->joined++;
     slot = theirs;
     return CTGPU_OK;
 }
@@ -160,6 +218,12 @@ extern "C" int ctgpu_comm_rank(ctgpu_ctx *ctx, int *rank, int *world) {
     if (!s) return ctgpu_fail(CTGPU_ERR_COMM, "this context has no communicator (ctgpu_comm_init)");
     if (rank) *rank = s->rank;
     if (world) *world = s->world;
+    // (what the communicator itself says, where this RCCL can be asked: a bench line then shows the ranks RCCL sees)
+    if (s->comm && rccl().comm_count && rccl().comm_user_rank) {
+        int n = 0, r = 0;
+        if (rccl().comm_count(s->comm, &n) == ncclSuccess && world) *world = n;
+        if (rccl().comm_user_rank(s->comm, &r) == ncclSuccess && rank) *rank = r;
+    }
     return CTGPU_OK;
 }
 
@@ -205,7 +269,8 @@ extern "C" int ctgpu_render_sharded(ctgpu_ctx *ctx, const ctgpu_frame_desc *fram
     if (rc != CTGPU_OK) (void)hipMemsetAsync(tiles, 0, n * sizeof(uint32_t), (hipStream_t)stream);
     const std::string first_error = rc != CTGPU_OK ? ctgpu_last_error() : "";
     (void)ctgpu_phase_mark(ctx, 1, (hipStream_t)stream);
-    const int gathered = ctgpu_gather_tiles(ctx, tiles, n, all, 0, stream);
+    HIP_TRY(hipSetDevice(ctgpu_device_of(ctx)));
+    const int gathered = gather_with_stamp(ctx, s, tiles, n, all, (hipStream_t)stream);
     (void)ctgpu_phase_mark(ctx, 2, (hipStream_t)stream);
     if (rc != CTGPU_OK) return ctgpu_fail(rc, "%s", first_error.c_str());
     if (gathered != CTGPU_OK) return gathered;

@@ -18,6 +18,18 @@ CTGPU_HIDDEN int ctgpu_device_of(const ctgpu_ctx *ctx);
 // the context's own tile buffer (n_tiles uint32) and, where n_all > 0, its gather buffer
 CTGPU_HIDDEN int ctgpu_shard_buffers(ctgpu_ctx *ctx, uint64_t n_tiles, uint64_t n_all, void **tiles, void **all);
 
+// What tells one frame's gather from another's when several contexts share a communicator (ctgpu_comm_share): the context's
+// place among the sharers and the number of sharded frames it has issued.  Every rank stamps its gather with the pair; the
+// root compares what arrived (ctgpu_comm.hip, "the order of the gathers").
+struct ctgpu_comm_stamp {
+    uint32_t index = 0;          // 0: the context that made the communicator, 1, 2, ...: the sharers in the order they joined
+    uint64_t frames = 0;         // sharded frames this context has issued
+    int64_t skew = 0;            // ctgpu_comm_debug_skew: added to what is stamped (never to what is expected)
+};
+CTGPU_HIDDEN ctgpu_comm_stamp &ctgpu_comm_stamp_of(ctgpu_ctx *ctx);
+// device words for the stamps: mine[2], and on the root all[world][2]; flag: the context's error word (4: stamps differ)
+CTGPU_HIDDEN int ctgpu_comm_stamp_buffers(ctgpu_ctx *ctx, int world, bool root, unsigned long long **mine, unsigned long long **all, uint32_t **flag);
+
 // ctgpu_render_sharded's phase marks: which = 0 start, 1 traced, 2 gathered, 3 assembled (no-op unless timing is on)
 CTGPU_HIDDEN int ctgpu_phase_mark(ctgpu_ctx *ctx, int which, hipStream_t stream);
 

@@ -339,6 +339,11 @@ int  ctgpu_comm_init(ctgpu_ctx *ctx, const void *id, int rank, int world);
 int  ctgpu_comm_share(ctgpu_ctx *ctx, ctgpu_ctx *owner);
 int  ctgpu_comm_rank(ctgpu_ctx *ctx, int *rank, int *world);
 int  ctgpu_comm_destroy(ctgpu_ctx *ctx);
+/* Contexts that share a communicator must issue their sharded frames in the same order on every rank (RCCL matches the
+ * gathers of a communicator by issue order).  ctgpu_render_sharded checks it: every frame's gather carries {the context's
+ * place among the sharers, the frames it has issued}, the root compares all ranks' pairs with its own, and a mismatch makes
+ * the next ctgpu_read_counters fail with CTGPU_ERR_COMM.  ctgpu_comm_debug_skew (test hook): stamp `delta` frames off. */
+int  ctgpu_comm_debug_skew(ctgpu_ctx *ctx, int delta);
 int  ctgpu_gather_tiles(ctgpu_ctx *ctx, const void *d_tiles, uint64_t n, void *d_all, int root, void *stream);
 int  ctgpu_render_sharded(ctgpu_ctx *ctx, const ctgpu_frame_desc *frame, int tile_rows, void *d_fb, void *stream);
 

@@ -281,6 +281,21 @@ def test_native_rccl_frame_on_a_world_of_one(scenes, gpu_ctx):
         for c, fb in zip((a, b), fbs):
             c.read_counters()
             assert (fb.cpu().numpy().view(np.uint32).reshape(frame.height, frame.width) == want).all()
+        assert a.comm_rank() == (0, 1) and b.comm_rank() == (0, 1)          # what the communicator itself reports
+        # the order of the gathers: every sharded frame's gather carries {the context's place among the sharers, its frame
+        # count}, and the root compares what arrives with its own.  A rank that issued its contexts' frames in another
+        # order would send another pair -- forced here by stamping context b one frame off: the frame still assembles
+        # (here, with one rank, even correctly), and the next counter read must refuse to vouch for it.
+        b.comm_debug_skew(1)
+        b.render_sharded(frame, 8, fbs[1].data_ptr(), streams[1].cuda_stream)
+        torch.cuda.synchronize()
+        with pytest.raises(RuntimeError, match="DIFFERENT frames"):
+            b.read_counters()
+        b.comm_debug_skew(0)
+        for c, st_, fb in zip((a, b), streams, fbs):
+            c.render_sharded(frame, 8, fb.data_ptr(), st_.cuda_stream)
+        torch.cuda.synchronize()
+        a.read_counters(); b.read_counters()        # in step again: nothing to report
         a.close()                                  # the owner goes first: the communicator lives on with b
         b.render_sharded(frame, 8, fbs[1].data_ptr(), streams[1].cuda_stream)
         torch.cuda.synchronize()
