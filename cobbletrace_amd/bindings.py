@@ -613,11 +613,11 @@ class GpuContext:
     def comm_rank(self):
         """(rank, world) as the communicator itself reports them (ncclCommUserRank / ncclCommCount where this RCCL has them)"""
         r, w = C.c_int(0), C.c_int(0)
-        self._check(self.lib.ctgpu_comm_rank(self.ctx, C.byref(r), C.byref(w)))
+        self._check(self.lib.ctgpu_comm_rank(self.handle, C.byref(r), C.byref(w)))
         return r.value, w.value
 
     def comm_debug_skew(self, delta):
-        self._check(self.lib.ctgpu_comm_debug_skew(self.ctx, int(delta)))
+        self._check(self.lib.ctgpu_comm_debug_skew(self.handle, int(delta)))
 
     def comm_share(self, owner):
         self._check(self.lib.ctgpu_comm_share(self.handle, owner.handle))
