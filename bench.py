@@ -605,6 +605,9 @@ def main():
         if path["shadow_tree"]:
             KERNELS[3] = "ct_walk_shadow_tree"
             own["ct_walk_shadow_tree"] = own.pop("ct_walk_packet<shadow>")
+        if path["closest_tree"]:
+            KERNELS[1] = "ct_walk_closest_tree"
+            own["ct_walk_closest_tree"] = own.pop("ct_walk_packet<primary>")
         kernels = {KERNELS[k]: {"avg_ms": round(alone_ms[k], 4), "avg_ms_inflight": round(avg_ms[k], 4), "launches_inflight": int(launches[k]),
                                 "own_bytes": int(own[KERNELS[k]]),
                                 "own_GB/s": round(own[KERNELS[k]] / max(alone_ms[k], 1e-9) / 1e6, 1)} for k in range(5)}
@@ -658,7 +661,7 @@ def main():
                     "bytes_per_launch": int(own[dom_name]),
                     "bytes_model": "the kernel's own requests: QuadNodes fetched x 128 B + triangle records fetched x 80 B "
                                    "(counted by the kernel) + its per-sample / per-ray arrays" +
-                                   (" (ct_walk_shadow_tree: the shadow tree's nodes and its own copy of the records, same sizes)" if path["shadow_tree"] and dom == 3 else ""),
+                                   (" (%s: the shadow tree's nodes and its own copy of the records, same sizes)" % dom_name if dom_name in ("ct_walk_shadow_tree", "ct_walk_closest_tree") else ""),
                     "per_launch": {"rays": int(per_launch_shadow if dom == 3 else per_launch_primary),
                                    "packets": int(packets[1 if dom == 3 else 0]), "quad_nodes": int(quads[1 if dom == 3 else 0]),
                                    "triangle_records": int(records[1 if dom == 3 else 0]),

@@ -66,13 +66,14 @@ class Stats(C.Structure):
                 ("pixels_written", C.c_uint64), ("node_visits", C.c_uint64), ("triangle_tests", C.c_uint64),
                 ("kernel_ms", C.c_double), ("total_ms", C.c_double), ("rays_shadow_elided", C.c_uint64),
                 ("walk_kind", C.c_uint32), ("bounce_kind", C.c_uint32), ("ordered", C.c_uint32), ("cull_tree", C.c_uint32),
-                ("shadow_tree", C.c_uint32), ("pad_", C.c_uint32), ("rays_shadow_left", C.c_uint64)]
+                ("shadow_tree", C.c_uint32), ("closest_tree", C.c_uint32), ("rays_shadow_left", C.c_uint64), ("rays_primary_left", C.c_uint64)]
 
     def path(self):
         """which code rendered the frame, as a dict (ctgpu.h CTGPU_WALK_* / CTGPU_BOUNCE_*)"""
         return {"walk": ("general", "per-lane", "packet")[self.walk_kind], "bounce": ("none", "levels", "general")[self.bounce_kind],
                 "ordered": bool(self.ordered), "cull_tree": bool(self.cull_tree), "shadow_tree": bool(self.shadow_tree),
-                "shadow_rays_left": int(self.rays_shadow_left)}
+                "closest_tree": bool(self.closest_tree), "shadow_rays_left": int(self.rays_shadow_left),
+                "primary_rays_left": int(self.rays_primary_left)}
 
     @property
     def rays(self):
@@ -110,7 +111,7 @@ class Config(C.Structure):
                 ("packet_lds_levels", C.c_int32), ("probe_above", C.c_int32), ("packet_budget", C.c_int32), ("packet_lanes", C.c_int32),
                 ("order", C.c_int32), ("order_heavy", C.c_float * 4), ("order_floor", C.c_int32), ("order_split_below", C.c_int32),
                 ("order_parts", C.c_int32 * 4), ("shadow_split_gap", C.c_float), ("big_leaf_min", C.c_int32), ("big_leaf_share", C.c_int32),
-                ("shadow_tree", C.c_int32), ("shadow_tree_build", C.c_int32), ("shadow_tree_leaf", C.c_int32),
+                ("shadow_tree", C.c_int32), ("closest_tree", C.c_int32), ("shadow_tree_build", C.c_int32), ("shadow_tree_leaf", C.c_int32),
                 ("shadow_tree_leaf_fill", C.c_int32), ("pack_on_host", C.c_int32),
                 ("thresh", C.c_int32 * 3), ("walk_thresh", C.c_int32 * 3), ("debug", C.c_uint32)]
 

@@ -42,7 +42,8 @@ struct alignas(128) QuadNode {
     float plane[4][3][2];         // [entry][axis]{min, max}: one packed fma serves both planes of an axis
     uint32_t ref[4];              // entry: kLeafBit | first TriRecord slot, or a QuadNode index
     uint32_t count;               // entries in use (2..4)
-    uint32_t pad_[3];
+    uint32_t axis;                // the shadow tree's nodes: their entries are stored in ascending order along this axis (3: not); else 0
+    uint32_t pad_[2];
 };
 static_assert(sizeof(QuadNode) == 128, "QuadNode is two s_load_dwordx16");
 
@@ -110,6 +111,7 @@ struct ShadowTreeLimits {
     float o_max;          // ... and every |o_i| <= o_max
 };
 static constexpr uint8_t kShadowLeft = 3;      // shadow byte: a needed ray the shadow tree's walk did not take
+static constexpr uint32_t kPrimaryLeft = 0xfffffffdu;    // hits[].slot: a primary ray ct_walk_closest_tree left to the reference-tree walk
 
 struct Material { uint32_t color; int32_t specular; float reflection; };
 struct Light { int32_t type; float intensity; double position[3]; double direction[3]; };

@@ -228,7 +228,7 @@ __global__ void k_quad_emit(const ctgpu_node *nodes, QuadOut out, uint32_t begin
         }
     }
     node.count = n;
-    node.pad_[0] = node.pad_[1] = node.pad_[2] = 0u;
+    node.axis = node.pad_[0] = node.pad_[1] = 0u;
     out.quads[q] = node;
     if (out.boxes) {
         double *dst = out.boxes + (size_t)q * 24;
@@ -458,7 +458,7 @@ __global__ void k_cull_emit(QuadNode *quads, uint32_t n_quads, uint32_t root, ui
                 }
             }
             node.count = used;
-            node.pad_[0] = node.pad_[1] = node.pad_[2] = 0u;
+            node.axis = node.pad_[0] = node.pad_[1] = 0u;
             quads[start[l] + i] = node;
         }
         span *= 4u;

@@ -18,18 +18,22 @@ namespace ctd {
 // 48 shadow rays ct_walk_shadow_tree left to the second shadow launch
 constexpr int kCounterWords = 50;
 constexpr int kCounterLeft = 48;
+constexpr int kCounterPrimaryLeft = 49;
 // ray-queue head words: walk 0 primary rays, walks 1..L the shadow rays of the scene's L shadow-casting lights, walks
 // L+1 / L+2 the handed-over primary / shadow rays, walks L+3..2L+2 the same lights' shadow rays once more (the second
 // shadow launch of a frame whose shadow rays walk the shadow tree: the rays that tree does not take, ct_walk_shadow_tree);
 // 8 shards each, one 128-byte line per head word; then 32 words for the two hand-over counters (everything cleared
 // together, per frame)
-__host__ __device__ constexpr uint32_t queue_walks(uint32_t n_shadow_lights) { return 2u * n_shadow_lights + 3u; }
+// walk 2L+3 the primary rays once more (the launch behind ct_walk_closest_tree: the rays it left);
+__host__ __device__ constexpr uint32_t queue_walks(uint32_t n_shadow_lights) { return 2u * n_shadow_lights + 4u; }
 __host__ __device__ constexpr uint32_t queue_second_shadow_walk(uint32_t n_shadow_lights) { return n_shadow_lights + 3u; }
+__host__ __device__ constexpr uint32_t queue_second_primary_walk(uint32_t n_shadow_lights) { return 2u * n_shadow_lights + 3u; }
 __host__ __device__ constexpr size_t queue_words(uint32_t n_shadow_lights) { return (size_t)queue_walks(n_shadow_lights) * 8u * 16u; }
 // ... and behind them: the two hand-over counters (32 words), then the head words of the heavy-chunk lists (ORDERED
 // walks: class 0 / 1 of the primary walk, class 0 / 1 of the shadow walk, 16 words apart).  One block, cleared per frame.
 __host__ __device__ constexpr size_t queue_order_heads(uint32_t n_shadow_lights) { return queue_words(n_shadow_lights) + 32u; }
-// ... and one more line: word 0 counts the shadow rays the shadow tree's walk left to the second shadow launch
+// ... and one more line: word 0 counts the shadow rays the shadow tree's walk left to the second shadow launch, word 1 the
+// primary rays ct_walk_closest_tree left to the second primary launch
 __host__ __device__ constexpr size_t queue_left_word(uint32_t n_shadow_lights) { return queue_words(n_shadow_lights) + 32u + 64u; }
 __host__ __device__ constexpr size_t queue_block_words(uint32_t n_shadow_lights) { return queue_words(n_shadow_lights) + 32u + 64u + 16u; }
 constexpr int kCounterElided = 16;
@@ -67,6 +71,8 @@ struct FrameParams {
     const TriRecord *stree_tris;  // the TriRecords in its own leaf order (a leaf entry: kLeafBit | first slot, `remaining` as in tris[])
     const uint32_t *leaf_of_slot; // slot of stree_tris -> the reference node (a leaf of ref_nodes[]) that holds that triangle
     ShadowTreeLimits stree_lim;   // which shadow rays may walk it
+    uint32_t closest_tree;        // 1: the frame's PRIMARY rays walk it too (ct_walk_closest_tree, DESIGN appendix F)
+    float    closest_tau;         // ... pruning entries beyond ray.t only while ray.t >= this (appendix D.2's tau, doubled)
 
     // frame
     int32_t  width, height, half; // bitmap size; half = height/2
@@ -155,7 +161,9 @@ struct PipelineParams {
                                  // two ranges at least this far apart (relative to the middle depth); < 0: never
     uint32_t shadow_live;        // the shadow byte that marks a ray the shadow walk has to trace: 0 (ct_light_gate), or kShadowLeft in the
                                  // launch that traces what ct_walk_shadow_tree left (it then also clears the byte of an unblocked ray)
-    unsigned long long *shadow_left;   // [1] rays ct_walk_shadow_tree left to that launch (it returns at once on 0)
+    unsigned long long *shadow_left;   // [0] rays ct_walk_shadow_tree left to that launch (it returns at once on 0); [1] the same for
+                                       // the primary rays ct_walk_closest_tree left
+    uint32_t primary_left;       // 1: this launch of the primary walk traces the samples marked kPrimaryLeft in hits[], nothing else
     uint32_t ordered;            // 1: the frame's packet walks are the ORDERED instantiations, order[] is set
     OrderParams order[2];
 };

@@ -833,7 +833,11 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
     // (the frame's shadow walk drains walks 1..L; the launch behind ct_walk_shadow_tree, which traces the rays that walk
     //  left -- W.shadow_live == kShadowLeft --, a second set of head words, and leaves at once when nothing was left)
     if (KIND == 1 && W.shadow_live != 0u && *W.shadow_left == 0ull) return;
-    unsigned long long *heads = W.queue + (size_t)(KIND != 1 ? 0u : (W.shadow_live != 0u ? queue_second_shadow_walk(W.n_shadow_lights) : 1u) * kShards) * 16u;
+    // (the same for the frame's primary rays: behind ct_walk_closest_tree this launch traces the samples that walk marked
+    //  kPrimaryLeft in hits[] and no others)
+    if (KIND == 0 && W.primary_left != 0u && W.shadow_left[1] == 0ull) return;
+    unsigned long long *heads = W.queue + (size_t)(KIND == 1 ? (W.shadow_live != 0u ? queue_second_shadow_walk(W.n_shadow_lights) : 1u) * kShards
+                                                  : (KIND == 0 && W.primary_left != 0u) ? queue_second_primary_walk(W.n_shadow_lights) * kShards : 0u) * 16u;
     const uint64_t shard_span = ((n_samples + kShards - 1) / kShards + q_chunk - 1) / q_chunk * q_chunk;
     uint32_t shard = blockIdx.x % n_shards, shards_done = 0;
     uint64_t light_base = 0, chunk_light_base = 0;       // first ray id of the packet's / the current chunk's light
@@ -1028,7 +1032,8 @@ __global__ __launch_bounds__(kWave, CT_PACKET_WAVES) void ct_walk_packet(const F
                 bool live = true;
                 if (KIND == 0) {
                     live = sample_position<SS>(P, W, id, px, py);
-                    if (!live) W.hits[id] = make_uint2(__float_as_uint(kNoHit), kInvalidSample);
+                    if (W.primary_left != 0u) live = live && W.hits[id].y == kPrimaryLeft;
+                    else if (!live) W.hits[id] = make_uint2(__float_as_uint(kNoHit), kInvalidSample);
                 } else if (KIND == 1) {
                     live = W.shadow[id] == W.shadow_live;
                 } else if (W.ray_live) {
@@ -2010,6 +2015,293 @@ __global__ __launch_bounds__(kWave, CT_STREE_WAVES) void ct_walk_shadow_tree(con
 #undef STREE_ARGS
 
 // ------------------------------------------------------------------------------------
+// ct_walk_closest_tree: the frame's PRIMARY rays through the shadow tree's nodes (DESIGN appendix F).
+// ClosestIntersection (raythread.cpp:197-228) returns ray.t = the least t over the triangle tests the reference makes and
+// the first triangle, in its visiting order, that reached it.  Which tests it makes depends on its order only through
+// pruning -- a box is skipped when its tmin is not below the ray.t found so far -- so the answer can be had from ANY walk that
+// (1) cannot miss a triangle whose test could lower or equal the least t (boxes that only exclude; an entry lying wholly
+// beyond ray.t (1 + 2^-18) excluded too, appendix D.2's third case with room to spare, while ray.t >= tau), (2) keeps the
+// least {t, place in the reference's order} over everything it tests, and (3) makes sure, for the winner alone, that the
+// reference tests it whatever it found before: its leaf's box passes the reference's own test with ray.t = the winner's t
+// (tmin < t is then certain for every ray.t the reference can have carried at that moment: all of them are >= t).  A ray
+// whose winner fails (3) -- the hit sits on the rim of its leaf's box; all hits on axis-aligned flat leaves do -- is left to a
+// second launch of ct_walk_packet<0>, like a ray outside the gate.  Same packets as the primary walk (64 consecutive sample
+// ids: four pixels' samples), same stack in the lanes of three registers; the per-lane tmin of a waiting entry sits in LDS
+// for the first kClosestLdsLevels levels (deeper ones are not pruned when popped, only when visited).
+// ------------------------------------------------------------------------------------
+constexpr uint32_t kClosestLdsLevels = 16;
+#define CT_CLOSEST_ENTRY(OUT, TMIN, PX, PY, PZ, NX, FX, NY, FY, NZ, FZ)                                \
+    "v_pk_fma_f32 v[56:57], " PX ", %20, %21 op_sel_hi:[1,0,0]\n\t"                                   \
+    "v_pk_fma_f32 v[58:59], " PY ", %20, %21 op_sel:[0,1,1] op_sel_hi:[1,1,1]\n\t"                    \
+    "v_pk_fma_f32 v[60:61], " PZ ", %22, %22 op_sel:[0,0,1] op_sel_hi:[1,0,1]\n\t"                    \
+    "v_max3_f32 " TMIN ", " NX ", " NY ", " NZ "\n\t"                                                  \
+    "v_min3_f32 v56, " FX ", " FY ", " FZ "\n\t"                                                       \
+    "v_min_f32 v56, v56, %23\n\t"                                                                      \
+    "v_max_f32 v62, 0, " TMIN "\n\t"                                                                   \
+    "v_cmp_ge_f32_e64 " OUT ", v56, v62\n\t"
+#define CT_CLOSEST_NODE(NX, FX, NY, FY, NZ, FZ)                                                       \
+    CT_CLOSEST_ENTRY("%0", "%4", "%8", "%9", "%10", NX, FX, NY, FY, NZ, FZ)                            \
+    CT_CLOSEST_ENTRY("%1", "%5", "%11", "%12", "%13", NX, FX, NY, FY, NZ, FZ)                          \
+    CT_CLOSEST_ENTRY("%2", "%6", "%14", "%15", "%16", NX, FX, NY, FY, NZ, FZ)                          \
+    CT_CLOSEST_ENTRY("%3", "%7", "%17", "%18", "%19", NX, FX, NY, FY, NZ, FZ)
+// the four entries against the packet's rays, each lane's "beyond ray.t" limit folded in: enter iff min(tmax, limit) >=
+// max(tmin, 0); tmin[k] comes back for the entries that will wait on the stack
+template <int OCT>
+__device__ __forceinline__ void node_enters_closest(const RayLine &r, const ScalarQuad &sq, float limit, unsigned long long enter[4], float tmin[4]) {
+    static_assert(OCT >= 0 && OCT < 8, "the packets whose rays share an octant");
+#define CT_CLOSEST_ASM(TEXT)                                                                                          \
+    asm volatile(TEXT : "=s"(enter[0]), "=s"(enter[1]), "=s"(enter[2]), "=s"(enter[3]), "=&v"(tmin[0]), "=&v"(tmin[1]), "=&v"(tmin[2]), "=&v"(tmin[3]) \
+                 : "s"(sq.planes(0, 0)), "s"(sq.planes(0, 1)), "s"(sq.planes(0, 2)), "s"(sq.planes(1, 0)), "s"(sq.planes(1, 1)), "s"(sq.planes(1, 2)), \
+                   "s"(sq.planes(2, 0)), "s"(sq.planes(2, 1)), "s"(sq.planes(2, 2)), "s"(sq.planes(3, 0)), "s"(sq.planes(3, 1)), "s"(sq.planes(3, 2)), \
+                   "v"(r.inv_xy), "v"(r.noi_xy), "v"(r.z), "v"(limit)                                                  \
+                 : "v56", "v57", "v58", "v59", "v60", "v61", "v62")
+    if (OCT == 0) CT_CLOSEST_ASM(CT_CLOSEST_NODE("v56", "v57", "v58", "v59", "v60", "v61"));
+    if (OCT == 1) CT_CLOSEST_ASM(CT_CLOSEST_NODE("v57", "v56", "v58", "v59", "v60", "v61"));
+    if (OCT == 2) CT_CLOSEST_ASM(CT_CLOSEST_NODE("v56", "v57", "v59", "v58", "v60", "v61"));
+    if (OCT == 3) CT_CLOSEST_ASM(CT_CLOSEST_NODE("v57", "v56", "v59", "v58", "v60", "v61"));
+    if (OCT == 4) CT_CLOSEST_ASM(CT_CLOSEST_NODE("v56", "v57", "v58", "v59", "v61", "v60"));
+    if (OCT == 5) CT_CLOSEST_ASM(CT_CLOSEST_NODE("v57", "v56", "v58", "v59", "v61", "v60"));
+    if (OCT == 6) CT_CLOSEST_ASM(CT_CLOSEST_NODE("v56", "v57", "v59", "v58", "v61", "v60"));
+    if (OCT == 7) CT_CLOSEST_ASM(CT_CLOSEST_NODE("v57", "v56", "v59", "v58", "v61", "v60"));
+#undef CT_CLOSEST_ASM
+}
+// (the packets whose rays point different ways: each axis' two parameters sorted per lane)
+__device__ __forceinline__ bool line_enters_closest(const RayLine &r, f32x2 px, f32x2 py, f32x2 pz, float limit, float &tmin) {
+    f32x2 tx, ty, tz;
+    float tmax, from, nx, ny, nz, fx, fy, fz;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(tx) : "s"(px), "v"(r.inv_xy), "v"(r.noi_xy));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,1] op_sel_hi:[1,1,1]" : "=v"(ty) : "s"(py), "v"(r.inv_xy), "v"(r.noi_xy));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(tz) : "s"(pz), "v"(r.z), "v"(r.z));
+    asm("v_min_f32 %0, %1, %2" : "=v"(nx) : "v"(tx.x), "v"(tx.y));
+    asm("v_min_f32 %0, %1, %2" : "=v"(ny) : "v"(ty.x), "v"(ty.y));
+    asm("v_min_f32 %0, %1, %2" : "=v"(nz) : "v"(tz.x), "v"(tz.y));
+    asm("v_max_f32 %0, %1, %2" : "=v"(fx) : "v"(tx.x), "v"(tx.y));
+    asm("v_max_f32 %0, %1, %2" : "=v"(fy) : "v"(ty.x), "v"(ty.y));
+    asm("v_max_f32 %0, %1, %2" : "=v"(fz) : "v"(tz.x), "v"(tz.y));
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(tmin) : "v"(nx), "v"(ny), "v"(nz));
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(tmax) : "v"(fx), "v"(fy), "v"(fz));
+    asm("v_min_f32 %0, %1, %2" : "=v"(tmax) : "v"(tmax), "v"(limit));
+    asm("v_max_f32 %0, 0, %1" : "=v"(from) : "v"(tmin));
+    return tmax >= from;
+}
+// what "beyond ray.t" means for a lane: entries whose tmin exceeds this are skipped (appendix F.2)
+__device__ __forceinline__ float closest_limit(float t, float tau) { return t >= tau ? t * (1.0f + 0x1p-18f) : __builtin_inff(); }
+
+template <bool SS>
+__global__ __launch_bounds__(kWave, CT_STREE_WAVES) void ct_walk_closest_tree(const FrameParams P_launch, const PipelineParams W_launch) {
+    FrameParams P = P_launch;
+    PipelineParams W = W_launch;
+    const uint32_t q_chunk = W.chunk;
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    float __attribute__((address_space(3))) *waiting_tmin = (float __attribute__((address_space(3))) *)lds_raw;      // [kClosestLdsLevels][64]
+    const uint32_t lane = threadIdx.x;
+    const uint64_t n_samples = W.n_samples;
+    unsigned long long *heads = W.queue;
+    const uint64_t shard_span = ((n_samples + kShards - 1) / kShards + q_chunk - 1) / q_chunk * q_chunk;
+    uint32_t shard = blockIdx.x % kShards, shards_done = 0;
+    d3 eye = make_d3(P.cam[0], P.cam[1], P.cam[2]);
+    uint64_t chunk_next = 0, chunk_end = 0;
+    bool wave_drained = false;
+    uint32_t n_traced = 0, n_left = 0, n_packets = 0, n_quads = 0, n_records = 0;
+    const unsigned char *nodes_base = (const unsigned char *)P.stree, *nodes_base64 = nodes_base + 64;
+    const unsigned char *tris_base = (const unsigned char *)P.stree_tris, *tris_base64 = tris_base + 64;
+    const float tau = P.closest_tau;
+
+    for (;;) {
+        asm volatile("" : "+s"(eye.x), "+s"(eye.y), "+s"(eye.z));      // (as in ct_walk_packet<0>: nothing derived from the eye is kept across packets)
+        // ---------------- fetch a packet: 64 consecutive sample ids
+        if (chunk_next >= chunk_end) {
+            if (wave_drained) break;
+            unsigned long long offset = 0;
+            if (lane == 0) offset = atomicAdd(heads + (size_t)shard * 16u, (unsigned long long)q_chunk);
+            offset = (unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)offset) |
+                     ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(offset >> 32)) << 32);
+            const uint64_t lo = (uint64_t)shard * shard_span + offset;
+            if (offset >= shard_span || lo >= n_samples) {
+                shards_done += 1;
+                shard = (shard + 1u) % kShards;
+                if (shards_done >= kShards) wave_drained = true;
+                continue;
+            }
+            uint64_t hi = lo + q_chunk;
+            if (hi > ((uint64_t)shard + 1u) * shard_span) hi = ((uint64_t)shard + 1u) * shard_span;
+            if (hi > n_samples) hi = n_samples;
+            chunk_next = lo; chunk_end = hi;
+        }
+        const uint64_t packet_base = chunk_next;
+        const uint64_t avail = chunk_end - chunk_next;
+        chunk_next += avail < 64u ? avail : 64u;
+        const uint64_t id = packet_base + lane;
+        float px = 0.0f, py = 0.0f;
+        bool has_ray = lane < avail;
+        if (has_ray) {
+            has_ray = sample_position<SS>(P, W, id, px, py);
+            if (!has_ray) W.hits[id] = make_uint2(__float_as_uint(kNoHit), kInvalidSample);
+        }
+        if (__ballot(has_ray) == 0ull) continue;
+        // ---------------- the rays (raythread.cpp:186-194, 462-508) and the gate
+        d3 d = make_d3(0, 0, 1);
+        RayLine rl = RayLine{};
+        bool left = false;
+        if (has_ray) {
+            d = primary_direction(P, px, py);
+            const d3 inv = make_d3(quick_reciprocal(d.x), quick_reciprocal(d.y), quick_reciprocal(d.z));
+            rl.inv_xy = f32x2{(float)inv.x, (float)inv.y};
+            rl.noi_xy = f32x2{-(float)(eye.x * inv.x), -(float)(eye.y * inv.y)};
+            rl.z = f32x2{(float)inv.z, -(float)(eye.z * inv.z)};
+            const double d_min = (double)P.stree_lim.d_min, d_max = (double)P.stree_lim.d_max;
+            const double ax = __builtin_fabs(d.x), ay = __builtin_fabs(d.y), az = __builtin_fabs(d.z);
+            left = !(ax >= d_min && ax <= d_max && ay >= d_min && ay <= d_max && az >= d_min && az <= d_max);      // (the eye itself: checked by the host)
+        }
+        float t = kNoHit, limit = __builtin_inff();
+        uint32_t best = kNoNode;                  // the winner's place in the reference's order (= its TriRecord slot there)
+        uint32_t hit_at = 0u;                     // ... and the byte offset of its record in the tree's own order
+        const unsigned long long rays = __ballot(has_ray && !left);
+        n_traced += (uint32_t)__popcll(rays);
+        if (rays != 0ull) {
+        n_packets += 1;
+        uint32_t octant = 8u;
+        {
+            const unsigned long long down_x = __ballot(has_ray && !left && __float_as_int(rl.inv_xy.x) < 0);
+            const unsigned long long down_y = __ballot(has_ray && !left && __float_as_int(rl.inv_xy.y) < 0);
+            const unsigned long long down_z = __ballot(has_ray && !left && __float_as_int(rl.z.x) < 0);
+            if ((down_x == 0ull || down_x == rays) && (down_y == 0ull || down_y == rays) && (down_z == 0ull || down_z == rays))
+                octant = (down_x ? 1u : 0u) | (down_y ? 2u : 0u) | (down_z ? 4u : 0u);
+        }
+        uint32_t cur = 0u;
+        unsigned long long mask = rays;
+        uint32_t sp = 0;
+        int stack_ref = 0, stack_mask_lo = 0, stack_mask_hi = 0;
+
+        auto shared_walk = [&](auto octant_tag) {
+        constexpr int OCT = decltype(octant_tag)::value;
+        while (mask != 0ull) {
+            if (cur & kLeafBit) {
+                const uint32_t first = cur & ~kLeafBit;
+                const bool mine = __builtin_amdgcn_inverse_ballot_w64(mask);
+                uint32_t count = 1;
+                for (uint32_t k = 0; k < count; k++) {
+                    const ScalarTri tr = scalar_load_tri_at(tris_base, tris_base64, first + k * (uint32_t)sizeof(TriRecord));
+                    if (k == 0) { count = tr.remaining(); n_records += count; }
+                    if (mine) {
+                        const d3 p1 = make_d3(tr.f64(0), tr.f64(1), tr.f64(2)), e1 = make_d3(tr.f64(3), tr.f64(4), tr.f64(5)),
+                                 e2 = make_d3(tr.f64(6), tr.f64(7), tr.f64(8));
+                        float found = kNoHit;           // what THIS test would make of ray.t = 1e30f: its own t where it would lower it
+                        (void)triangle_test(eye, d, found, p1, e1, e2);
+                        const uint32_t place = (uint32_t)tr.b[2];          // (this tree's records carry their slot in the reference's order)
+                        // the least t; among equal ones the triangle the reference meets first (bvh.cpp:212: strict <)
+                        if (found < t || (found == t && found != kNoHit && place < best)) {
+                            t = found; best = place; hit_at = first + k * (uint32_t)sizeof(TriRecord);
+                            limit = closest_limit(t, tau);
+                        }
+                    }
+                }
+                mask = 0ull;
+            } else {
+                n_quads += 1;
+                const ScalarQuad sq = scalar_load_quad_at(nodes_base, nodes_base64, cur);
+                unsigned long long enter[4];
+                float tmin[4];
+                if constexpr (OCT < 8) {
+                    node_enters_closest<OCT>(rl, sq, limit, enter, tmin);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) enter[k] &= mask;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        enter[k] = __ballot(line_enters_closest(rl, sq.planes(k, 0), sq.planes(k, 1), sq.planes(k, 2), limit, tmin[k])) & mask;
+                }
+                // Front to back: the node's entries are stored in ascending order of their boxes' centres along one axis
+                // (ct_shadow_tree_build.h); a packet whose rays point DOWN that axis goes through them backwards.  The entry met
+                // first is entered, the others wait, nearest on top.
+                uint32_t next_ref = 0;
+                unsigned long long next_mask = 0ull;
+                float next_tmin = 0.0f;
+                const auto meet = [&](int k) {
+                    if (enter[k] != 0ull) {
+                        if (next_mask != 0ull) {
+                            const bool level = lane == sp;
+                            stack_ref = level ? (int)next_ref : stack_ref;
+                            stack_mask_lo = level ? (int)(uint32_t)next_mask : stack_mask_lo;
+                            stack_mask_hi = level ? (int)(uint32_t)(next_mask >> 32) : stack_mask_hi;
+                            if (sp < kClosestLdsLevels) waiting_tmin[sp * kWave + lane] = next_tmin;
+                            sp += 1;
+                        }
+                        next_ref = sq.ref(k);
+                        next_mask = enter[k];
+                        next_tmin = tmin[k];
+                    }
+                };
+                const uint32_t axis = (uint32_t)sq.b[13];
+                const bool backwards = OCT < 8 && axis < 3u && (((uint32_t)OCT >> axis) & 1u) != 0u;
+                if (!backwards) { meet(3); meet(2); meet(1); meet(0); }
+                else { meet(0); meet(1); meet(2); meet(3); }
+                cur = next_ref;
+                mask = next_mask;
+                if (mask != 0ull) continue;
+            }
+            while (mask == 0ull && sp > 0) {
+                sp -= 1;
+                const uint32_t pushed_lo = (uint32_t)__builtin_amdgcn_readlane(stack_mask_lo, (int)sp);
+                const uint32_t pushed_hi = (uint32_t)__builtin_amdgcn_readlane(stack_mask_hi, (int)sp);
+                mask = (unsigned long long)pushed_lo | ((unsigned long long)pushed_hi << 32);
+                cur = (uint32_t)__builtin_amdgcn_readlane(stack_ref, (int)sp);
+                // a lane whose ray.t has dropped below the entry's tmin since it was pushed need not go in (the levels kept in LDS)
+                if (sp < kClosestLdsLevels) mask &= __ballot(!(waiting_tmin[sp * kWave + lane] > limit));
+            }
+        }
+        };
+        switch (octant) {
+            case 0: shared_walk(std::integral_constant<int, 0>{}); break;
+            case 1: shared_walk(std::integral_constant<int, 1>{}); break;
+            case 2: shared_walk(std::integral_constant<int, 2>{}); break;
+            case 3: shared_walk(std::integral_constant<int, 3>{}); break;
+            case 4: shared_walk(std::integral_constant<int, 4>{}); break;
+            case 5: shared_walk(std::integral_constant<int, 5>{}); break;
+            case 6: shared_walk(std::integral_constant<int, 6>{}); break;
+            case 7: shared_walk(std::integral_constant<int, 7>{}); break;
+            default: shared_walk(std::integral_constant<int, 8>{}); break;
+        }
+        // ---------------- the winner's leaf: does the reference test it, whatever it has found before?  Its leaf's box
+        // with ray.t = the winner's own t (bvh.cpp:165-179): tmax >= tmin, tmax > 0, and tmin < t -- certain then for every
+        // ray.t the reference can carry when it comes to that leaf (all >= t, the least of its tests); the ancestors follow
+        // (nested boxes, ray.t only shrinks: appendix B2).  Not certain: the ray is left.
+        if (has_ray && !left && t != kNoHit) {
+            const ctgpu_node *leaf = P.ref_nodes + P.leaf_of_slot[hit_at / (uint32_t)sizeof(TriRecord)];
+            const double4 b0 = *reinterpret_cast<const double4 *>(&leaf->bmin[0]);
+            const double2 b1 = *reinterpret_cast<const double2 *>(&leaf->bmax[1]);
+            const double bmin[3] = {b0.x, b0.y, b0.z}, bmax[3] = {b0.w, b1.x, b1.y};
+            const d3 inv = make_d3(quick_reciprocal(d.x), quick_reciprocal(d.y), quick_reciprocal(d.z));
+            float tmin64, tmax64;
+            bool verdict;
+            slab_approx(eye, inv, bmin, bmax, tmin64, tmax64);
+            if (!box_verdict_positive_t(tmin64, tmax64, t, verdict)) {
+                (void)slab_in_sequence(eye, d, bmin, bmax, tmin64, tmax64);
+                verdict = tmax64 >= tmin64 && tmin64 < t && tmax64 > 0;
+            }
+            left = !verdict;
+        }
+        }   // (a packet with rays inside the gate)
+        // ---------------- retire
+        {
+            const uint32_t gone = (uint32_t)__popcll(__ballot(has_ray && left));
+            const uint32_t walked_and_gone = (uint32_t)__popcll(__ballot(has_ray && left) & rays);
+            n_left += gone;
+            n_traced -= walked_and_gone;
+        }
+        if (has_ray) W.hits[id] = left ? make_uint2(__float_as_uint(kNoHit), kPrimaryLeft) : make_uint2(__float_as_uint(t), best);
+    }
+    if (lane == 0) {
+        atomicAdd(&P.counters[0], (unsigned long long)n_traced);
+        if (n_left) { atomicAdd(W.shadow_left + 1, (unsigned long long)n_left); atomicAdd(&P.counters[kCounterPrimaryLeft], (unsigned long long)n_left); }
+        unsigned long long *work = W.walk_work + (size_t)(blockIdx.x & 63u) * 8u;
+        atomicAdd(work + 0, (unsigned long long)n_packets);
+        atomicAdd(work + 1, (unsigned long long)n_quads);
+        atomicAdd(work + 2, (unsigned long long)n_records);
+    }
+}
+
+// ------------------------------------------------------------------------------------
 // ct_shade: lighting of every sample of a pixel in order, running blend, pixel store.
 // raythread.cpp:353-366 (TraceRay without reflection), 275-327 (ComputeLighting with the
 // shadow decisions read from the mask), 482-498 (blend), color.h.
@@ -2473,12 +2765,14 @@ int pipeline_packet_occupancy(uint32_t depth, uint32_t lds_levels) {
 
 int pipeline_stree_occupancy() {
     int a = 0, b = 0;
-    int c = 0, e = 0;
+    int c = 0, e = 0, f = 0, g = 0;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&f, ct_walk_closest_tree<true>, kWave, (size_t)kClosestLdsLevels * kWave * sizeof(float));
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&g, ct_walk_closest_tree<false>, kWave, (size_t)kClosestLdsLevels * kWave * sizeof(float));
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, ct_walk_shadow_tree<true, false>, kWave, 512);
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, ct_walk_shadow_tree<false, false>, kWave, 512);
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, ct_walk_shadow_tree<true, true>, kWave, 512);
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&e, ct_walk_shadow_tree<false, true>, kWave, 512);
-    return std::min(std::min(a, b), std::min(c, e));
+    return std::min(std::min(std::min(a, b), std::min(c, e)), std::min(f, g));
 }
 
 // ct_order_build: the heavy lists of this frame's two packet walks from the costs the frame before left (blockIdx.y:
@@ -2599,6 +2893,18 @@ void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hip
         const size_t lds_l = (size_t)W.lds_depth * kWave * 12u;
         const dim3 grid_l(W.listed_blocks);
         const bool handover = W.packet_budget != 0u;
+        if (P.closest_tree && P.stree && !handover && !ordered) {
+            // the primary rays through the shadow tree's nodes (appendix F); what that walk leaves -- rays outside the gate, winners
+            // on the rim of their leaf's box: hits[].slot = kPrimaryLeft, counted in W.shadow_left[1] -- goes through the
+            // reference's tree in a launch whose waves return at once on zero
+            const dim3 grid_s(W.stree_blocks ? W.stree_blocks : W.walk_blocks);
+            const size_t lds_c = (size_t)kClosestLdsLevels * kWave * sizeof(float);
+            if (ss) hipLaunchKernelGGL((ct_walk_closest_tree<true>), grid_s, wave, lds_c, stream, P, W);
+            else hipLaunchKernelGGL((ct_walk_closest_tree<false>), grid_s, wave, lds_c, stream, P, W);
+            PipelineParams Wl = W;
+            Wl.primary_left = 1u;
+            launch_frame_walk<0>(ss, false, false, P.cull_first != kNoNode, grid, wave, lds_p, stream, P, Wl);
+        } else
         launch_frame_walk<0>(ss, handover, ordered, P.cull_first != kNoNode, grid, wave, lds_p, stream, P, W);
         if (handover && ss) hipLaunchKernelGGL((ct_walk<0, true, true>), grid_l, wave, lds_l, stream, P, W);
         if (handover && !ss) hipLaunchKernelGGL((ct_walk<0, false, true>), grid_l, wave, lds_l, stream, P, W);

@@ -62,6 +62,8 @@ __global__ void k_gather_records(const TriRecord *recs, const uint32_t *order, c
     const uint32_t from = order[s];
     TriRecord t = recs[from];
     t.remaining = remaining[s];
+    t.triangle = from;            // (here: the record's slot in the REFERENCE's order -- what hits[] names, and the reference's
+                                  //  visiting order, which decides between triangles hit at the same t: ct_walk_closest_tree)
     out[s] = t;
     leaf_of[s] = leaf_of_slot[from];
 }
@@ -404,6 +406,7 @@ int ctgpu_build_shadow_tree(int device, const void *d_tris, uint32_t n, const ct
     out->d_max = std::nextafterf((float)d_max, 0.0f);           // (towards zero: the gate's comparisons are the stricter side)
     out->o_max = std::nextafterf((float)o_max, 0.0f);
     out->gamma = gamma;
+    out->tau = std::nextafterf((float)(2.0 * 0x1p-12 * K * K * s_lim), INFINITY);
     out->usable = true;
     out->build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     if (std::getenv("CTGPU_DEBUG_SHADOW_TREE"))

@@ -24,7 +24,8 @@ struct Quad {
     float plane[4][3][2];         // [entry][axis]{min, max}
     uint32_t ref[4];              // kLeaf | first slot of a run of triangles (the tree's own slot order), or a node index
     uint32_t count;
-    uint32_t pad_[3];
+    uint32_t axis;                // the entries are listed in ascending order of their boxes' centres along this axis (0 x, 1 y, 2 z)
+    uint32_t pad_[2];
 };
 static_assert(sizeof(Quad) == 128, "QuadNode");
 constexpr uint32_t kLeaf = 0x80000000u;
@@ -297,15 +298,21 @@ inline float plane_up(float p, double gamma) { return -plane_down(-p, gamma); }
 // ------------------------------------------------------------------ four entries a node
 // The node that stands for an inner binary node: its two children, the one with the largest box opened in turn until four
 // entries are there or only leaves are left.  Per binary node that heads a four-wide node: its entries (binary node ids, in
-// the order the walk will meet them), how many, what its subtree needs of the walk's stack, how many four-wide nodes and
-// triangles it holds.  Entries are ordered leaves first, then subtrees by their need, least first: the deepest subtree is
-// entered with nothing of this node waiting, need(node) = max over k of (count - 1 - k + need(entry k)).
+// the order they are stored), how many, what its subtree needs of the walk's stack, how many four-wide nodes and triangles
+// it holds.  Entries are stored in ascending order of their boxes' centres along the axis on which those centres spread
+// most: a closest-hit walk meets them front to back by going through them forwards or backwards, as its rays point up or
+// down that axis (the any-hit walk does not care).  Either way may happen, so a node can leave count - 1 entries waiting
+// whichever entry the walk is in: need(node) = count - 1 + the largest need among its entries.
 struct FourWide {
     const std::vector<BinNode> &bin;
     std::vector<uint32_t> entry;      // [bin][4]
     std::vector<uint8_t> count;       // [bin] 0: not (yet) a four-wide node's head
+    std::vector<uint8_t> axis;        // [bin] the axis its entries are ordered along
     std::vector<uint32_t> need, size, tris; // [bin]
-    explicit FourWide(const std::vector<BinNode> &nodes) : bin(nodes), entry(nodes.size() * 4u), count(nodes.size(), 0), need(nodes.size(), 0),
+    bool by_need = false;             // the fallback order: leaves first, then subtrees by their need, least first, walked forwards
+                                      // only -- need(node) = max over k of (count - 1 - k + need(entry k)), the least any order gives;
+                                      // such a node says axis = 3 (the closest-hit walk, which wants front to back, stays off the tree)
+    explicit FourWide(const std::vector<BinNode> &nodes) : bin(nodes), entry(nodes.size() * 4u), count(nodes.size(), 0), axis(nodes.size(), 0), need(nodes.size(), 0),
                                                             size(nodes.size(), 0), tris(nodes.size(), 0) {}
 
     uint32_t open(uint32_t id, uint32_t ids[4]) const {
@@ -337,20 +344,31 @@ struct FourWide {
                 if (bin[child].left != kNone && !count[child]) push(child);     // (may move `stack`: f is not used after it)
                 continue;
             }
-            uint32_t key[4], perm[4] = {0, 1, 2, 3};
+            float centre[4][3], lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+            for (uint32_t k = 0; k < f.n; k++)
+                for (int a = 0; a < 3; a++) {
+                    centre[k][a] = 0.5f * (bin[f.ids[k]].box.lo[a] + bin[f.ids[k]].box.hi[a]);
+                    lo[a] = std::min(lo[a], centre[k][a]); hi[a] = std::max(hi[a], centre[k][a]);
+                }
+            int along = 0;
+            for (int a = 1; a < 3; a++) if (hi[a] - lo[a] > hi[along] - lo[along]) along = a;
+            uint32_t perm[4] = {0, 1, 2, 3}, key[4];
             for (uint32_t k = 0; k < f.n; k++) key[k] = bin[f.ids[k]].left == kNone ? 0u : 1u + need[f.ids[k]];
             for (uint32_t i = 1; i < f.n; i++)                                  // (insertion sort, stable)
-                for (uint32_t j = i; j > 0 && key[perm[j]] < key[perm[j - 1]]; j--) std::swap(perm[j], perm[j - 1]);
-            uint32_t worst = 0, nodes = 1, below = 0;
+                for (uint32_t j = i; j > 0 && (by_need ? key[perm[j]] < key[perm[j - 1]] : centre[perm[j]][along] < centre[perm[j - 1]][along]); j--)
+                    std::swap(perm[j], perm[j - 1]);
+            uint32_t deepest = 0, worst = 0, nodes = 1, below = 0;
             for (uint32_t k = 0; k < f.n; k++) {
                 const uint32_t id = f.ids[perm[k]];
                 entry[(size_t)f.id * 4 + k] = id;
                 const bool leaf = bin[id].left == kNone;
+                deepest = std::max(deepest, leaf ? 0u : need[id]);
                 worst = std::max(worst, f.n - 1u - k + (leaf ? 0u : need[id]));
                 nodes += leaf ? 0u : size[id];
                 below += leaf ? bin[id].count : tris[id];
             }
-            need[f.id] = worst; size[f.id] = nodes; tris[f.id] = below;
+            need[f.id] = by_need ? worst : f.n - 1u + deepest; size[f.id] = nodes; tris[f.id] = below;
+            axis[f.id] = by_need ? 3u : (uint8_t)along;
             count[f.id] = (uint8_t)f.n;
             stack.pop_back();
         }
@@ -395,7 +413,7 @@ inline uint32_t four_wide_from_binary(const std::vector<BinNode> &bin, uint32_t 
     }
     // ---- four entries a node: the subtrees a few levels down settle side by side, then the top
     threads = std::max(1u, threads);
-    FourWide four(bin);
+    FourWide four_by_place(bin);
     std::vector<uint32_t> frontier;
     std::vector<uint8_t> is_frontier(bin.size(), 0);
     if (threads > 1u && n >= kParallelAbove) {
@@ -405,7 +423,7 @@ inline uint32_t four_wide_from_binary(const std::vector<BinNode> &bin, uint32_t 
             walk.pop_back();
             if (depth == 5u) { frontier.push_back(id); is_frontier[id] = 1; continue; }
             uint32_t ids[4];
-            const uint32_t c = four.open(id, ids);
+            const uint32_t c = four_by_place.open(id, ids);
             for (uint32_t k = 0; k < c; k++) if (bin[ids[k]].left != kNone) walk.push_back({ids[k], depth + 1u});
         }
     }
@@ -417,8 +435,18 @@ inline uint32_t four_wide_from_binary(const std::vector<BinNode> &bin, uint32_t 
         run();
         for (auto &t : pool) t.join();
     };
-    if (!frontier.empty()) over_frontier([&](size_t i) { four.settle(frontier[i]); });
-    four.settle(root);
+    if (!frontier.empty()) over_frontier([&](size_t i) { four_by_place.settle(frontier[i]); });
+    four_by_place.settle(root);
+    // (the walk's stack is the 64 lanes of a register: a tree whose positional order could leave more waiting falls back to
+    //  the order that needs least -- and tells the closest-hit walk, by axis = 3, to stay off it)
+    FourWide four_by_need(bin);
+    four_by_need.by_need = true;
+    const bool fallback = four_by_place.need[root] > 63u;
+    if (fallback) {
+        if (!frontier.empty()) over_frontier([&](size_t i) { four_by_need.settle(frontier[i]); });
+        four_by_need.settle(root);
+    }
+    FourWide &four = fallback ? four_by_need : four_by_place;
     const uint32_t need = four.need[root];
     const auto clock2 = std::chrono::steady_clock::now();
     // ---- numbered in the walk's own order (depth first, entries as stored: a subtree's nodes and triangles lie together)
@@ -452,6 +480,7 @@ inline uint32_t four_wide_from_binary(const std::vector<BinNode> &bin, uint32_t 
                 }
             }
             node.count = c;
+            node.axis = four.axis[at.head];
         }
     };
     write(Job{root, 0u, 0u}, !frontier.empty());

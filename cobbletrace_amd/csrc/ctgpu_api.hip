@@ -25,7 +25,7 @@ using namespace ctd;
 
 // sizes the bindings (cobbletrace_amd/bindings.py) rely on
 static_assert(sizeof(ctgpu_node) == 64 && sizeof(ctgpu_light) == 56 && sizeof(ctgpu_material) == 12, "scene records");
-static_assert(sizeof(ctgpu_scene_desc) == 88 && sizeof(ctgpu_sphere) == 48 && sizeof(ctgpu_frame_desc) == 136 && sizeof(ctgpu_stats) == 104, "descriptors");
+static_assert(sizeof(ctgpu_scene_desc) == 88 && sizeof(ctgpu_sphere) == 48 && sizeof(ctgpu_frame_desc) == 136 && sizeof(ctgpu_stats) == 112, "descriptors");
 static_assert(sizeof(ctgpu_ray) == 56 && sizeof(ctgpu_hit) == 16 && sizeof(ctgpu_partition) == 12, "test-hook records");
 
 // ------------------------------------------------------------------ error plumbing
@@ -96,6 +96,7 @@ struct SceneStore {
     DeviceArray<TriRecord> stree_tris;          // the TriRecords once more, in that tree's own leaf order
     DeviceArray<uint32_t> leaf_of_slot;         // slot of stree_tris -> reference leaf node (the verdict of the leaf's box)
     ShadowTreeLimits stree_lim = {0, 0, 0};
+    float stree_tau = 0.0f;
     uint32_t stree_pending = 0;
     double stree_gamma = 0.0, stree_ms = 0.0;
     bool stree_usable = false;
@@ -235,7 +236,12 @@ struct ctgpu_ctx {
         int kind = -1;                          // 0 / 1: a single-sample / supersampled frame on the fast path (walk choice)
         int reflective_kind = -1;               // 0 / 1: a reflective single-sample / supersampled frame (bounce choice)
     } pending;
-    struct Path { uint32_t walk_kind = 0, bounce_kind = 0, ordered = 0, cull_tree = 0, shadow_tree = 0; } path;     // what the latest frame ran on (ctgpu_stats)
+    // The closest-hit walk of the shadow tree's nodes leaves a ray whose winner sits on the rim of its leaf's box to the walk of the
+    // reference's tree; in scenes of axis-aligned flat geometry (a floor, the faces of the rounded cubes) that is every hit on such
+    // a face, and the frame pays both walks.  A context that sees more than a sixteenth of a frame's primary rays left keeps the
+    // reference's tree for its primary rays from then on (same pixels either way; a new scene starts over).
+    bool closest_off = false;
+    struct Path { uint32_t walk_kind = 0, bounce_kind = 0, ordered = 0, cull_tree = 0, shadow_tree = 0, closest_tree = 0; } path;     // what the latest frame ran on (ctgpu_stats)
     int big_leaf_min = 8;                       // CTGPU_BIG_LEAF: leaves of at least this many triangles go through the triangle boxes (0: off)
     int big_leaf_share = 20;                    // CTGPU_BIG_LEAF_SHARE: ... and only in scenes where at least this percentage of all triangles sits in such leaves
     int probe_above = 100;                      // CTGPU_PROBE_ABOVE: fetches per packet beyond which the per-lane walk gets a trial frame
@@ -325,6 +331,7 @@ extern "C" int ctgpu_default_config(ctgpu_config *c) {
     c->order_floor = 64; c->order_split_below = 8;
     c->big_leaf_min = 8; c->big_leaf_share = 20;
     c->shadow_tree = 1; c->shadow_tree_build = 0; c->shadow_tree_leaf = 2; c->shadow_tree_leaf_fill = 50;
+    c->closest_tree = 1;
     c->shadow_split_gap = -1.0f;
     const int thresh[3] = {40, 20, 12}, walk_thresh[3] = {64, 32, 24};       // (measured best on MI355X)
     for (int k = 0; k < 3; k++) { c->thresh[k] = thresh[k]; c->walk_thresh[k] = walk_thresh[k]; }
@@ -358,6 +365,7 @@ extern "C" int ctgpu_config_from_environment(ctgpu_config *c) {
     number("CTGPU_BIG_LEAF_SHARE", c->big_leaf_share, 0, 100);
     number("CTGPU_SHADOW_TREE", c->shadow_tree, 0, 2);
     number("CTGPU_SHADOW_TREE_BUILD", c->shadow_tree_build, 0, 2);
+    number("CTGPU_CLOSEST_TREE", c->closest_tree, 0, 2);
     number("CTGPU_SHADOW_TREE_LEAF", c->shadow_tree_leaf, 1, 4);
     number("CTGPU_SHADOW_TREE_LEAF_FILL", c->shadow_tree_leaf_fill, 0, 100);
     number("CTGPU_PACKET_BUDGET", c->packet_budget, 0, big);
@@ -397,7 +405,7 @@ extern "C" int ctgpu_create_with_config(int device, const ctgpu_config *config, 
     if (c.lds_depth < 1 || c.packet_lds_levels < 1 || c.packet_lanes < 1 || c.packet_lanes > 64 || c.blocks_per_cu < 0 || c.chunk < 0 ||
         c.chunk_shadow < 0 || c.order < 0 || c.order > 3 || c.big_leaf_min < 0 || c.big_leaf_share < 0 || c.big_leaf_share > 100 ||
         c.shadow_tree < 0 || c.shadow_tree > 2 || c.shadow_tree_build < 0 || c.shadow_tree_build > 2 ||
-        c.shadow_tree_leaf < 1 || c.shadow_tree_leaf > 4 || c.shadow_tree_leaf_fill < 0 || c.shadow_tree_leaf_fill > 100 ||
+        c.closest_tree < 0 || c.closest_tree > 2 || c.shadow_tree_leaf < 1 || c.shadow_tree_leaf > 4 || c.shadow_tree_leaf_fill < 0 || c.shadow_tree_leaf_fill > 100 ||
         c.packet_budget < 0 || c.order_floor < 0 || c.order_split_below < 0 || c.probe_above < 0 ||
         !(c.order_heavy[0] >= c.order_heavy[1] && c.order_heavy[1] >= c.order_heavy[2] && c.order_heavy[2] >= c.order_heavy[3] && c.order_heavy[3] > 0.0f) ||
         !part_ok(c.order_parts[0]) || !part_ok(c.order_parts[1]) || !part_ok(c.order_parts[2]) || !part_ok(c.order_parts[3]))
@@ -808,7 +816,7 @@ extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
             S.stree_tris.adopt((TriRecord *)st.records, N);
             S.leaf_of_slot.adopt(st.leaf_of_slot, N);
             S.stree_lim.d_min = st.d_min; S.stree_lim.d_max = st.d_max; S.stree_lim.o_max = st.o_max;
-            S.stree_pending = st.pending; S.stree_gamma = st.gamma; S.stree_ms = st.build_ms;
+            S.stree_pending = st.pending; S.stree_gamma = st.gamma; S.stree_ms = st.build_ms; S.stree_tau = st.tau;
             S.stree_usable = true;
         }
     }
@@ -876,6 +884,7 @@ extern "C" int ctgpu_upload_scene(ctgpu_ctx *ctx, const ctgpu_scene_desc *s) {
     S.tree_depth = depth;
     S.has_reflection = reflective;
     ctx->scene = store;
+    ctx->closest_off = false;
     ctx->choice[0] = ctx->choice[1] = ctgpu_ctx::WalkChoice();       // another scene: the measured choices start over
     ctx->bounce_choice[0] = ctx->bounce_choice[1] = ctgpu_ctx::BounceChoice();
     return CTGPU_OK;
@@ -891,6 +900,7 @@ extern "C" int ctgpu_share_scene(ctgpu_ctx *ctx, ctgpu_ctx *owner) {
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     ctx->scene = owner->scene;
+    ctx->closest_off = false;
     ctx->choice[0] = ctx->choice[1] = ctgpu_ctx::WalkChoice();
     ctx->bounce_choice[0] = ctx->bounce_choice[1] = ctgpu_ctx::BounceChoice();
     return CTGPU_OK;
@@ -1073,6 +1083,14 @@ int fill_params(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, const ctgpu_partition
     if (ctx->scene->stree_usable && (ctx->cfg.shadow_tree == 2 || (ctx->cfg.shadow_tree == 1 && (f->flags & CTGPU_F_SUPERSAMPLE) != 0))) {
         P.stree = ctx->scene->stree.ptr; P.stree_tris = ctx->scene->stree_tris.ptr; P.leaf_of_slot = ctx->scene->leaf_of_slot.ptr;
         P.stree_lim = ctx->scene->stree_lim;
+        // ... and the primary rays (CTGPU_CLOSEST_TREE; appendix F): the eye must lie where the boxes' growth covers the
+        // binary32 arithmetic, |eye_i| <= o_max like a shadow ray's origin (a far-away camera keeps the reference's tree)
+        const bool eye_inside = std::fabs(f->cam_pos[0]) <= ctx->scene->stree_lim.o_max && std::fabs(f->cam_pos[1]) <= ctx->scene->stree_lim.o_max &&
+                                std::fabs(f->cam_pos[2]) <= ctx->scene->stree_lim.o_max;
+        if (eye_inside && !ctx->closest_off && (ctx->cfg.closest_tree == 2 || (ctx->cfg.closest_tree == 1 && (f->flags & CTGPU_F_SUPERSAMPLE) != 0))) {
+            P.closest_tree = 1u;
+            P.closest_tau = ctx->scene->stree_tau;
+        }
     }
     std::memcpy(P.root_min, ctx->scene->root_min, 24);
     std::memcpy(P.root_max, ctx->scene->root_max, 24);
@@ -1179,6 +1197,9 @@ int read_counters(ctgpu_ctx *ctx, ctgpu_stats *st) {
         st->node_visits = c[3]; st->triangle_tests = c[4];
         st->rays_shadow_elided = c[kCounterElided];
         st->rays_shadow_left = c[kCounterLeft];
+        st->rays_primary_left = c[kCounterPrimaryLeft];
+        st->closest_tree = ctx->path.closest_tree;
+        if (ctx->path.closest_tree && c[kCounterPrimaryLeft] * 16ull > c[0]) ctx->closest_off = true;
         st->walk_kind = ctx->path.walk_kind; st->bounce_kind = ctx->path.bounce_kind; st->ordered = ctx->path.ordered;
         st->cull_tree = ctx->path.cull_tree; st->shadow_tree = ctx->path.shadow_tree;
     }
@@ -1359,6 +1380,7 @@ int launch_frame(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, FrameParams &P, hipS
     ctx->path.cull_tree = (W.packet && P.cull_first != kNoNode) ? 1u : 0u;
     // (the same condition launch_pipeline takes the shadow tree under)
     ctx->path.shadow_tree = (W.packet && W.n_shadow_lights != 0u && P.stree && W.packet_budget == 0u) ? 1u : 0u;
+    ctx->path.closest_tree = (W.packet && P.closest_tree && P.stree && W.packet_budget == 0u && !W.ordered) ? 1u : 0u;
     return CTGPU_OK;
 }
 

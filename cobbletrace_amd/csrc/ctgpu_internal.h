@@ -87,6 +87,7 @@ struct ctgpu_shadow_tree {
     uint32_t pending = 0;                  // most entries ever waiting on the walk's stack (<= 63)
     float d_min = 0, d_max = 0, o_max = 0; // the gate (ShadowTreeLimits)
     double gamma = 0;                      // what every stored plane was moved outward by
+    float tau = 0;                         // closest-hit walks prune entries beyond ray.t only while ray.t >= tau
     double build_ms = 0;                   // wall time of the build, copies included
     bool usable = false;
 };

@@ -159,9 +159,11 @@ typedef struct ctgpu_stats {
     uint32_t ordered;                /* 1: heavy chunks were handed out first (ctgpu_order_info)                        */
     uint32_t cull_tree;              /* 1: the tree the frame walked carries cull nodes in place of big leaves          */
     uint32_t shadow_tree;            /* 1: the shadow rays walked the shadow tree (ctgpu_config.shadow_tree)            */
-    uint32_t pad_;
+    uint32_t closest_tree;           /* 1: the primary rays walked it too (ctgpu_config.closest_tree)                   */
     uint64_t rays_shadow_left;       /* ... and this many of them it left to the walk of the reference's tree (rays outside
                                         its gate; counted in rays_shadow like the others)                               */
+    uint64_t rays_primary_left;      /* the same for the primary rays: outside the gate, or a closest hit on the rim of its
+                                        leaf's box (counted in rays_primary like the others)                             */
 } ctgpu_stats;
 #define CTGPU_WALK_GENERAL   0       /* the general path's one kernel (reflective frames it was chosen for, CTGPU_FORCE_MEGAKERNEL) */
 #define CTGPU_WALK_PER_LANE  1       /* wavefront pipeline, every lane its own walk (ct_walk)                          */
@@ -224,6 +226,9 @@ typedef struct ctgpu_config {
     int32_t big_leaf_share;       /* CTGPU_BIG_LEAF_SHARE ... in scenes where at least this percentage of the triangles sits in such leaves */
     int32_t shadow_tree;          /* CTGPU_SHADOW_TREE    the frame's shadow rays walk a tree of this library's own over the same triangles (order-free
                                      any-hit query, raythread.cpp:303-307; DESIGN appendix E): 0 never, 1 supersampled frames (default), 2 every frame */
+    int32_t closest_tree;         /* CTGPU_CLOSEST_TREE   the frame's PRIMARY rays walk that tree too (the least t over every test the reference
+                                     could make, the winner checked against the reference's own leaf box; DESIGN appendix F): 0 never, 1
+                                     supersampled frames (default), 2 every frame.  Needs shadow_tree != 0 (it is the same tree) */
     int32_t shadow_tree_build;    /* CTGPU_SHADOW_TREE_BUILD  how that tree is made: 0 clustered on the device (default; nearest neighbours along a
                                      space-filling curve merge round by round), 1 binned surface-area heuristic on host threads, 2 object medians (host) */
     int32_t shadow_tree_leaf;     /* CTGPU_SHADOW_TREE_LEAF   most triangles one of its leaves holds (1..4, default 2) ... */

@@ -134,6 +134,11 @@ int main(int argc, char **argv) {
         const Quad &q = quads[it.node];
         if (q.count < 1 || q.count > 4) { std::printf("FAIL count\n"); return 1; }
         worst = std::max(worst, it.waiting + q.count - 1u);
+        if (q.axis > 3u) { std::printf("FAIL axis\n"); return 1; }
+        for (uint32_t k = 1; k < q.count && q.axis < 3u; k++) {          // stored in ascending order of the boxes' centres along the node's axis
+            const float c0 = 0.5f * (q.plane[k - 1][q.axis][0] + q.plane[k - 1][q.axis][1]), c1 = 0.5f * (q.plane[k][q.axis][0] + q.plane[k][q.axis][1]);
+            if (c1 < c0 - 1e-3f * (std::fabs(c0) + std::fabs(c1) + 1e-6f)) { std::printf("FAIL entries not in order along the axis\n"); return 1; }
+        }
         for (uint32_t k = 0; k < q.count; k++) {
             if (q.ref[k] & kLeaf) {
                 const uint32_t first = q.ref[k] & 0x3fffffffu;
@@ -148,7 +153,7 @@ int main(int argc, char **argv) {
                         }
                 }
             } else {
-                stack.push_back({q.ref[k], it.waiting + q.count - 1u - k});
+                stack.push_back({q.ref[k], it.waiting + q.count - 1u - (q.axis == 3u ? k : 0u)});        // (axis < 3: the walk may go through the entries either way)
             }
         }
         for (uint32_t k = q.count; k < 4; k++) {
@@ -196,7 +201,9 @@ int main(int argc, char **argv) {
             } else {
                 const Quad &q = quads[cur];
                 uint32_t next_ref = 0; bool have = false;
-                for (int k = 3; k >= 0; k--) {
+                const bool backwards = q.axis < 3u && d[q.axis] < 0.0f;          // front to back: up or down the node's axis
+                for (int j = 3; j >= 0; j--) {
+                    const int k = backwards ? 3 - j : j;
                     if (enters(q.plane[k], inv, noi)) {
                         if (have) { if (sp >= 64 || sp + 1 > need) { std::printf("FAIL stack %u beyond need %u\n", sp + 1, need); return 1; } stack_ref[sp++] = next_ref; }
                         next_ref = q.ref[k]; have = true;

@@ -34,7 +34,7 @@ def test_abi_version_and_structs():
     # struct sizes the header promises
     assert C.sizeof(ca.Node) == 64 and C.sizeof(ca.Light) == 56 and C.sizeof(ca.Material) == 12
     assert C.sizeof(ca.Ray) == 56 and C.sizeof(ca.Hit) == 16
-    assert C.sizeof(ca.FrameDesc) == 136 and C.sizeof(ca.SceneDesc) == 88 and C.sizeof(ca.Stats) == 104
+    assert C.sizeof(ca.FrameDesc) == 136 and C.sizeof(ca.SceneDesc) == 88 and C.sizeof(ca.Stats) == 112
 
 
 def test_no_gpu_means_errors_not_fallbacks():

@@ -14,7 +14,7 @@ import cobbletrace_amd as ca
 
 pytestmark = pytest.mark.gpu
 
-QUAD = np.dtype([("plane", "<f4", (4, 3, 2)), ("ref", "<u4", (4,)), ("count", "<u4"), ("pad", "<u4", (3,))])
+QUAD = np.dtype([("plane", "<f4", (4, 3, 2)), ("ref", "<u4", (4,)), ("count", "<u4"), ("axis", "<u4"), ("pad", "<u4", (2,))])
 TRI = np.dtype([("p1", "<f8", (3,)), ("e1", "<f8", (3,)), ("e2", "<f8", (3,)), ("triangle", "<u4"), ("remaining", "<u4")])
 NODE = np.dtype([("bmin", "<f8", (3,)), ("bmax", "<f8", (3,)), ("left", "<u4"), ("first", "<u4"), ("count", "<u4"), ("pad", "<u4")])
 LEAF, ONE, SLOT = 0x80000000, 0x40000000, 0x3FFFFFFF
@@ -25,10 +25,13 @@ def _oracle():
     return oracle
 
 
-def _context(shadow_tree, desc, build=0, leaf=2, fill=50):
+def _context(shadow_tree, desc, build=0, leaf=2, fill=50, closest=0, order=None):
     """a context that owns the knobs this file is about (the suite may run with CTGPU_SHADOW_TREE* in the environment)"""
     cfg = ca.config_from_environment()
     cfg.shadow_tree, cfg.shadow_tree_build, cfg.shadow_tree_leaf, cfg.shadow_tree_leaf_fill = shadow_tree, build, leaf, fill
+    cfg.closest_tree = closest
+    if order is not None:
+        cfg.order = order
     cfg.packet_walk = 1
     ctx = ca.GpuContext(0, cfg)
     ctx.upload(desc)
@@ -40,8 +43,10 @@ def _context(shadow_tree, desc, build=0, leaf=2, fill=50):
 def test_the_tree_in_hbm(name, build, leaf, fill, scenes):
     """Every triangle under exactly one entry, every entry's box around what lies below it, a leaf's entry around its
     triangles grown by appendix D's 1/256 and by gamma; the tree's own records are the reference's, permuted, leaf by leaf;
-    entries a node does not have are the corner point with a reference that is safe to follow; the stack bound the
-    library reports is the tree's; leaf_of_slot names the reference's leaves."""
+    entries a node does not have are the corner point with a reference that is safe to follow; a node's entries stand in
+    ascending order of their centres along the axis the node names (the closest-hit walk goes through them forwards or
+    backwards, as its rays point), so any entry may have the node's count - 1 others waiting: the stack bound the library
+    reports is the tree's under that rule; leaf_of_slot names the reference's leaves."""
     scene = scenes(name)
     ctx = _context(2, scene.desc, build, leaf, fill)
     try:
@@ -60,10 +65,13 @@ def test_the_tree_in_hbm(name, build, leaf, fill, scenes):
         n = info.n_triangles
         assert len(quads) == info.shadow_tree_nodes and len(leaf_of) == n and len(tris) == n
         # the same records, permuted (the triangle's index names it), each leaf a run that counts down
-        back = np.argsort(reference_order["triangle"])
-        same = reference_order[back][tris["triangle"]]
-        for f in ("p1", "e1", "e2", "triangle"):
+        # (the tree's own records carry, where the reference's carry the scene triangle, their slot in the REFERENCE's order:
+        #  what hits[] names and what decides between equal t -- ct_walk_closest_tree)
+        assert sorted(tris["triangle"].tolist()) == list(range(n))
+        same = reference_order[tris["triangle"]]
+        for f in ("p1", "e1", "e2"):
             assert (same[f] == tris[f]).all()
+        scene_triangle = same["triangle"]
         rem = tris["remaining"]
         assert rem.min() >= 1 and rem.max() <= leaf and (rem[:-1][rem[:-1] > 1] - 1 == rem[1:][rem[:-1] > 1]).all() and rem[-1] == 1
         starts = np.concatenate([[True], rem[:-1] == 1])
@@ -85,6 +93,10 @@ def test_the_tree_in_hbm(name, build, leaf, fill, scenes):
             count = int(q["count"])
             assert 1 <= count <= 4
             worst = max(worst, waiting + count - 1)
+            axis = int(q["axis"])
+            assert axis < 3 and (q["pad"] == 0).all()
+            centres = q["plane"][:count, axis, :].astype(np.float64).sum(1) * 0.5
+            assert (np.diff(centres) >= -4.0 * info.shadow_tree_gamma - 1e-6 * np.abs(centres).max()).all(), (at, centres)
             for k in range(count):
                 ref = int(q["ref"][k])
                 if ref & LEAF:
@@ -96,7 +108,7 @@ def test_the_tree_in_hbm(name, build, leaf, fill, scenes):
                         assert (q["plane"][k][:, 0] <= lo[t] - pad[t]).all() and (q["plane"][k][:, 1] >= hi[t] + pad[t]).all()
                 else:
                     assert at < ref < len(quads)
-                    stack.append((ref, waiting + count - 1 - k))
+                    stack.append((ref, waiting + count - 1))
             for k in range(count, 4):
                 assert (q["plane"][k][:, 0] == q["plane"][k][:, 1]).all()
                 assert (int(q["ref"][k]) & LEAF) and (int(q["ref"][k]) & SLOT) < n and starts[int(q["ref"][k]) & SLOT]
@@ -121,7 +133,7 @@ def test_the_tree_in_hbm(name, build, leaf, fill, scenes):
         leaf_of_triangle = np.full(n, 0xFFFFFFFF, np.uint32)
         for i in np.nonzero(nodes["count"])[0]:
             leaf_of_triangle[indexes[nodes["first"][i]:nodes["first"][i] + nodes["count"][i]]] = i
-        assert (leaf_of == leaf_of_triangle[tris["triangle"]]).all()
+        assert (leaf_of == leaf_of_triangle[scene_triangle]).all()
     finally:
         ctx.close()
 
@@ -192,6 +204,85 @@ def test_frames_and_counts_equal_the_reference_trees_walk(name, size, scenes):
         ref.close()
         for ctx in trees:
             ctx.close()
+
+
+@pytest.mark.parametrize("name,size", [("bunny", (640, 360)), ("dragon", (480, 270)), ("import", (640, 360))])
+def test_primary_rays_through_the_tree(name, size, scenes):
+    """CTGPU_CLOSEST_TREE: the primary rays walk the shadow tree's nodes too (appendix F) -- the least t over everything the
+    reference could test, among equal ones the triangle it meets first, the winner checked against the reference's own box of
+    its leaf, everything else left to the reference-tree walk.  Frames, ray counts and what ctgpu_stats says, against the walk
+    of the reference's tree; a band against the oracle.  (Frames that hand their heavy chunks out first keep the
+    reference's tree for their primary rays: the contexts here switch that order off so that small frames take the walk.)
+    The import scene's hits lie on axis-aligned flat faces, whose leaf boxes are flat: every such winner sits on the rim, a
+    third of the primary rays are left, and the context goes back to the reference's tree after the first frame."""
+    scene = scenes(name)
+    ref = _context(0, scene.desc, order=0)
+    tree = _context(2, scene.desc, closest=2, order=0)
+    try:
+        for ss in (True, False):
+            frame = scene.frame(size[0], size[1], supersampling=ss, rng_seed=11)
+            want, wst = ref.render(frame)
+            assert wst.closest_tree == 0 and wst.rays_primary_left == 0
+            for k in range(2):
+                got, st = tree.render(frame)
+                assert (got == want).all(), "%s ss=%d frame %d: %d pixels differ" % (name, ss, k, int((got != want).sum()))
+                assert (st.rays_primary, st.rays_shadow, st.rays_shadow_elided) == (wst.rays_primary, wst.rays_shadow, wst.rays_shadow_elided)
+                if name == "import":
+                    # the first frame of the context took the walk and left many rays; from then on the reference's tree
+                    assert (st.closest_tree, st.rays_primary_left > 0) == ((1, True) if (ss and k == 0) else (0, False))
+                else:
+                    assert st.closest_tree == 1 and st.shadow_tree == 1 and st.rays_primary_left * 16 <= st.rays_primary       # (more than a sixteenth left would send the context back to the reference's tree)
+        frame = scene.frame(size[0], size[1], supersampling=True, rng_seed=11)
+        fresh = _context(2, scene.desc, closest=2, order=0)
+        try:
+            got, st = fresh.render(frame)
+            assert st.closest_tree == 1
+        finally:
+            fresh.close()
+        bands = frame.num_threads
+        want, _ = _oracle().render(scene.desc, frame, os_threads=4, band_first=bands // 2, band_count=1)
+        rows = np.nonzero((want != 0).any(axis=1))[0]
+        assert len(rows) and (got[rows] == want[rows]).all()
+    finally:
+        ref.close(); tree.close()
+
+
+def test_equal_t_goes_to_the_triangle_the_reference_meets_first(tmp_path):
+    """bvh.cpp:212 records a triangle only when it lowers ray.t STRICTLY: of several triangles hit at the same t the one the
+    reference's walk meets first wins, and with it its colour.  Stacks of coincident triangles in different colours, in a
+    scene with enough other geometry that the tree's order and the reference's differ: the tree's walk keeps the least
+    {t, place in the reference's order}."""
+    rng = np.random.default_rng(5)
+    tris = _bumpy_sheet(rng, n=10)
+    colours = [[250, 40, 40], [40, 250, 40], [40, 40, 250], [240, 240, 40], [40, 240, 240]]
+    coloured = []
+    for k in range(40):
+        c = np.array([rng.uniform(-1.6, 1.6), rng.uniform(-0.5, 0.8), rng.uniform(1.5, 4.0)])
+        a, b = rng.standard_normal(3) * 0.5, rng.standard_normal(3) * 0.5
+        p = [c.tolist(), (c + a).tolist(), (c + b).tolist()]
+        for j in rng.permutation(len(colours))[:int(rng.integers(2, 5))]:
+            coloured.append((p, colours[j]))
+    import json
+    objs = [{"type": "triangle", "p1": t[0], "p2": t[1], "p3": t[2], "color": [200, 160, 90], "specular": 40, "reflection": 0} for t in tris]
+    objs += [{"type": "triangle", "p1": p[0], "p2": p[1], "p3": p[2], "color": col, "specular": -1, "reflection": 0} for p, col in coloured]
+    order = rng.permutation(len(objs))
+    scene_json = {"objects": [objs[i] for i in order], "camera": {"position": [0, 0.8, -2.5]},
+                  "lights": [{"type": "ambient", "intensity": 0.6}, {"type": "directional", "intensity": 0.4, "direction": [-1, 2, -1.5]}],
+                  "settings": {"numberOfThreads": 4, "subsampling": False, "wireframe": False, "supersampling": True}}
+    path = tmp_path / "stacks.json"
+    path.write_text(json.dumps(scene_json))
+    scene = ca.HostScene(str(path))
+    tree = _context(2, scene.desc, closest=2, order=0)
+    try:
+        for ss in (True, False):
+            frame = scene.frame(320, 240, threads=4, supersampling=ss, rng_seed=2)
+            got, st = tree.render(frame)
+            want, _ = _oracle().render(scene.desc, frame, os_threads=4)
+            assert st.closest_tree == 1
+            assert (got == want).all(), "%d pixels differ" % int((got != want).sum())
+            assert len(np.unique(want)) > 6                    # several of the stacks' colours are in the picture
+    finally:
+        tree.close()
 
 
 def test_heavy_chunks_first_through_the_shadow_tree(scenes):
@@ -294,12 +385,17 @@ def test_a_triangle_hit_outside_its_leafs_box_does_not_count(tmp_path):
                 nodes[i].bmin[a] = lo + 0.25 * (hi - lo); nodes[i].bmax[a] = hi - 0.25 * (hi - lo)
     copy = ca.SceneDesc(d.n_triangles, d.n_nodes, d.n_lights, 0, d.vertices, d.materials, nodes, d.indexes, d.lights)
     tree, ref = _context(2, copy), _context(0, copy)
+    both = _context(2, copy, closest=2, order=0)
     try:
         assert tree.scene_info().shadow_tree_nodes > 0
         for ss in (True, False):
             frame = scene.frame(320, 240, threads=4, supersampling=ss, rng_seed=4)
             got, st = tree.render(frame)
             want, cst = _oracle().render(copy, frame, os_threads=4)
+            if ss:      # the primary rays through the tree as well: their winners, too, count only inside the (shrunk) leaf boxes
+                again, bst = both.render(frame)
+                assert bst.closest_tree == 1 and bst.rays_primary_left > 0
+                assert (again == want).all(), "%d pixels differ with the primary rays through the tree" % int((again != want).sum())
             plain, _ = _oracle().render(d, frame, os_threads=4)
             assert (plain != want).any()                      # the shrunk boxes changed what the reference renders
             assert (got == want).all(), "%d pixels differ" % int((got != want).sum())
@@ -308,4 +404,4 @@ def test_a_triangle_hit_outside_its_leafs_box_does_not_count(tmp_path):
             assert st.rays_shadow_left > 0                        # rays whose hit lay outside the shrunk box of its leaf went on to the second launch
             assert (st.rays_primary, st.rays_shadow, st.rays_shadow_elided) == (ost.rays_primary, ost.rays_shadow, ost.rays_shadow_elided)
     finally:
-        tree.close(); ref.close()
+        tree.close(); ref.close(); both.close()

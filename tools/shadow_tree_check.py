@@ -17,12 +17,14 @@ args = sys.argv[1:]
 size = (1920, 1080)
 builds = [(0, 2, 50)]
 single = False
+closest = [1]
 names = []
 i = 0
 while i < len(args):
     if args[i] == "--size": size = tuple(int(v) for v in args[i + 1].split("x")); i += 2
     elif args[i] == "--builds": builds = [tuple(int(x) for x in v.split(":")) for v in args[i + 1].split(",")]; i += 2
     elif args[i] == "--single": single = True; i += 1
+    elif args[i] == "--closest": closest = [int(v) for v in args[i + 1].split(",")]; i += 2
     else: names.append(args[i]); i += 1
 names = names or ["dragon"]
 bad = 0
@@ -40,18 +42,19 @@ def measure(ctx, frame, n=10):
 for name in names:
     scene = ca.HostScene(os.path.join(A, FILES[name]))
     contexts = []
-    cfg = ca.default_config(); cfg.shadow_tree = 0
+    cfg = ca.default_config(); cfg.shadow_tree = 0; cfg.closest_tree = 0
     ref = ca.GpuContext(0, cfg); ref.upload(scene.desc, build_on_device=True)
     contexts.append(("reference's tree", ref))
-    for b in builds:
+    for b, c in [(b, c) for b in builds for c in closest]:
         cfg = ca.default_config(); cfg.shadow_tree = 2; cfg.shadow_tree_build, cfg.shadow_tree_leaf, cfg.shadow_tree_leaf_fill = b
+        cfg.closest_tree = 2 if c else 0
         ctx = ca.GpuContext(0, cfg)
         t0 = time.time(); ctx.upload(scene.desc, build_on_device=True); t1 = time.time()
         info = ctx.scene_info()
         print("%s: shadow tree build %s: %d nodes for %d triangles, stack %d, gamma %.3g, built in %.1f ms (upload %.1f ms), scene %.1f MB" %
               (name, b, info.shadow_tree_nodes, info.n_triangles, info.shadow_tree_pending, info.shadow_tree_gamma, info.shadow_tree_ms,
                (t1 - t0) * 1e3, info.hbm_bytes / 1e6), flush=True)
-        contexts.append(("shadow tree %d:%d:%d" % b, ctx))
+        contexts.append(("tree %d:%d:%d%s" % (b + (" +primary" if c else "",)), ctx))
     for ss in ((True,) if not single else (True, False)):
         frame = scene.frame(size[0], size[1], supersampling=ss)
         base = None
@@ -60,6 +63,7 @@ for name in names:
             line = "%s %dx%d ss=%d  %-24s frame %.3f  primary %.3f  gate %.3f  shadow %.3f  shade %.3f ms | shadow walk per launch: %d packets, %d nodes, %d records, %d blocked; rays %d + %d" % (
                 name, size[0], size[1], ss, label, sum(ms), ms[1], ms[2], ms[3], ms[4], ww.packets[1] // n, ww.quad_nodes[1] // n,
                 ww.triangle_records[1] // n, ww.shadow_rays_blocked // n, st.rays_primary, st.rays_shadow)
+            line += " | primary walk: %d nodes, %d records, %d left" % (ww.quad_nodes[0] // n, ww.triangle_records[0] // n, st.rays_primary_left)
             if base is None: base = (fb, st)
             else:
                 diff = int((fb != base[0]).sum())

@@ -13,7 +13,7 @@ import bench                                        # kernel names and the sourc
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 out = "gpurun_out"
-MATCH = (("ct_sample_grid", "ct_sample_grid"), ("ct_walk_packet<0", "ct_walk_packet<primary>"), ("ct_walk_shadow_tree", "ct_walk_shadow_tree"),
+MATCH = (("ct_sample_grid", "ct_sample_grid"), ("ct_walk_closest_tree", "ct_walk_closest_tree"), ("ct_walk_packet<0", "ct_walk_packet<primary>"), ("ct_walk_shadow_tree", "ct_walk_shadow_tree"),
          ("ct_light_gate", "ct_light_gate"), ("ct_walk_packet<1", "ct_walk_packet<shadow>"), ("ct_shade", "ct_shade"),
          ("ct_assemble", "ct_assemble"))
 CLOCK_HZ, SIMDS = 2.4e9, 1024                      # MI355X: 256 CUs x 4 SIMDs
@@ -72,7 +72,7 @@ issue = {"kernel_source_hash": bench.kernel_source_hash(), "tag": tag, "unit_not
 lines += ["## Instruction issue of the walk kernels (rocprofv3 --pmc, passes of their own)", "",
           "| kernel | VALU instr | SALU instr | VALU pipe busy % | SALU / CU-cycle % | lane util % | wave: issuing % | waiting for issue % | in s_waitcnt % |",
           "|---|---|---|---|---|---|---|---|---|"]
-for k in ("ct_walk_packet<primary>", "ct_walk_shadow_tree", "ct_walk_packet<shadow>"):
+for k in ("ct_walk_closest_tree", "ct_walk_packet<primary>", "ct_walk_shadow_tree", "ct_walk_packet<shadow>"):
     if k not in stats or not counters[k]["SQ_WAVE_CYCLES"]:
         continue
     c = counters[k]
