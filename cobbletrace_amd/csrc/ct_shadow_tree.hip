@@ -377,7 +377,7 @@ int ctgpu_build_shadow_tree(int device, const void *d_tris, uint32_t n, const ct
         need = ctst::build_shadow_tree(boxes.data(), n, opt, gamma, bound, quads, order, remaining);
     }
     if (need > 63u) return CTGPU_OK;                                         // (the walk's stack: the lanes of a register)
-    if (!ctst::references_to_byte_offsets(quads, n, (uint32_t)sizeof(TriRecord))) return CTGPU_OK;
+    if (!ctst::references_to_byte_offsets(quads, n, (uint32_t)sizeof(TriRecord), remaining)) return CTGPU_OK;
 
     QuadNode *d_quads = nullptr;
     TriRecord *d_records = nullptr;

@@ -574,13 +574,18 @@ inline void pair_up_leaves(std::vector<BinNode> &bin, uint32_t n, float leaf_rho
 }
 
 // What the walk reads: the same nodes with every reference turned into the BYTE OFFSET of what it names (a node: index *
-// 128; a leaf: kLeaf | first record * record_bytes), so that a visit's scalar loads take the reference as it is.
-// false: an offset would not fit below kLeaf.
-inline bool references_to_byte_offsets(std::vector<Quad> &quads, uint32_t n, uint32_t record_bytes) {
-    if ((uint64_t)quads.size() * sizeof(Quad) >= (uint64_t)kLeaf || (uint64_t)n * record_bytes >= (uint64_t)kLeaf) return false;
+// 128; a leaf: kLeaf | first record * record_bytes | its number of triangles - 1 in the four low bits, which a multiple of
+// 16 leaves free), so that a visit's scalar loads take the reference as it is and a leaf's size is known without its
+// records.  false: an offset would not fit below kLeaf, or a leaf holds more than 16 triangles.
+inline bool references_to_byte_offsets(std::vector<Quad> &quads, uint32_t n, uint32_t record_bytes, const std::vector<uint32_t> &remaining) {
+    if ((uint64_t)quads.size() * sizeof(Quad) >= (uint64_t)kLeaf || (uint64_t)n * record_bytes >= (uint64_t)kLeaf || record_bytes % 16u != 0u) return false;
     for (Quad &q : quads)
-        for (int k = 0; k < 4; k++)
-            q.ref[k] = (q.ref[k] & kLeaf) ? (kLeaf | ((q.ref[k] & ~kLeaf) * record_bytes)) : q.ref[k] * (uint32_t)sizeof(Quad);
+        for (int k = 0; k < 4; k++) {
+            if (!(q.ref[k] & kLeaf)) { q.ref[k] *= (uint32_t)sizeof(Quad); continue; }
+            const uint32_t slot = q.ref[k] & ~kLeaf;
+            if (slot >= n || remaining[slot] < 1u || remaining[slot] > 16u) return false;
+            q.ref[k] = kLeaf | (slot * record_bytes) | (remaining[slot] - 1u);
+        }
     return true;
 }
 

@@ -57,6 +57,10 @@ def test_the_tree_in_hbm(name, build, leaf, fill, scenes):
         #  so that a visit's scalar loads take it as it is; back to indices for the checks)
         refs = quads["ref"]
         leafs = (refs & LEAF) != 0
+        # (... and a leaf's reference carries, in the four low bits a multiple of 16 leaves free, its number of triangles - 1:
+        #  the walk notes a leaf's tests without fetching a record)
+        sizes = np.where(leafs, (refs & 15) + 1, 0)
+        refs = np.where(leafs, refs & ~np.uint32(15), refs)
         assert ((refs[leafs] & ~np.uint32(LEAF)) % 80 == 0).all() and (refs[~leafs] % 128 == 0).all()
         quads["ref"] = np.where(leafs, LEAF | ((refs & ~np.uint32(LEAF)) // 80), refs // 128)
         tris = ctx.scene_array(9).view(TRI)
@@ -101,7 +105,7 @@ def test_the_tree_in_hbm(name, build, leaf, fill, scenes):
                 ref = int(q["ref"][k])
                 if ref & LEAF:
                     first = ref & SLOT
-                    assert first < n and starts[first]
+                    assert first < n and starts[first] and int(sizes[at][k]) == int(rem[first])
                     for t in range(first, first + int(rem[first])):
                         assert not seen_tri[t]
                         seen_tri[t] = True
