@@ -204,10 +204,6 @@ struct Walker {
 // with a double wait on every push and pop.)
 typedef StackEntry __attribute__((address_space(3))) LdsEntry;
 typedef uint32_t __attribute__((address_space(3))) LdsWord;
-typedef unsigned long long __attribute__((address_space(3))) LdsPair;
-typedef double __attribute__((address_space(3))) LdsDouble;
-constexpr uint32_t kPairRoom = 128;            // ct_walk_shadow_tree's noted tests: fewer than 64 waiting + at most 64 from one more triangle
-constexpr size_t kShadowTreeLds = 128 * 4 + 64 * 4 + kPairRoom * 8 + 6 * 64 * 8;
 typedef StackEntry __attribute__((address_space(1))) HbmEntry;
 typedef uint32_t __attribute__((address_space(1))) HbmWord;
 
@@ -1725,9 +1721,6 @@ __global__ __launch_bounds__(kWave, CT_STREE_WAVES) void ct_walk_shadow_tree(con
     const uint32_t q_chunk = W.chunk_shadow;
     extern __shared__ __align__(16) unsigned char lds_raw[];
     LdsWord *win_list = (LdsWord *)lds_raw;          // [128] the open window's live ray offsets
-    LdsWord *hit_flag = win_list + 128;              // [64]  per ray of the packet: the record whose test moved its ray.t (kNoNode: none yet)
-    LdsPair *pair_q = (LdsPair *)(hit_flag + 64);    // [kPairRoom] {record offset, lane}: triangle tests waiting for a full wave of them
-    LdsDouble *ray_lds = (LdsDouble *)(pair_q + kPairRoom);      // [6][64] the packet's rays: origin x y z, direction x y z
     const uint32_t lane = threadIdx.x;
     const uint64_t n_samples = W.n_samples;
     const uint32_t n_shards = kShards * W.n_shadow_lights;
@@ -1736,7 +1729,9 @@ __global__ __launch_bounds__(kWave, CT_STREE_WAVES) void ct_walk_shadow_tree(con
     uint32_t shard = blockIdx.x % n_shards, shards_done = 0;
     uint64_t light_base = 0, chunk_light_base = 0;
     uint32_t light_index = 0, chunk_light_index = 0;
+    d3 shadow_o = make_d3(0, 0, 0), d = make_d3(0, 0, 1);
     RayLine rl = RayLine{};
+    float t = kNoHit;
     bool has_ray = false;
     uint64_t ray_id = 0;
     uint64_t chunk_next = 0, chunk_end = 0;
@@ -1846,12 +1841,11 @@ __global__ __launch_bounds__(kWave, CT_STREE_WAVES) void ct_walk_shadow_tree(con
             else (void)sample_position<SS>(P, W, sample, px, py);
             const uint2 h = W.hits[sample];
             const float tclosest = (h.y != kNoNode) ? __uint_as_float(h.x) : kFarAway;
-            const d3 shadow_o = make_d3(P.cam[0], P.cam[1], P.cam[2]) + scale((double)tclosest, primary_direction(P, px, py));
+            shadow_o = make_d3(P.cam[0], P.cam[1], P.cam[2]) + scale((double)tclosest, primary_direction(P, px, py));
             const Light &shadow_light = P.lights[light_index];
-            const d3 d = (shadow_light.type == CTGPU_LIGHT_POINT) ? load_d3(shadow_light.position) - shadow_o
-                                                                  : load_d3(shadow_light.direction);
-            ray_lds[0 * kWave + lane] = shadow_o.x; ray_lds[1 * kWave + lane] = shadow_o.y; ray_lds[2 * kWave + lane] = shadow_o.z;
-            ray_lds[3 * kWave + lane] = d.x; ray_lds[4 * kWave + lane] = d.y; ray_lds[5 * kWave + lane] = d.z;
+            d = (shadow_light.type == CTGPU_LIGHT_POINT) ? load_d3(shadow_light.position) - shadow_o
+                                                         : load_d3(shadow_light.direction);
+            t = kNoHit;
             const d3 inv = make_d3(quick_reciprocal(d.x), quick_reciprocal(d.y), quick_reciprocal(d.z));
             rl.inv_xy = f32x2{(float)inv.x, (float)inv.y};
             rl.noi_xy = f32x2{-(float)(shadow_o.x * inv.x), -(float)(shadow_o.y * inv.y)};
@@ -1886,64 +1880,30 @@ __global__ __launch_bounds__(kWave, CT_STREE_WAVES) void ct_walk_shadow_tree(con
         unsigned long long mask = tracing;
         uint32_t sp = 0;
         int stack_ref = 0, stack_mask_lo = 0, stack_mask_hi = 0;
-        uint32_t hit_at = kNoNode;              // the TriRecord whose test moved this lane's ray.t (byte offset; kNoNode: none)
-        uint32_t q_count = 0;                   // {ray, triangle} tests waiting in pair_q
-        hit_flag[lane] = kNoNode;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        // The triangle tests of a packet, a full wave of them at a time.  A leaf is met by the few lanes whose rays enter
-        // ITS box (a fifth of the packet on average: profiles/r05_issue.json, lane use of the tests), and the test is ~70
-        // binary64 instructions whoever is awake: the walk only NOTES {record, lane} for every such lane and carries on --
-        // no record is fetched on the walk's own chain -- and when 64 notes are there (or the walk is over), lane j makes
-        // the j-th noted test: the noted lane's ray out of LDS, the record by a vector load, the reference's test
-        // (bvh.cpp:147-163), and a hit lands in hit_flag[noted lane].  An any-hit ray's answer does not depend on when, or
-        // in which order, its tests are made (appendix E.0); a ray walks a little further than it had to, that is all.
-        const auto test_noted = [&](uint32_t n) {
-            q_count -= n;
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            if (lane < n) {
-                const unsigned long long note = pair_q[q_count + lane];
-                const uint32_t of = (uint32_t)(note >> 32), record = (uint32_t)note;
-                if (hit_flag[of] == kNoNode) {
-                    const d3 ro = make_d3(ray_lds[0 * kWave + of], ray_lds[1 * kWave + of], ray_lds[2 * kWave + of]);
-                    const d3 rd = make_d3(ray_lds[3 * kWave + of], ray_lds[4 * kWave + of], ray_lds[5 * kWave + of]);
-                    const double2 *rec = reinterpret_cast<const double2 *>(tris_base + record);
-                    const double2 r0 = rec[0], r1 = rec[1], r2 = rec[2], r3 = rec[3];
-                    const double r4 = *reinterpret_cast<const double *>(rec + 4);
-                    float found = kNoHit;
-                    (void)triangle_test(ro, rd, found, make_d3(r0.x, r0.y, r1.x), make_d3(r1.y, r2.x, r2.y), make_d3(r3.x, r3.y, r4));
-                    if (found != kNoHit) hit_flag[of] = record;
-                }
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            hit_at = hit_flag[lane];
-            // (a lane whose ray.t moved stops here; whether the reference would have made that test at all is looked
-            //  at after the walk, once per packet: "the verdict of the leaf's box" below)
-            tracing &= __ballot(hit_at == kNoNode);
-        };
+        uint32_t hit_at = 0u;                   // the TriRecord whose test moved this lane's ray.t
 
         auto shared_walk = [&](auto octant_tag) {
         constexpr int OCT = decltype(octant_tag)::value;
         while (mask != 0ull) {
             if (cur & kLeafBit) {
-                // a leaf: a run of triangles (mostly one or two); the lanes that met its box note its tests
+                // a leaf: a run of triangles (mostly one or two), tested by the lanes that met the leaf's box
                 const uint32_t first = cur & ~(kLeafBit | 15u);      // (byte offset of the leaf's first record)
-                const uint32_t count = (cur & 15u) + 1u;
-                n_records += count;
                 const bool mine = __builtin_amdgcn_inverse_ballot_w64(mask);
-                const uint32_t place = __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
-                const uint32_t met = (uint32_t)__popcll(mask);
+                const uint32_t count = (cur & 15u) + 1u;              // (a leaf's reference says how many: ct_shadow_tree_build.h)
+                n_records += count;
                 for (uint32_t k = 0; k < count; k++) {
-                    if (mine) pair_q[q_count + place] = (unsigned long long)(first + k * (uint32_t)sizeof(TriRecord)) | ((unsigned long long)lane << 32);
-                    q_count += met;
-                    if (q_count >= 64u) {                  // (at most 63 before + 64 now: kPairRoom = 128)
-                        test_noted(64u);
-                        if (tracing == 0ull) break;
+                    const ScalarTri tr = scalar_load_tri_at(tris_base, tris_base64, first + k * (uint32_t)sizeof(TriRecord));
+                    if (mine && t == kNoHit) {
+                        const d3 p1 = make_d3(tr.f64(0), tr.f64(1), tr.f64(2)), e1 = make_d3(tr.f64(3), tr.f64(4), tr.f64(5)),
+                                 e2 = make_d3(tr.f64(6), tr.f64(7), tr.f64(8));
+                        (void)triangle_test(shadow_o, d, t, p1, e1, e2);
+                        if (t != kNoHit) hit_at = first + k * (uint32_t)sizeof(TriRecord);
                     }
                 }
-                if (tracing == 0ull) { sp = 0; q_count = 0; }        // every ray of the packet has its blocker
+                // (a lane whose ray.t moved stops here; whether the reference would have made that test at all is looked
+                //  at after the walk, once per packet: "the verdict of the leaf's box" below)
+                tracing &= __ballot(t == kNoHit);
+                if (tracing == 0ull) sp = 0;               // every ray of the packet has its blocker
                 mask = 0ull;
             } else {
                 n_quads += 1;
@@ -1999,7 +1959,6 @@ __global__ __launch_bounds__(kWave, CT_STREE_WAVES) void ct_walk_shadow_tree(con
             case 7: shared_walk(std::integral_constant<int, 7>{}); break;
             default: shared_walk(std::integral_constant<int, 8>{}); break;
         }
-        if (q_count != 0u) test_noted(q_count);        // (the walk is over: what is still noted, fewer than 64)
 
         // ---------------- the verdict of the leaf's box
         // A triangle test moved the ray's ray.t: would the reference have made that test?  Only inside the triangle's leaf,
@@ -2009,14 +1968,11 @@ __global__ __launch_bounds__(kWave, CT_STREE_WAVES) void ct_walk_shadow_tree(con
         // (the triangle test and the box test disagree at the box's rim: one ray in millions) has stopped half-way through
         // its walk; it is left to the second launch like a ray outside the gate.
         STREE_ARGS();
-        const bool moved = has_ray && hit_at != kNoNode;
-        if (moved) {
+        if (has_ray && t != kNoHit) {
             const ctgpu_node *leaf = P.ref_nodes + P.leaf_of_slot[hit_at / (uint32_t)sizeof(TriRecord)];
             const double4 b0 = *reinterpret_cast<const double4 *>(&leaf->bmin[0]);     // bmin xyz, bmax x
             const double2 b1 = *reinterpret_cast<const double2 *>(&leaf->bmax[1]);     // bmax yz
             const double bmin[3] = {b0.x, b0.y, b0.z}, bmax[3] = {b0.w, b1.x, b1.y};
-            const d3 shadow_o = make_d3(ray_lds[0 * kWave + lane], ray_lds[1 * kWave + lane], ray_lds[2 * kWave + lane]);
-            const d3 d = make_d3(ray_lds[3 * kWave + lane], ray_lds[4 * kWave + lane], ray_lds[5 * kWave + lane]);
             const d3 inv = make_d3(quick_reciprocal(d.x), quick_reciprocal(d.y), quick_reciprocal(d.z));
             float tmin64, tmax64;
             bool verdict;
@@ -2028,18 +1984,18 @@ __global__ __launch_bounds__(kWave, CT_STREE_WAVES) void ct_walk_shadow_tree(con
             if (!verdict) { W.shadow[ray_id] = kShadowLeft; has_ray = false; left = true; }
         }
         {
-            const uint32_t undone = (uint32_t)__popcll(__ballot(left && moved));
+            const uint32_t undone = (uint32_t)__popcll(__ballot(left && t != kNoHit));
             n_left += undone;
             n_traced -= undone;
         }
         // ---------------- retire the packet
         if (ORDERED && lane == 0) atomicAdd(W.order[1].cost_out + cost_at, n_quads + n_records - cost_mark);
         {
-            const unsigned long long blocked = __ballot(has_ray && moved);
+            const unsigned long long blocked = __ballot(has_ray && t != kNoHit);
             n_blocked += (uint32_t)__popcll(blocked);
             n_all_blocked += (blocked == rays) ? 1u : 0u;
         }
-        if (has_ray && moved) W.shadow[ray_id] = 1;
+        if (has_ray && t != kNoHit) W.shadow[ray_id] = 1;
     }
 
     if (lane == 0) {
@@ -2814,10 +2770,10 @@ int pipeline_stree_occupancy() {
     int c = 0, e = 0, f = 0, g = 0;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&f, ct_walk_closest_tree<true>, kWave, (size_t)kClosestLdsLevels * kWave * sizeof(float));
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&g, ct_walk_closest_tree<false>, kWave, (size_t)kClosestLdsLevels * kWave * sizeof(float));
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, ct_walk_shadow_tree<true, false>, kWave, kShadowTreeLds);
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, ct_walk_shadow_tree<false, false>, kWave, kShadowTreeLds);
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, ct_walk_shadow_tree<true, true>, kWave, kShadowTreeLds);
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&e, ct_walk_shadow_tree<false, true>, kWave, kShadowTreeLds);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, ct_walk_shadow_tree<true, false>, kWave, 512);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&b, ct_walk_shadow_tree<false, false>, kWave, 512);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&c, ct_walk_shadow_tree<true, true>, kWave, 512);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&e, ct_walk_shadow_tree<false, true>, kWave, 512);
     return std::min(std::min(std::min(a, b), std::min(c, e)), std::min(f, g));
 }
 
@@ -2962,10 +2918,10 @@ void launch_pipeline(const FrameParams &P, const PipelineParams &W, bool ss, hip
             // the shadow tree takes the frame's shadow rays; what it leaves (rays outside its gate: shadow byte kShadowLeft,
             // counted in *W.shadow_left) goes through the reference's tree in a launch whose waves return at once on zero
             const dim3 grid_s(W.stree_blocks ? W.stree_blocks : W.walk_blocks);
-            if (ss && ordered) hipLaunchKernelGGL((ct_walk_shadow_tree<true, true>), grid_s, wave, kShadowTreeLds, stream, P, W);
-            if (ss && !ordered) hipLaunchKernelGGL((ct_walk_shadow_tree<true, false>), grid_s, wave, kShadowTreeLds, stream, P, W);
-            if (!ss && ordered) hipLaunchKernelGGL((ct_walk_shadow_tree<false, true>), grid_s, wave, kShadowTreeLds, stream, P, W);
-            if (!ss && !ordered) hipLaunchKernelGGL((ct_walk_shadow_tree<false, false>), grid_s, wave, kShadowTreeLds, stream, P, W);
+            if (ss && ordered) hipLaunchKernelGGL((ct_walk_shadow_tree<true, true>), grid_s, wave, 512, stream, P, W);
+            if (ss && !ordered) hipLaunchKernelGGL((ct_walk_shadow_tree<true, false>), grid_s, wave, 512, stream, P, W);
+            if (!ss && ordered) hipLaunchKernelGGL((ct_walk_shadow_tree<false, true>), grid_s, wave, 512, stream, P, W);
+            if (!ss && !ordered) hipLaunchKernelGGL((ct_walk_shadow_tree<false, false>), grid_s, wave, 512, stream, P, W);
             PipelineParams Wl = W;
             Wl.shadow_live = kShadowLeft;
             launch_frame_walk<1>(ss, false, false, P.cull_first != kNoNode, grid, wave, lds_p, stream, P, Wl);
