@@ -2,7 +2,7 @@
 # tools/r05_evidence.sh -- on the GPU box: round 5's profiles in one go (gpurun_out/r05_*): the default bench under rocprofv3
 # (kernel stats, HBM traffic, issue counters: tools/collect_profiles.sh), per-kernel stats and issue counters of C5
 # (3840x2160 x 16: BASELINE configs[4]), the configs table, and the fuzz tools with every frame's shadow rays through the
-# shadow tree.
+# shadow tree, and once more with the primary rays through it as well.
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 cd $R
@@ -18,4 +18,6 @@ echo "c5 done"
 cd $R && python3 tools/run_configs.py > $O/r05_configs.log 2>&1 || exit 1
 CTGPU_SHADOW_TREE=2 timeout -k 10 150 python3 tools/fuzz_parity.py 100 5001 > $O/r05_fuzz_scenes.log 2>&1; echo "fuzz scenes rc $?" >> $O/r05_fuzz_scenes.log
 CTGPU_SHADOW_TREE=2 timeout -k 10 150 python3 tools/fuzz_views.py 100 7001 > $O/r05_fuzz_views.log 2>&1; echo "fuzz views rc $?" >> $O/r05_fuzz_views.log
-tail -2 $O/r05_fuzz_scenes.log $O/r05_fuzz_views.log
+CTGPU_SHADOW_TREE=2 CTGPU_CLOSEST_TREE=2 CTGPU_ORDER=0 timeout -k 10 120 python3 tools/fuzz_parity.py 100 6001 > $O/r05_fuzz_scenes_closest.log 2>&1; echo "fuzz scenes rc $?" >> $O/r05_fuzz_scenes_closest.log
+CTGPU_SHADOW_TREE=2 CTGPU_CLOSEST_TREE=2 CTGPU_ORDER=0 timeout -k 10 120 python3 tools/fuzz_views.py 100 8001 > $O/r05_fuzz_views_closest.log 2>&1; echo "fuzz views rc $?" >> $O/r05_fuzz_views_closest.log
+tail -q -n 2 $O/r05_fuzz_scenes.log $O/r05_fuzz_views.log $O/r05_fuzz_scenes_closest.log $O/r05_fuzz_views_closest.log
