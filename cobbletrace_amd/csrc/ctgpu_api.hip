@@ -330,7 +330,7 @@ extern "C" int ctgpu_default_config(ctgpu_config *c) {
     for (int k = 0; k < 4; k++) { c->order_heavy[k] = heavy[k]; c->order_parts[k] = parts[k]; }
     c->order_floor = 64; c->order_split_below = 8;
     c->big_leaf_min = 8; c->big_leaf_share = 20;
-    c->shadow_tree = 1; c->shadow_tree_build = 0; c->shadow_tree_leaf = 2; c->shadow_tree_leaf_fill = 50;
+    c->shadow_tree = 2; c->shadow_tree_build = 0; c->shadow_tree_leaf = 2; c->shadow_tree_leaf_fill = 50;      // (2: every frame -- single-sample frames' shadow walks gain 3-15 % too, profiles/r05_single_sample.log)
     c->closest_tree = 1;
     c->shadow_split_gap = -1.0f;
     const int thresh[3] = {40, 20, 12}, walk_thresh[3] = {64, 32, 24};       // (measured best on MI355X)

@@ -225,7 +225,7 @@ typedef struct ctgpu_config {
     int32_t big_leaf_min;         /* CTGPU_BIG_LEAF       leaves of at least this many triangles get cull nodes (0: none) */
     int32_t big_leaf_share;       /* CTGPU_BIG_LEAF_SHARE ... in scenes where at least this percentage of the triangles sits in such leaves */
     int32_t shadow_tree;          /* CTGPU_SHADOW_TREE    the frame's shadow rays walk a tree of this library's own over the same triangles (order-free
-                                     any-hit query, raythread.cpp:303-307; DESIGN appendix E): 0 never, 1 supersampled frames (default), 2 every frame */
+                                     any-hit query, raythread.cpp:303-307; DESIGN appendix E): 0 never, 1 supersampled frames only, 2 every frame (default) */
     int32_t closest_tree;         /* CTGPU_CLOSEST_TREE   the frame's PRIMARY rays walk that tree too (the least t over every test the reference
                                      could make, the winner checked against the reference's own leaf box; DESIGN appendix F): 0 never, 1
                                      supersampled frames (default), 2 every frame.  Needs shadow_tree != 0 (it is the same tree) */

@@ -227,7 +227,8 @@ def test_frames_with_and_without_cull_nodes(ss, scenes, monkeypatch):
     want, _ = _oracle().render(scene.desc, frame)
     records = {}
     for big in (4, 0):
-        ctx = _context(monkeypatch, scene, CTGPU_BIG_LEAF=big)
+        # (the count below is of the walks of the reference's tree, where the cull nodes live: the trees of appendix E / F off)
+        ctx = _context(monkeypatch, scene, CTGPU_BIG_LEAF=big, CTGPU_SHADOW_TREE=0, CTGPU_CLOSEST_TREE=0)
         try:
             ctx.read_walk_work()
             fb, st = ctx.render(frame)
