@@ -314,8 +314,10 @@ def main():
     inflight = args.inflight if args.inflight > 0 else 4
     # Throughput tuning through the library's documented knobs (read at context creation): with several
     # frames in flight and only an eighth of the frame per rank, a smaller persistent grid per context
-    # and 128-ray-id chunks beat the defaults, which are tuned for one frame's latency.
-    if inflight > 1 and world >= 8:
+    # and 128-ray-id chunks beat the defaults, which are tuned for one frame's latency (DESIGN.md section 6;
+    # profiles/r05_rank_share.log, rank 0's share rehearsed on one GPU: a quarter of the frame 0.62 -> 0.56 ms, an eighth
+    # 0.47 -> 0.30 ms, a half and the whole frame the same either way).
+    if inflight > 1 and world >= 4:
         os.environ.setdefault("CTGPU_BLOCKS_PER_CU", "12")
         os.environ.setdefault("CTGPU_CHUNK", "128")
 

@@ -2031,7 +2031,13 @@ __global__ __launch_bounds__(kWave, CT_STREE_WAVES) void ct_walk_shadow_tree(con
 // ids: four pixels' samples), same stack in the lanes of three registers; the per-lane tmin of a waiting entry sits in LDS
 // for the first kClosestLdsLevels levels (deeper ones are not pruned when popped, only when visited).
 // ------------------------------------------------------------------------------------
-constexpr uint32_t kClosestLdsLevels = 16;
+#ifndef CT_CLOSEST_WAVES
+#define CT_CLOSEST_WAVES 7
+#endif
+#ifndef CT_CLOSEST_LDS_LEVELS
+#define CT_CLOSEST_LDS_LEVELS 16
+#endif
+constexpr uint32_t kClosestLdsLevels = CT_CLOSEST_LDS_LEVELS;
 #define CT_CLOSEST_ENTRY(OUT, TMIN, PX, PY, PZ, NX, FX, NY, FY, NZ, FZ)                                \
     "v_pk_fma_f32 v[56:57], " PX ", %20, %21 op_sel_hi:[1,0,0]\n\t"                                   \
     "v_pk_fma_f32 v[58:59], " PY ", %20, %21 op_sel:[0,1,1] op_sel_hi:[1,1,1]\n\t"                    \
@@ -2090,7 +2096,7 @@ __device__ __forceinline__ bool line_enters_closest(const RayLine &r, f32x2 px, 
 __device__ __forceinline__ float closest_limit(float t, float tau) { return t >= tau ? t * (1.0f + 0x1p-18f) : __builtin_inff(); }
 
 template <bool SS>
-__global__ __launch_bounds__(kWave, CT_STREE_WAVES) void ct_walk_closest_tree(const FrameParams P_launch, const PipelineParams W_launch) {
+__global__ __launch_bounds__(kWave, CT_CLOSEST_WAVES) void ct_walk_closest_tree(const FrameParams P_launch, const PipelineParams W_launch) {
     FrameParams P = P_launch;
     PipelineParams W = W_launch;
     const uint32_t q_chunk = W.chunk;

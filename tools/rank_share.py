@@ -50,6 +50,8 @@ for world in ints("WORLDS", "1,2,4,8"):
                     one(i)
                 torch.cuda.synchronize()
                 ms = (time.perf_counter() - t0) / n_frames * 1e3
-                print("%s world %d blocks/CU %2d chunk %3d inflight %d: %.3f ms per frame on rank 0" % (name, world, blocks, chunk, inflight, ms), flush=True)
+                st = slots[0][0].read_counters()
+                print("%s world %d blocks/CU %2d chunk %3d inflight %d: %.3f ms per frame on rank 0  (walks: %s)" % (
+                    name, world, blocks, chunk, inflight, ms, ", ".join(k for k in ("ordered", "cull_tree", "shadow_tree", "closest_tree") if st.path()[k]) or "reference's tree"), flush=True)
                 for s in slots:
                     s[0].close()
