@@ -239,8 +239,11 @@ struct ctgpu_ctx {
     // The closest-hit walk of the shadow tree's nodes leaves a ray whose winner sits on the rim of its leaf's box to the walk of the
     // reference's tree; in scenes of axis-aligned flat geometry (a floor, the faces of the rounded cubes) that is every hit on such
     // a face, and the frame pays both walks.  A context that sees more than a sixteenth of a frame's primary rays left keeps the
-    // reference's tree for its primary rays from then on (same pixels either way; a new scene starts over).
+    // reference's tree for its primary rays from then on (same pixels either way; a new scene starts over) -- and looks again
+    // every kClosestRetry frames: the camera may have turned from the floor to the statue (one frame in 256 at the worse rate).
     bool closest_off = false;
+    uint32_t closest_off_frames = 0;
+    static constexpr uint32_t kClosestRetry = 256;
     struct Path { uint32_t walk_kind = 0, bounce_kind = 0, ordered = 0, cull_tree = 0, shadow_tree = 0, closest_tree = 0; } path;     // what the latest frame ran on (ctgpu_stats)
     int big_leaf_min = 8;                       // CTGPU_BIG_LEAF: leaves of at least this many triangles go through the triangle boxes (0: off)
     int big_leaf_share = 20;                    // CTGPU_BIG_LEAF_SHARE: ... and only in scenes where at least this percentage of all triangles sits in such leaves
@@ -1087,7 +1090,9 @@ int fill_params(ctgpu_ctx *ctx, const ctgpu_frame_desc *f, const ctgpu_partition
         // binary32 arithmetic, |eye_i| <= o_max like a shadow ray's origin (a far-away camera keeps the reference's tree)
         const bool eye_inside = std::fabs(f->cam_pos[0]) <= ctx->scene->stree_lim.o_max && std::fabs(f->cam_pos[1]) <= ctx->scene->stree_lim.o_max &&
                                 std::fabs(f->cam_pos[2]) <= ctx->scene->stree_lim.o_max;
-        if (eye_inside && !ctx->closest_off && (ctx->cfg.closest_tree == 2 || (ctx->cfg.closest_tree == 1 && (f->flags & CTGPU_F_SUPERSAMPLE) != 0))) {
+        const bool wanted = eye_inside && (ctx->cfg.closest_tree == 2 || (ctx->cfg.closest_tree == 1 && (f->flags & CTGPU_F_SUPERSAMPLE) != 0));
+        if (wanted && ctx->closest_off && ++ctx->closest_off_frames >= ctgpu_ctx::kClosestRetry) ctx->closest_off = false;
+        if (wanted && !ctx->closest_off) {
             P.closest_tree = 1u;
             P.closest_tau = ctx->scene->stree_tau;
         }
@@ -1199,7 +1204,7 @@ int read_counters(ctgpu_ctx *ctx, ctgpu_stats *st) {
         st->rays_shadow_left = c[kCounterLeft];
         st->rays_primary_left = c[kCounterPrimaryLeft];
         st->closest_tree = ctx->path.closest_tree;
-        if (ctx->path.closest_tree && c[kCounterPrimaryLeft] * 16ull > c[0]) ctx->closest_off = true;
+        if (ctx->path.closest_tree && c[kCounterPrimaryLeft] * 16ull > c[0]) { ctx->closest_off = true; ctx->closest_off_frames = 0; }
         st->walk_kind = ctx->path.walk_kind; st->bounce_kind = ctx->path.bounce_kind; st->ordered = ctx->path.ordered;
         st->cull_tree = ctx->path.cull_tree; st->shadow_tree = ctx->path.shadow_tree;
     }

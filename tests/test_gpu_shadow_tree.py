@@ -251,6 +251,52 @@ def test_primary_rays_through_the_tree(name, size, scenes):
         ref.close(); tree.close()
 
 
+def test_a_context_that_went_back_looks_again(scenes):
+    """The import scene hands a third of its primary rays back (flat axis-aligned faces: appendix F.4), so its context keeps the
+    reference's tree after the first frame -- and tries the tree again every 256 frames, in case the camera now looks at
+    something else.  Same pixels on every frame of the way."""
+    scene = scenes("import")
+    tree = _context(2, scene.desc, closest=2, order=0)
+    try:
+        frame = scene.frame(192, 108, supersampling=True, rng_seed=1)
+        want = None
+        took = []
+        for k in range(1, 260):
+            got, st = tree.render(frame)
+            want = got.copy() if want is None else want
+            assert (got == want).all(), k
+            if st.closest_tree:
+                took.append(k)
+                assert st.rays_primary_left > 0
+        assert took == [1, 257], took
+        ref, _ = _oracle().render(scene.desc, frame, os_threads=4)
+        assert (want == ref).all()
+    finally:
+        tree.close()
+
+
+def test_an_eye_far_away_keeps_the_references_tree(scenes):
+    """The boxes' growth covers the binary32 arithmetic for origins within o_max = 2 V of the scene (appendix E.1); a shadow
+    ray starts on a surface, a primary ray at the eye -- wherever the caller puts it.  A camera beyond that (checked by the
+    host, per frame) keeps the reference's tree for its primary rays; its shadow rays still start on surfaces and walk the
+    shadow tree.  Moved back inside, the next frame's primary rays take the tree again.  Rotated cameras as well."""
+    scene = scenes("bunny")
+    tree = _context(2, scene.desc, closest=2, order=0)
+    try:
+        near = scene.frame(480, 270, supersampling=True, rng_seed=6)
+        far = scene.frame(480, 270, supersampling=True, rng_seed=6)
+        extent = float(np.abs(np.ctypeslib.as_array(scene.desc.vertices, shape=(scene.desc.n_triangles * 9,))).max())
+        far.cam_pos = (C.c_double * 3)(near.cam_pos[0] * 0.5, near.cam_pos[1], -(40.0 * extent + 50.0))
+        turned = scene.frame(480, 270, supersampling=True, rng_seed=6, rotation=ca.camera_rotation(0.21, -0.13, 0.05))
+        for frame, expected in ((near, 1), (far, 0), (turned, 1), (near, 1)):
+            got, st = tree.render(frame)
+            want, _ = _oracle().render(scene.desc, frame, os_threads=4)
+            assert (got == want).all(), int((got != want).sum())
+            assert st.closest_tree == expected and st.shadow_tree == 1
+    finally:
+        tree.close()
+
+
 def test_equal_t_goes_to_the_triangle_the_reference_meets_first(tmp_path):
     """bvh.cpp:212 records a triangle only when it lowers ray.t STRICTLY: of several triangles hit at the same t the one the
     reference's walk meets first wins, and with it its colour.  Stacks of coincident triangles in different colours, in a
