@@ -1730,10 +1730,10 @@ __global__ __launch_bounds__(kWave, CT_STREE_WAVES) void ct_walk_shadow_tree(con
     uint64_t light_base = 0, chunk_light_base = 0;
     uint32_t light_index = 0, chunk_light_index = 0;
     d3 shadow_o = make_d3(0, 0, 0), d = make_d3(0, 0, 1);
-    RayLine rl = RayLine{};
     float t = kNoHit;
     bool has_ray = false;
-    uint64_t ray_id = 0;
+    uint32_t ray_at = 0;               // the ray's id = ray_base (the packet's window: the same for all its lanes) + ray_at
+    uint64_t ray_base = 0;
     uint64_t chunk_next = 0, chunk_end = 0;
     bool wave_drained = false;
     uint32_t n_traced = 0, n_left = 0;
@@ -1749,7 +1749,8 @@ __global__ __launch_bounds__(kWave, CT_STREE_WAVES) void ct_walk_shadow_tree(con
         for (;;) {
             if (win_pos < win_count) {
                 const uint32_t n = win_count - win_pos < 64u ? win_count - win_pos : 64u;
-                if (lane < n) { ray_id = win_base + win_list[win_pos + lane]; has_ray = true; }
+                ray_base = win_base;
+                if (lane < n) { ray_at = win_list[win_pos + lane]; has_ray = true; }
                 win_pos += n;
                 break;
             }
@@ -1833,9 +1834,10 @@ __global__ __launch_bounds__(kWave, CT_STREE_WAVES) void ct_walk_shadow_tree(con
         if (ORDERED) cost_mark = n_quads + n_records;
         // ---------------- the rays (raythread.cpp:360, 289-303), and which of them the shadow tree takes
         STREE_ARGS();
+        RayLine rl = RayLine{};                  // (per packet: nothing of it is carried from one packet to the next)
         bool left = false;
         if (has_ray) {
-            const uint64_t sample = ray_id - light_base;
+            const uint64_t sample = (ray_base - light_base) + ray_at;
             float px, py;
             if (SS) { const float2 c = W.coords[sample]; px = c.x; py = c.y; }
             else (void)sample_position<SS>(P, W, sample, px, py);
@@ -1857,7 +1859,7 @@ __global__ __launch_bounds__(kWave, CT_STREE_WAVES) void ct_walk_shadow_tree(con
             const bool inside = ax >= d_min && ax <= d_max && ay >= d_min && ay <= d_max && az >= d_min && az <= d_max &&
                                 __builtin_fabs(shadow_o.x) <= o_max && __builtin_fabs(shadow_o.y) <= o_max && __builtin_fabs(shadow_o.z) <= o_max;
             left = !inside;
-            if (left) { W.shadow[ray_id] = kShadowLeft; has_ray = false; }
+            if (left) { W.shadow[ray_base + ray_at] = kShadowLeft; has_ray = false; }
         }
         n_left += (uint32_t)__popcll(__ballot(left));
         unsigned long long tracing = __ballot(has_ray);
@@ -1981,7 +1983,7 @@ __global__ __launch_bounds__(kWave, CT_STREE_WAVES) void ct_walk_shadow_tree(con
                 (void)slab_in_sequence(shadow_o, d, bmin, bmax, tmin64, tmax64);
                 verdict = tmax64 >= tmin64 && tmin64 < kNoHit && tmax64 > 0;
             }
-            if (!verdict) { W.shadow[ray_id] = kShadowLeft; has_ray = false; left = true; }
+            if (!verdict) { W.shadow[ray_base + ray_at] = kShadowLeft; has_ray = false; left = true; }
         }
         {
             const uint32_t undone = (uint32_t)__popcll(__ballot(left && t != kNoHit));
@@ -1995,7 +1997,7 @@ __global__ __launch_bounds__(kWave, CT_STREE_WAVES) void ct_walk_shadow_tree(con
             n_blocked += (uint32_t)__popcll(blocked);
             n_all_blocked += (blocked == rays) ? 1u : 0u;
         }
-        if (has_ray && t != kNoHit) W.shadow[ray_id] = 1;
+        if (has_ray && t != kNoHit) W.shadow[ray_base + ray_at] = 1;
     }
 
     if (lane == 0) {
