@@ -2164,6 +2164,7 @@ __global__ __launch_bounds__(kWave, CT_CLOSEST_WAVES) void ct_walk_closest_tree(
             left = !(ax >= d_min && ax <= d_max && ay >= d_min && ay <= d_max && az >= d_min && az <= d_max);      // (the eye itself: checked by the host)
         }
         float t = kNoHit, limit = __builtin_inff();
+        float t_other = kNoHit;                   // the least t over every tested triangle but the winner (appendix F.1, promise 3)
         uint32_t best = kNoNode;                  // the winner's place in the reference's order (= its TriRecord slot there)
         uint32_t hit_at = 0u;                     // ... and the byte offset of its record in the tree's own order
         const unsigned long long rays = __ballot(has_ray && !left);
@@ -2200,6 +2201,9 @@ __global__ __launch_bounds__(kWave, CT_CLOSEST_WAVES) void ct_walk_closest_tree(
                         (void)triangle_test(eye, d, found, p1, e1, e2);
                         const uint32_t place = (uint32_t)tr.b[2];          // (this tree's records carry their slot in the reference's order)
                         // the least t; among equal ones the triangle the reference meets first (bvh.cpp:212: strict <)
+                        // (the least over all tested but the winner: a new winner hands its t down, anything else competes
+                        //  with its own -- min(t_other, max(found, t)) in both cases, and 1e30f where the test found nothing)
+                        t_other = lesser(t_other, greater(found, t));
                         if (found < t || (found == t && found != kNoHit && place < best)) {
                             t = found; best = place; hit_at = first + k * (uint32_t)sizeof(TriRecord);
                             limit = closest_limit(t, tau);
@@ -2273,9 +2277,13 @@ __global__ __launch_bounds__(kWave, CT_CLOSEST_WAVES) void ct_walk_closest_tree(
             default: shared_walk(std::integral_constant<int, 8>{}); break;
         }
         // ---------------- the winner's leaf: does the reference test it, whatever it has found before?  Its leaf's box
-        // with ray.t = the winner's own t (bvh.cpp:165-179): tmax >= tmin, tmax > 0, and tmin < t -- certain then for every
-        // ray.t the reference can carry when it comes to that leaf (all >= t, the least of its tests); the ancestors follow
-        // (nested boxes, ray.t only shrinks: appendix B2).  Not certain: the ray is left.
+        // (bvh.cpp:165-179): tmax >= tmin, tmax > 0, and tmin below every ray.t the reference can carry when it comes to that
+        // leaf.  That ray.t is the least t_i over triangles it tested BEFORE the leaf: each of them was either tested by this
+        // walk too -- t_i >= t_other, the least over all this lane tested but the winner -- or lay beyond the walk's limit when
+        // it was skipped: t_i > t (1 + 2^-19) (appendix F.1).  So tmin < min(t_other, t (1 + 2^-19)) settles it; the ancestors
+        // follow (nested boxes, they are met with a ray.t no smaller: appendix B2).  A hit on the rim of a flat leaf's box,
+        // where tmin and t are two roundings of one number, passes unless another tested triangle sits at (nearly) the same
+        // t.  Not certain: the ray is left.
         if (has_ray && !left && t != kNoHit) {
             const ctgpu_node *leaf = P.ref_nodes + P.leaf_of_slot[hit_at / (uint32_t)sizeof(TriRecord)];
             const double4 b0 = *reinterpret_cast<const double4 *>(&leaf->bmin[0]);
@@ -2284,10 +2292,11 @@ __global__ __launch_bounds__(kWave, CT_CLOSEST_WAVES) void ct_walk_closest_tree(
             const d3 inv = make_d3(quick_reciprocal(d.x), quick_reciprocal(d.y), quick_reciprocal(d.z));
             float tmin64, tmax64;
             bool verdict;
+            const float carried = lesser(t_other, t * (1.0f + 0x1p-19f));
             slab_approx(eye, inv, bmin, bmax, tmin64, tmax64);
-            if (!box_verdict_positive_t(tmin64, tmax64, t, verdict)) {
+            if (!box_verdict_positive_t(tmin64, tmax64, carried, verdict)) {
                 (void)slab_in_sequence(eye, d, bmin, bmax, tmin64, tmax64);
-                verdict = tmax64 >= tmin64 && tmin64 < t && tmax64 > 0;
+                verdict = tmax64 >= tmin64 && tmin64 < carried && tmax64 > 0;
             }
             left = !verdict;
         }
