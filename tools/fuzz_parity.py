@@ -15,6 +15,7 @@ tmp = tempfile.mkdtemp()
 t_end = time.time() + budget
 n_scenes = n_frames = n_rays = 0
 worst = 0
+n_tree = [0, 0]
 while time.time() < t_end:
     rng = np.random.default_rng(seed)
     n = int(rng.choice([1, 2, 3, 7, 40, 300, 2500]))
@@ -37,6 +38,12 @@ while time.time() < t_end:
         tris.append({"type": "triangle", "p1": [float("%.6g" % v) for v in p[0]], "p2": [float("%.6g" % v) for v in p[1]],
                      "p3": [float("%.6g" % v) for v in p[2]], "color": [int(v) for v in rng.integers(0, 256, 3)],
                      "specular": int(rng.choice([-1, 1, 10, 100, 1000])), "reflection": float(rng.choice([0, 0, 0, 0.3]))})
+    # a sixth of the scenes: some triangles once or twice more, vertex for vertex, in another colour and somewhere else in the
+    # list -- equal t, and the first the reference's walk meets must win (bvh.cpp:212; DESIGN appendix F.1)
+    if rng.random() < 0.17 and tris:
+        for i in rng.integers(0, len(tris), max(1, len(tris) // 4)):
+            twin = dict(tris[int(i)], color=[int(v) for v in rng.integers(0, 256, 3)])
+            tris.insert(int(rng.integers(0, len(tris) + 1)), twin)
     use_spheres = rng.random() < 0.3
     if use_spheres:
         for _ in range(int(rng.integers(1, 6))):
@@ -110,11 +117,14 @@ while time.time() < t_end:
     n_scenes += 1
     n_frames += 3
     n_rays += 3 * m
-    print("seed %d: %d triangles%s, scale %g, %dx%d ss=%d sub=%d flags %d rng %d lights %d: max diff %d, %d px differ, rays %s" %
-          (seed, n, " (clustered, %d cull nodes)" % (len(ctx_cull) // 128) if clustered else "", scale, w, h, bool(frame.flags & 1), bool(frame.flags & 2), frame.flags >> 2, frame.rng_mode, len(lights), diff, int((got != want).sum()),
+    n_tree[0] += st.shadow_tree; n_tree[1] += st.closest_tree
+    print("seed %d: %d triangles%s%s, scale %g, %dx%d ss=%d sub=%d flags %d rng %d lights %d: max diff %d, %d px differ, rays %s" %
+          (seed, n, " (clustered, %d cull nodes)" % (len(ctx_cull) // 128) if clustered else "",
+           " [%s]" % "+".join(k for k, on in (("shadow tree", st.shadow_tree), ("primary rays through it", st.closest_tree)) if on) if st.shadow_tree else "", scale, w, h, bool(frame.flags & 1), bool(frame.flags & 2), frame.flags >> 2, frame.rng_mode, len(lights), diff, int((got != want).sum()),
            "equal" if ray_ok else "DIFFER"), flush=True)
     if not ok or not ray_ok:
         print("MISMATCH at seed %d (scene kept in %s)" % (seed, path))
         sys.exit(1)
     seed += 1
-print("%d scenes, %d frames, %d rays: no difference beyond %d LSB" % (n_scenes, n_frames, n_rays, worst))
+print("%d scenes (%d with the shadow rays through the shadow tree, %d with the primary rays too), %d frames, %d rays: no difference beyond %d LSB" %
+      (n_scenes, n_tree[0], n_tree[1], n_frames, n_rays, worst))
