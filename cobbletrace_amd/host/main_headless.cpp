@@ -15,7 +15,8 @@ static void usage() {
     std::fprintf(stderr,
                  "cobbletrace_headless scenefile [--width W] [--height H] [--out image.ppm]\n"
                  "                     [--rng hash|libc] [--seed N] [--device N] [--gpus N] [--keys wasd...] [--async] [--spheres] [--reflect-fix]\n\n"
-                 "To run cobbletrace provide a scene file.  See assets/scene_file_1.json for an example.\n");
+                 "Renders the scene file's view (and one more frame per key of --keys) on the GPU and writes the last frame.\n"
+                 "Scene files: assets/*.json (the reference's format).  Like the reference's Help(), this leaves with status 0.\n");
     std::exit(0);
 }
 

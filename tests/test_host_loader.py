@@ -297,7 +297,7 @@ def test_viewer_builds_against_the_sdl_double():
     exe = os.path.join(ROOT, "cobbletrace_amd", "host", "cobbletrace_viewer_double")
     assert os.path.exists(exe), "make -C cobbletrace_amd/host"
     proc = subprocess.run([exe], capture_output=True, text=True, timeout=60)
-    assert proc.returncode == 0 and "provide a scene file" in proc.stderr
+    assert proc.returncode == 0 and "usage: cobbletrace_viewer scene.json" in proc.stderr
 
 
 def test_blit_is_a_frame_sink_without_sdl(tmp_path, monkeypatch):
